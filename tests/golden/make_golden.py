@@ -1,0 +1,409 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    OMP_NUM_THREADS=1 MKL_NUM_THREADS=1 python tests/golden/make_golden.py
+
+The reference (YuanchenBei/ColdRec, pure Python) is imported in place -- nothing of
+its source is copied; only inputs and the outputs it computes are stored, as small
+``.npz`` files.  ``model/__init__.py`` of the reference imports faiss (absent here), so
+``model`` is registered as a bare namespace package and ``model.MF`` /
+``model.LightGCN`` are imported directly.
+
+Fixtures (ids refer to SURVEY.md section 8(c)):
+  toy_item.npz / toy_user.npz  the toy split fed to the reference + its id tables
+  g1_sampler.npz   util/utils.py:123-157   next_batch_pairwise triples, 3 epochs
+  g2_loss.npz      util/utils.py:25-29,44-48  bpr_loss / l2_reg_loss + autograd grads
+  g3_mf.npz        model/MF.py:12-29       per-step losses, tables after 1/10/50 Adam steps
+  g4_graph.npz     util/databuilder.py:220-254  normalised bipartite adjacency (CSR)
+  g5_lgcn.npz      model/LightGCN.py:86-96  encoder outputs L=1..3, 20 training steps
+  g6_eval_*.npz    model/BaseRecommender.py:109-188  _evaluate top-k for all/warm/cold
+  g7_metrics.npz   util/evaluator.py:153-187  ranking_evaluation on the g6 lists
+  g8_e2e.json      model/BaseRecommender.py:353-370  MF.run() d=64, 3 epochs, test metrics
+"""
+import json
+import os
+import sys
+import types
+from argparse import Namespace
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
+
+import numpy as np
+import torch
+
+torch.set_num_threads(1)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+_m = types.ModuleType("model")
+_m.__path__ = [os.path.join(REF, "model")]
+sys.modules["model"] = _m
+
+from util.utils import next_batch_pairwise, bpr_loss, l2_reg_loss, set_seed  # noqa: E402  (reference)
+from util.databuilder import ColdStartDataBuilder, TorchGraphInterface  # noqa: E402  (reference)
+from util.evaluator import ranking_evaluation  # noqa: E402  (reference)
+from model.MF import MF, Matrix_Factorization  # noqa: E402  (reference)
+from model.LightGCN import LightGCN, LGCN_Encoder  # noqa: E402  (reference)
+
+from coldrec_amd.data.synth import make_dataset  # noqa: E402  (ours: input generator only)
+
+
+def out(name):
+    return os.path.join(HERE, name)
+
+
+def ref_builder(split):
+    info = split.info
+    return ColdStartDataBuilder(
+        split.as_lists("warm_train"), split.as_lists("warm_val"), split.as_lists("cold_val"),
+        split.as_lists("overall_val"), split.as_lists("warm_test"), split.as_lists("cold_test"),
+        split.as_lists("overall_test"), info["user_num"], info["item_num"],
+        info["warm_user"], info["warm_item"], info["cold_user"], info["cold_item"],
+        split.content if split.cold_object == "user" else None,
+        split.content if split.cold_object == "item" else None)
+
+
+def ref_args(**kw):
+    a = dict(dataset="toy", model="MF", epochs=3, layers=2, topN="10,20", bs=512, emb_size=64,
+             lr=0.001, reg=0.0001, runs=1, seed=2024, use_gpu=False, save_emb=False, gpu_id=0,
+             cold_object="item", backbone="MF", early_stop=10, eval_every=1)
+    a.update(kw)
+    return Namespace(**a)
+
+
+def ref_config(data, **kw):
+    return types.SimpleNamespace(args=ref_args(**kw), data=data, device=torch.device("cpu"))
+
+
+def dump_split(split, data, fname):
+    """Inputs + the id tables / sets the reference builder derived from them."""
+    n_u, n_i = len(data.user), len(data.item)
+    user_keys = np.array([data.id2user[k] for k in range(n_u)], dtype=np.int64)
+    item_keys = np.array([data.id2item[k] for k in range(n_i)], dtype=np.int64)
+    np.savez_compressed(
+        out(fname), cold_object=split.cold_object, user_num=split.user_num, item_num=split.item_num,
+        warm_train=split.warm_train, warm_val=split.warm_val, warm_test=split.warm_test,
+        cold_val=split.cold_val, cold_test=split.cold_test, overall_val=split.overall_val,
+        overall_test=split.overall_test, warm_user=split.info["warm_user"],
+        warm_item=split.info["warm_item"], cold_user=split.info["cold_user"],
+        cold_item=split.info["cold_item"],
+        content=split.content if split.content is not None else np.zeros((0, 0), np.float32),
+        user_keys=user_keys, item_keys=item_keys,
+        mapped_warm_user_idx=np.asarray(data.mapped_warm_user_idx, dtype=np.int64),
+        mapped_warm_item_idx=np.asarray(data.mapped_warm_item_idx, dtype=np.int64),
+        mapped_cold_user_idx=np.asarray(data.mapped_cold_user_idx, dtype=np.int64),
+        mapped_cold_item_idx=np.asarray(data.mapped_cold_item_idx, dtype=np.int64))
+
+
+def g1_sampler(split):
+    data = ref_builder(split)          # fresh builder: training_data order untouched
+    np.random.seed(2024)
+    u, i, j, sizes = [], [], [], []
+    for _epoch in range(3):
+        for bu, bi, bj in next_batch_pairwise(data, 1024):
+            u += bu; i += bi; j += bj; sizes.append(len(bu))
+    tail = np.random.randint(0, 1 << 30, size=4)   # RNG state probe after the 3 epochs
+    np.savez_compressed(out("g1_sampler.npz"), seed=2024, batch_size=1024, epochs=3,
+                        u=np.array(u, np.int64), i=np.array(i, np.int64), j=np.array(j, np.int64),
+                        sizes=np.array(sizes, np.int64), rng_tail=tail)
+
+
+def g2_loss():
+    g = torch.Generator().manual_seed(7)
+    res = {}
+    cases = {
+        "rand": (64, 16, 1.0, 1e-4),
+        "reg": (48, 32, 0.3, 0.05),
+        "sat": (32, 8, 40.0, 1e-4),     # saturated sigmoid on both sides
+    }
+    for name, (B, d, scale, reg) in cases.items():
+        u = (torch.randn(B, d, generator=g) * scale).requires_grad_()
+        p = (torch.randn(B, d, generator=g) * scale).requires_grad_()
+        n = (torch.randn(B, d, generator=g) * scale).requires_grad_()
+        lb = bpr_loss(u, p, n)
+        lr_ = l2_reg_loss(reg, u, p, n)
+        (lb + lr_).backward()
+        res.update({f"{name}_u": u.detach().numpy(), f"{name}_p": p.detach().numpy(),
+                    f"{name}_n": n.detach().numpy(), f"{name}_reg": np.float64(reg),
+                    f"{name}_bpr": lb.detach().numpy(), f"{name}_l2": lr_.detach().numpy(),
+                    f"{name}_gu": u.grad.numpy(), f"{name}_gp": p.grad.numpy(),
+                    f"{name}_gn": n.grad.numpy()})
+    # gather from tables with duplicate rows: dense table gradients (index backward accumulates)
+    U = (torch.randn(10, 16, generator=g) * 0.5).requires_grad_()
+    V = (torch.randn(12, 16, generator=g) * 0.5).requires_grad_()
+    ui = [0, 3, 3, 9, 1, 3, 0, 7]
+    pi = [2, 2, 5, 11, 0, 2, 4, 4]
+    ni = [5, 1, 1, 0, 11, 5, 5, 2]
+    ue, pe, ne = U[ui], V[pi], V[ni]
+    loss = bpr_loss(ue, pe, ne) + l2_reg_loss(0.01, ue, pe, ne)
+    loss.backward()
+    res.update(dup_U=U.detach().numpy(), dup_V=V.detach().numpy(), dup_ui=np.array(ui),
+               dup_pi=np.array(pi), dup_ni=np.array(ni), dup_reg=np.float64(0.01),
+               dup_loss=loss.detach().numpy(), dup_gU=U.grad.numpy(), dup_gV=V.grad.numpy())
+    np.savez_compressed(out("g2_loss.npz"), **res)
+
+
+def g3_mf(split):
+    res = {}
+    steps_keep = (1, 10, 50)
+    for d in (16, 64):
+        data = ref_builder(split)
+        set_seed(2024, False)
+        model = Matrix_Factorization(data, d)
+        U0 = model.embedding_dict["user_emb"].detach().clone().numpy()
+        V0 = model.embedding_dict["item_emb"].detach().clone().numpy()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses, tu, ti, tj, sizes = [], [], [], [], []
+        step = 0
+        done = False
+        while not done:
+            for bu, bi, bj in next_batch_pairwise(data, 512):
+                ue_all, ie_all = model()
+                ue, pe, ne = ue_all[bu], ie_all[bi], ie_all[bj]
+                loss = bpr_loss(ue, pe, ne) + l2_reg_loss(1e-4, ue, pe, ne)
+                opt.zero_grad(); loss.backward(); opt.step()
+                step += 1
+                losses.append(loss.item())
+                tu += bu; ti += bi; tj += bj; sizes.append(len(bu))
+                if step in steps_keep:
+                    res[f"d{d}_U_step{step}"] = model.embedding_dict["user_emb"].detach().clone().numpy()
+                    res[f"d{d}_V_step{step}"] = model.embedding_dict["item_emb"].detach().clone().numpy()
+                if step == max(steps_keep):
+                    done = True
+                    break
+        res.update({f"d{d}_U0": U0, f"d{d}_V0": V0, f"d{d}_loss": np.array(losses, np.float64)})
+        if d == 16:
+            res.update(u=np.array(tu, np.int32), i=np.array(ti, np.int32), j=np.array(tj, np.int32),
+                       sizes=np.array(sizes, np.int64))
+        else:   # the triples do not depend on d (separate numpy stream, same seed)
+            assert np.array_equal(res["u"], np.array(tu, np.int32))
+    res.update(lr=1e-3, reg=1e-4, batch_size=512, seed=2024)
+    np.savez_compressed(out("g3_mf.npz"), **res)
+
+
+def g4_graph(split):
+    data = ref_builder(split)
+    adj = data.norm_adj.tocsr()
+    adj.sort_indices()
+    coo = TorchGraphInterface.convert_sparse_mat_to_tensor(data.norm_adj)
+    np.savez_compressed(out("g4_graph.npz"), n=adj.shape[0], indptr=adj.indptr.astype(np.int64),
+                        indices=adj.indices.astype(np.int64), data=adj.data.astype(np.float32),
+                        coo_rows=coo.indices()[0].numpy(), coo_cols=coo.indices()[1].numpy(),
+                        coo_vals=coo.values().numpy())
+
+
+def g5_lgcn(split):
+    res = {}
+    data = ref_builder(split)
+    for L in (1, 2, 3):
+        set_seed(2024, False)
+        enc = LGCN_Encoder(data, 32, L, torch.device("cpu"))
+        with torch.no_grad():
+            uo, io = enc()
+        if L == 1:
+            res["U0"] = enc.embedding_dict["user_emb"].detach().clone().numpy()
+            res["V0"] = enc.embedding_dict["item_emb"].detach().clone().numpy()
+        res[f"L{L}_user_out"] = uo.numpy().copy()
+        res[f"L{L}_item_out"] = io.numpy().copy()
+    # 20 training steps, L=3, d=32 (LightGCN.py:14-29)
+    data = ref_builder(split)
+    set_seed(2024, False)
+    enc = LGCN_Encoder(data, 32, 3, torch.device("cpu"))
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-3)
+    losses, tu, ti, tj, sizes = [], [], [], [], []
+    gU1 = gV1 = None
+    step = 0
+    while step < 20:
+        for bu, bi, bj in next_batch_pairwise(data, 512):
+            ua, ia = enc()
+            ue, pe, ne = ua[bu], ia[bi], ia[bj]
+            loss = bpr_loss(ue, pe, ne) + l2_reg_loss(1e-4, ue, pe, ne)
+            opt.zero_grad(); loss.backward()
+            if step == 0:
+                gU1 = enc.embedding_dict["user_emb"].grad.detach().clone().numpy()
+                gV1 = enc.embedding_dict["item_emb"].grad.detach().clone().numpy()
+            opt.step()
+            step += 1
+            losses.append(loss.item())
+            tu += bu; ti += bi; tj += bj; sizes.append(len(bu))
+            if step == 20:
+                break
+    res.update(train_loss=np.array(losses, np.float64), train_u=np.array(tu, np.int32),
+               train_i=np.array(ti, np.int32), train_j=np.array(tj, np.int32),
+               train_sizes=np.array(sizes, np.int64), train_gU_step1=gU1, train_gV_step1=gV1,
+               train_U_end=enc.embedding_dict["user_emb"].detach().numpy().copy(),
+               train_V_end=enc.embedding_dict["item_emb"].detach().numpy().copy(),
+               lr=1e-3, reg=1e-4, batch_size=512)
+    np.savez_compressed(out("g5_lgcn.npz"), **res)
+
+
+def _rank_gap_ok(U, V, users_int, S_masked, k, d):
+    """Rigorous margin: any fp32 summation order of a length-d dot product errs by at most
+    gamma_d * sum_k |u_k v_k| (gamma_d = d*2^-24/(1-d*2^-24)); the top-(k+1) adjacent gaps of
+    every row must exceed twice that, so the ranking is the same for MKL, fmaf chains and fp64."""
+    gam = d * 2.0 ** -24 / (1 - d * 2.0 ** -24)
+    err = gam * (np.abs(U[users_int]).astype(np.float64) @ np.abs(V).T.astype(np.float64)).max(axis=1)
+    top = -np.sort(-S_masked, axis=1)[:, :k + 1]
+    gaps = top[:, :-1] - top[:, 1:]
+    real = top[:, 1:] > -1e8          # gaps between two masked (-1e9) entries are ties by design
+    gaps = np.where(real, gaps, np.inf)
+    return bool((gaps.min(axis=1) > 2 * err).all()), float(gaps.min()), float(err.max())
+
+
+def g6_eval(split, tag, mode):
+    """mode: 'cont' continuous N(0,.3) with verified rank margin (seed searched);
+    'fine' multiples of 2^-10 (all dot products exact in fp32, ties absent -- verified);
+    'quant' multiples of 2^-4 (exact, many ties: compare per-score multisets)."""
+    data = ref_builder(split)
+    d = 16 if mode == "cont" else 32
+    seed = {"cont": 100, "fine": 200, "quant": 300}[mode]
+    while True:
+        cfg = ref_config(data, cold_object=split.cold_object, emb_size=d, bs=100)
+        trainer = MF(cfg)
+        rng = np.random.default_rng(seed)
+        if mode == "quant":
+            U = rng.integers(-16, 17, size=(data.user_num, d)).astype(np.float32) / 16
+            V = rng.integers(-16, 17, size=(data.item_num, d)).astype(np.float32) / 16
+        elif mode == "fine":
+            U = np.round(rng.standard_normal((data.user_num, d)) * 0.3 * 1024).clip(-1024, 1024).astype(np.float32) / 1024
+            V = np.round(rng.standard_normal((data.item_num, d)) * 0.3 * 1024).clip(-1024, 1024).astype(np.float32) / 1024
+        else:
+            U = rng.standard_normal((data.user_num, d)).astype(np.float32) * 0.3
+            V = rng.standard_normal((data.item_num, d)).astype(np.float32) * 0.3
+        trainer.user_emb, trainer.item_emb = torch.from_numpy(U), torch.from_numpy(V)
+        res = dict(U=U, V=V, k=trainer.max_N, cold_object=split.cold_object, seed=seed, mode=mode)
+        lists = {}
+        ok_all = True
+        for t in ("all", "warm", "cold"):
+            test_set = {"all": data.overall_test_set, "warm": data.warm_test_set, "cold": data.cold_test_set}[t]
+            rec = trainer.test(t)
+            users = list(test_set.keys())
+            assert list(rec.keys()) == users
+            idx = np.array([[data.item[it] for it, _ in rec[u]] for u in users], np.int64)
+            sc = np.array([[s for _, s in rec[u]] for u in users], np.float32)
+            cache = trainer._get_eval_cache(test_set, t)
+            rated = [r.numpy() if r is not None else np.zeros(0, np.int64) for r in cache["rated_item_ids"]]
+            rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+            cand = cache["candidate_mask"].numpy() if cache["candidate_mask"] is not None else np.zeros(0, np.int64)
+            users_int = np.array([data.user[u] for u in users], np.int64)
+            res.update({f"{t}_users": np.array(users, np.int64), f"{t}_users_int": users_int,
+                        f"{t}_rated_rowptr": rowptr,
+                        f"{t}_rated_col": np.concatenate(rated).astype(np.int64) if rated else np.zeros(0, np.int64),
+                        f"{t}_cand": cand.astype(np.int64), f"{t}_idx": idx, f"{t}_score": sc})
+            lists[t] = (test_set, rec)
+            if mode in ("cont", "fine"):
+                S = U[users_int].astype(np.float64) @ V.T.astype(np.float64)
+                for r in range(len(users)):
+                    S[r, rated[r]] = -1e9
+                if cand.size:
+                    S[:, cand] = -1e9
+                ok, gap, err = _rank_gap_ok(U, V, users_int, S, trainer.max_N, d)
+                if mode == "fine":   # exact arithmetic: only ties could reorder
+                    ok = gap > 0
+                res[f"{t}_min_gap"] = gap
+                res[f"{t}_max_err"] = err
+                ok_all &= ok
+        if ok_all:
+            break
+        seed += 1
+    np.savez_compressed(out(f"g6_eval_{tag}.npz"), **res)
+    return lists
+
+
+def g6_small():
+    """A user with fewer than k unmasked candidates: masked items are returned (-1e9)."""
+    rng = np.random.default_rng(5)
+    n_user, n_item = 6, 26
+    train = [[u, i, 1.0] for u in range(n_user) for i in rng.choice(n_item - 4, size=4 + 3 * u, replace=False)]
+    cold_items = list(range(n_item - 4, n_item))
+    test = [[u, cold_items[u % 4], 1.0] for u in range(n_user)]
+    warm_items = sorted({t[1] for t in train})
+    data = ColdStartDataBuilder(train, test, test, test, test, test, test, n_user, n_item,
+                                list(range(n_user)), warm_items, [], cold_items, None,
+                                np.zeros((n_item, 2), np.float32))
+    cfg = ref_config(data, cold_object="item", emb_size=8, bs=4)
+    trainer = MF(cfg)
+    U = rng.standard_normal((data.user_num, 8)).astype(np.float32)
+    V = rng.standard_normal((data.item_num, 8)).astype(np.float32)
+    trainer.user_emb, trainer.item_emb = torch.from_numpy(U), torch.from_numpy(V)
+    res = dict(U=U, V=V, k=trainer.max_N)
+    for t in ("all", "warm", "cold"):
+        rec = trainer.test(t)
+        users = list(data.overall_test_set.keys())
+        cache = trainer._get_eval_cache(data.overall_test_set, t)
+        rated = [r.numpy() if r is not None else np.zeros(0, np.int64) for r in cache["rated_item_ids"]]
+        rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+        cand = cache["candidate_mask"].numpy() if cache["candidate_mask"] is not None else np.zeros(0, np.int64)
+        res.update({f"{t}_users_int": np.array([data.user[u] for u in users], np.int64),
+                    f"{t}_rated_rowptr": rowptr, f"{t}_rated_col": np.concatenate(rated).astype(np.int64),
+                    f"{t}_cand": cand.astype(np.int64),
+                    f"{t}_idx": np.array([[data.item[it] for it, _ in rec[u]] for u in users], np.int64),
+                    f"{t}_score": np.array([[s for _, s in rec[u]] for u in users], np.float32)})
+    np.savez_compressed(out("g6_eval_small.npz"), **res)
+
+
+def g7_metrics(lists):
+    res = {}
+    for t, (test_set, rec) in lists.items():
+        users = list(test_set.keys())
+        measure, perf = ranking_evaluation(test_set, rec, [10, 20])
+        gt_rowptr = np.concatenate([[0], np.cumsum([len(test_set[u]) for u in users])]).astype(np.int64)
+        gt_items = np.array([it for u in users for it in test_set[u].keys()], np.int64)
+        pred = np.array([[it for it, _ in rec[u]] for u in users], np.int64)
+        res.update({f"{t}_gt_rowptr": gt_rowptr, f"{t}_gt_items": gt_items, f"{t}_pred": pred,
+                    f"{t}_perf": np.array(perf, np.float64), f"{t}_measure": np.array(measure)})
+    np.savez_compressed(out("g7_metrics.npz"), **res)
+
+
+def g8_e2e(split):
+    data = ref_builder(split)
+    cfg = ref_config(data, emb_size=64, epochs=3, bs=512)
+    set_seed(2024, False)
+    trainer = MF(cfg)
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        trainer.run()
+    log = buf.getvalue()
+    loss_lines = [ln for ln in log.splitlines() if ln.startswith("training:")]
+    payload = dict(
+        args=vars(cfg.args), overall=trainer.overall_test_results, cold=trainer.cold_test_results,
+        warm=trainer.warm_test_results, best=[trainer.bestPerformance[0], trainer.bestPerformance[1]],
+        epochs_ran=trainer.epochs_ran, loss_lines=loss_lines,
+        user_emb_norm=float(trainer.user_emb.norm()), item_emb_norm=float(trainer.item_emb.norm()))
+    with open(out("g8_e2e.json"), "w") as f:
+        json.dump(payload, f, indent=1)
+    np.savez_compressed(out("g8_e2e_emb.npz"), U=trainer.user_emb.detach().numpy(),
+                        V=trainer.item_emb.detach().numpy())
+
+
+def main():
+    split_i = make_dataset("toy", "item", seed=1)
+    split_u = make_dataset("toy", "user", seed=2)
+    dump_split(split_i, ref_builder(split_i), "toy_item.npz")
+    dump_split(split_u, ref_builder(split_u), "toy_user.npz")
+    g1_sampler(split_i)
+    g2_loss()
+    g3_mf(split_i)
+    g4_graph(split_i)
+    g5_lgcn(split_i)
+    g6_eval(split_i, "item_cont", "cont")
+    lists = g6_eval(split_i, "item_fine", "fine")
+    g6_eval(split_i, "item_quant", "quant")
+    g6_eval(split_u, "user_cont", "cont")
+    g6_eval(split_u, "user_fine", "fine")
+    g6_small()
+    g7_metrics(lists)
+    g8_e2e(split_i)
+    total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
+    print("golden vectors written, %.1f KiB" % (total / 1024))
+
+
+if __name__ == "__main__":
+    main()
