@@ -1,0 +1,101 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY: the reference path restated with the SAME library
+calls the reference makes (a "port", used as the CPU baseline and as a second checker).
+
+The reference is pure Python over PyTorch; its source cannot travel to the GPU box, so this
+module re-expresses the few library calls on the hot path, each citing where the reference
+makes them.  It is validated against tests/golden (tests/test_oracle_golden.py) and timed
+by bench.py's ``cpu_baseline`` leg with ``torch.set_num_threads(os.cpu_count())``.
+Nothing under coldrec_amd/ imports it.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+
+def eval_block(user_emb: torch.Tensor, item_emb: torch.Tensor, users: torch.Tensor,
+               rated: List[Optional[torch.Tensor]], cand: Optional[torch.Tensor], k: int):
+    """One user block of BaseColdStartTrainer._evaluate (model/BaseRecommender.py:172-183):
+    batch_predict (model/MF.py:58-63) -> per-user rated mask -> candidate column mask -> topk."""
+    S = torch.matmul(user_emb[users], item_emb.transpose(0, 1))          # MF.py:62
+    for j, ids in enumerate(rated):                                      # BaseRecommender.py:175-177
+        if ids is not None:
+            S[j, ids] = -10e8
+    if cand is not None:                                                 # :179-180
+        S[:, cand] = -10e8
+    scores, idx = torch.topk(S, k, dim=1, largest=True, sorted=True)    # :182
+    return scores, idx
+
+
+def bpr_loss(u, p, n):
+    """util/utils.py:25-29."""
+    pos = torch.mul(u, p).sum(dim=1)
+    neg = torch.mul(u, n).sum(dim=1)
+    return torch.mean(-torch.log(10e-6 + torch.sigmoid(pos - neg)))
+
+
+def l2_reg_loss(reg, *embs):
+    """util/utils.py:44-48 (Frobenius norm of each gathered matrix / batch rows)."""
+    acc = 0
+    for e in embs:
+        acc = acc + torch.norm(e, p=2) / e.shape[0]
+    return acc * reg
+
+
+class MFPort:
+    """model/MF.py:12-29,66-82: two tables, gather by index lists, BPR + L2, dense Adam."""
+
+    def __init__(self, U0: np.ndarray, V0: np.ndarray, lr: float, reg: float):
+        self.U = torch.nn.Parameter(torch.from_numpy(np.array(U0, np.float32)))
+        self.V = torch.nn.Parameter(torch.from_numpy(np.array(V0, np.float32)))
+        self.opt = torch.optim.Adam([self.U, self.V], lr=lr)             # MF.py:14
+        self.reg = reg
+
+    def step(self, ui, pi, ni) -> float:
+        ui, pi, ni = list(map(int, ui)), list(map(int, pi)), list(map(int, ni))
+        ue, pe, ne = self.U[ui], self.V[pi], self.V[ni]                  # MF.py:22 (list index)
+        loss = bpr_loss(ue, pe, ne) + l2_reg_loss(self.reg, ue, pe, ne)  # MF.py:23
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return float(loss.item())
+
+
+def coo_adj(rowptr, col, val) -> torch.Tensor:
+    """util/databuilder.py:953-962 result: coalesced int64 COO fp32 tensor."""
+    n = len(rowptr) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    idx = torch.from_numpy(np.vstack([rows, np.asarray(col, np.int64)]))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(np.asarray(val, np.float32)), (n, n)).coalesce()
+
+
+class LGCNPort:
+    """model/LightGCN.py:14-29,86-96: full-graph L-layer propagation per batch via
+    torch.sparse.mm on the COO adjacency, mean of layer outputs, BPR + L2, dense Adam."""
+
+    def __init__(self, U0, V0, adj: torch.Tensor, n_layers: int, lr: float, reg: float):
+        self.U = torch.nn.Parameter(torch.from_numpy(np.array(U0, np.float32)))
+        self.V = torch.nn.Parameter(torch.from_numpy(np.array(V0, np.float32)))
+        self.adj, self.L, self.reg = adj, n_layers, reg
+        self.opt = torch.optim.Adam([self.U, self.V], lr=lr)
+
+    def forward(self):
+        ego = torch.cat([self.U, self.V], 0)
+        layers = [ego]
+        for _ in range(self.L):
+            ego = torch.sparse.mm(self.adj, ego)                         # LightGCN.py:90
+            layers.append(ego)
+        out = torch.mean(torch.stack(layers, dim=1), dim=1)
+        return out[: self.U.shape[0]], out[self.U.shape[0]:]
+
+    def step(self, ui, pi, ni) -> float:
+        ui, pi, ni = list(map(int, ui)), list(map(int, pi)), list(map(int, ni))
+        ua, ia = self.forward()
+        ue, pe, ne = ua[ui], ia[pi], ia[ni]
+        loss = bpr_loss(ue, pe, ne) + l2_reg_loss(self.reg, ue, pe, ne)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return float(loss.item())
