@@ -114,6 +114,19 @@ def merge_topk(scores, idx, k_out):
     return sc, ix
 
 
+def scores_dense(U, users, V):
+    """Canonical (fmaf-chain) dense score matrix, shape (n_users, n_items)."""
+    U = np.ascontiguousarray(U, np.float32)
+    V = np.ascontiguousarray(V, np.float32)
+    users = None if users is None else np.ascontiguousarray(users, np.int64)
+    n = U.shape[0] if users is None else users.shape[0]
+    S = np.empty((n, V.shape[0]), np.float32)
+    _lib().orc_scores_dense(_p(U, ctypes.c_float), _p(users, ctypes.c_int64), ctypes.c_int64(n),
+                            _p(V, ctypes.c_float), ctypes.c_int64(V.shape[0]), ctypes.c_int(U.shape[1]),
+                            _p(S, ctypes.c_float))
+    return S
+
+
 def dot_chain(a, b) -> np.float32:
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)

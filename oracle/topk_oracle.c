@@ -56,6 +56,16 @@ float orc_dot_chain(const float* a, const float* b, int d) {
     return s;
 }
 
+/* dense canonical scores S[b][i] (model/MF.py:62 restated with the fmaf chain) */
+int orc_scores_dense(const float* Uemb, const int64_t* users, int64_t n_users, const float* V,
+                     int64_t n_items, int d, float* S) {
+    for (int64_t b = 0; b < n_users; ++b) {
+        const float* u = Uemb + (users ? users[b] : b) * (int64_t)d;
+        for (int64_t i = 0; i < n_items; ++i) S[b * n_items + i] = orc_dot_chain(u, V + i * (int64_t)d, d);
+    }
+    return 0;
+}
+
 /*
  * Fused restatement.  Uemb (n_user_rows, d) row-major; users[b] = row of Uemb for block slot b
  * (NULL = identity); Vshard = rows [item_base, item_base+n_items) of the item table;
