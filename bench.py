@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ranked items/s of the fused full-catalogue evaluation (BASELINE.json
+config 4: 1M users x 10M items, d=128, k=20) on N MI355X.
+
+One "step" = one block of ``--users-per-step`` users scored and ranked against the WHOLE
+catalogue: crh_score_topk_f32 over the rank's item shard (rows [r*I/N, (r+1)*I/N)), then for
+N > 1 an RCCL all-gather of the per-shard top-k and the canonical merge.
+Total work per step is fixed as N grows ("scaling": "strong", the north_star's ">= 6x further
+at 8 GPUs").  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 4 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 4 --warmup 1
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (score_topk_kernel):
+achieved = 2*d flop per (user,item) pair x pairs per launch / average kernel time measured with
+HIP events recorded around that kernel on its stream.  ``cpu_baseline`` is the reference path
+restated with the same library calls (oracle/ref_port.py: torch.matmul -> masks -> torch.topk),
+timed on the host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+CHUNK_ROWS = 1_250_000         # item table is generated in chunks so shards agree for N = 1,2,4,8
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs (libamdhip64 via ctypes) recorded by the C ABI around the kernel."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.pairs = []
+        for _ in range(n):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0
+            assert self.hip.hipEventCreate(ctypes.byref(b)) == 0
+            self.pairs.append((a, b))
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            out.append(ms.value)
+        return out
+
+
+def xavier_(rows, d, seed, device, fan_rows):
+    g = torch.Generator(device=device).manual_seed(seed)
+    a = (6.0 / (fan_rows + d)) ** 0.5
+    return (torch.rand((rows, d), generator=g, device=device, dtype=torch.float32) * 2 - 1) * a
+
+
+def item_shard(n_items, d, lo, hi, device):
+    """Rows [lo, hi) of the synthetic item table U(-a, a) (seed 3 + chunk), xavier-like."""
+    parts = []
+    for c in range(lo // CHUNK_ROWS, (hi + CHUNK_ROWS - 1) // CHUNK_ROWS):
+        c_lo, c_hi = c * CHUNK_ROWS, min((c + 1) * CHUNK_ROWS, n_items)
+        chunk = xavier_(c_hi - c_lo, d, 3000 + c, device, n_items)
+        parts.append(chunk[max(lo, c_lo) - c_lo: min(hi, c_hi) - c_lo])
+    return torch.cat(parts, 0).contiguous()
+
+
+def rated_lists(n_users, n_items, mean_len, seed):
+    """Per-user training items: Zipf-truncated lengths (mean ~mean_len), uniform ids, ascending."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.zipf(1.6, n_users) * (mean_len // 4), 40 * mean_len).astype(np.int64)
+    rowptr = np.zeros(n_users + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    col = rng.integers(0, n_items, int(rowptr[-1]), dtype=np.int64)
+    row_of = np.repeat(np.arange(n_users), lens)
+    order = np.lexsort((col, row_of))
+    return rowptr, col[order].astype(np.int32)
+
+
+def cpu_baseline(U_cpu, V_cpu, rowptr, col, cold_ids, k, reps):
+    """oracle/ref_port.eval_block (the reference's own library calls) on the host cores."""
+    from oracle import ref_port
+    torch.set_num_threads(os.cpu_count())
+    users = torch.arange(U_cpu.shape[0])
+    rated = []
+    for r in range(U_cpu.shape[0]):
+        ids = col[rowptr[r]:rowptr[r + 1]]
+        ids = ids[ids < V_cpu.shape[0]]
+        rated.append(torch.from_numpy(ids.astype(np.int64)) if len(ids) else None)
+    cand = torch.from_numpy(cold_ids[cold_ids < V_cpu.shape[0]].astype(np.int64))
+    ref_port.eval_block(U_cpu[:8], V_cpu, users[:8], rated[:8], cand, k)   # touch pages / warm MKL
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref_port.eval_block(U_cpu, V_cpu, users, rated, cand, k)
+    dt = (time.perf_counter() - t0) / reps
+    return U_cpu.shape[0] * V_cpu.shape[0] / dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--items", type=int, default=10_000_000)
+    ap.add_argument("--users", type=int, default=1_000_000, help="rows of the user table")
+    ap.add_argument("--users-per-step", type=int, default=16384)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--n-splits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-users", type=int, default=256)
+    ap.add_argument("--cpu-sample-items", type=int, default=2_500_000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: coldrec_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from coldrec_amd import ops
+    from coldrec_amd.eval import ShardedTopK
+
+    I, d, k, Bu = args.items, args.dim, args.k, args.users_per_step
+    lo, hi = rank * I // world, (rank + 1) * I // world
+    V = item_shard(I, d, lo, hi, dev)
+    n_blocks = args.warmup + args.steps
+    n_user_rows = min(args.users, Bu * n_blocks)
+    U = xavier_(n_user_rows, d, 17, dev, args.users)
+    rowptr, col = rated_lists(n_user_rows, I, 50, seed=4)
+    cold = np.where(np.random.default_rng(5).random(I) < 0.2)[0]       # 'warm' setting: cold items masked
+    bitmap = ops.make_bitmap(I, cold, dev)
+    blocks = []
+    for b in range(n_blocks):
+        u0 = (b * Bu) % max(n_user_rows - Bu + 1, 1)
+        rp = torch.from_numpy(rowptr[u0:u0 + Bu + 1] - rowptr[u0]).to(dev)
+        rc = torch.from_numpy(col[rowptr[u0]:rowptr[u0 + Bu]]).to(dev)
+        blocks.append((torch.arange(u0, u0 + Bu, dtype=torch.int32, device=dev), rp, rc))
+
+    engine = ShardedTopK(V, item_base=lo, n_items_global=I, k=k, world=world, rank=rank)
+    events = HipEvents(args.steps)
+
+    def step(b, ev=None):
+        users, rp, rc = blocks[b]
+        return engine.topk(U, users, rp, rc, bitmap, n_splits=args.n_splits, kernel_events=ev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        out = step(args.warmup + s, events.pairs[s])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = Bu * I / (ms_per_step * 1e-3)
+    kern_ms = float(np.mean(events.elapsed_ms()))
+    flops_per_launch = 2.0 * d * Bu * (hi - lo)
+    achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+
+    result = {
+        "metric": "ranked items/sec (full-catalogue eval)", "value": value, "unit": "items/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[3] full-catalogue eval: %d-row user table x %d items, d=%d, k=%d, "
+                               "user block %d per step, rated CSR (mean ~50) + 20%% cold-item bitmap ('warm' setting), "
+                               "item table row-sharded over %d GPU(s)" % (args.users, I, d, k, Bu, world),
+                   "users_per_step": Bu, "items": I, "dim": d, "k": k,
+                   "parallelism": "item-row-shard x%d + all_gather(top-k) + canonical merge" % world if world > 1
+                   else "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "score_topk_kernel<%d>" % d, "achieved": achieved,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "kernel_ms": kern_ms, "flops_per_launch": flops_per_launch, "traffic": None},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nu, ni = args.cpu_sample_users, min(args.cpu_sample_items, hi - lo)
+        Uc, Vc = U[:nu].cpu(), V[:ni].cpu()
+        rate = cpu_baseline(Uc, Vc, rowptr[:nu + 1], col, cold, k, reps=2)
+        result["cpu_baseline"] = {
+            "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
+                      "%d threads, 2 reps" % (nu, ni, torch.__version__, os.cpu_count())}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    del out
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

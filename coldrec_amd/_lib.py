@@ -1,0 +1,81 @@
+"""ctypes binding of libcoldrec_hip.so (the C ABI declared in include/coldrec_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised.  Tensors cross the boundary as raw device pointers
+(``tensor.data_ptr()``) plus sizes, the stream as ``torch.cuda.current_stream().cuda_stream``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcoldrec_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+PAD_IDX = 0x7FFFFFFF
+MASKED_SCORE = -1.0e9
+MAX_K = 64
+
+_lib = None
+
+_vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
+SIGNATURES = {
+    "crh_last_error": (ctypes.c_char_p, []),
+    "crh_version": (_i32, []),
+    "crh_score_topk_supports_dim": (_i32, [_i32]),
+    "crh_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "crh_score_topk_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
+                                  _vp, _sz, _vp]),
+    "crh_score_topk_f32_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
+                                     _vp, _sz, _vp, _i32, _vp, _vp]),
+    "crh_mask_topk_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "crh_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into coldrec_amd/lib/ (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "coldrec_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "all"])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "coldrec_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().crh_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,358 @@
+// Fused full-catalogue scoring + masking + per-user top-k for gfx950 (MI355X).
+//
+// Replaces model/MF.py:58-63 (user_emb[users] @ item_emb.T), model/BaseRecommender.py:175-180
+// (the -10e8 masks) and :182 (torch.topk) of the reference without ever writing the
+// (users x items) score block to memory.
+//
+// Design (one wave64 is the unit of work; waves never synchronise with each other):
+//   * a wave owns 32*UW users.  Their embeddings are loaded once and stay in VGPRs as the
+//     B operand of v_mfma_f32_32x32x2_f32 for the whole kernel (the "hot user block").
+//   * the wave streams its item range in tiles of 32 items.  Lane (i, h) = (lane&31, lane>>5)
+//     loads 16 B of row i per 8-wide k chunk (h selects the half), then two
+//     v_permlane32_swap per chunk put k = 2t in the low half-wave and k = 2t+1 in the high
+//     half-wave, which is exactly the A fragment of the 32x32x2 MFMA.  Issued in k order into
+//     ONE accumulator per (item tile, user tile), the MFMA result is bit-identical to the
+//     canonical fp32 fma chain of the oracle (oracle/topk_oracle.c).
+//   * accumulator layout (A = items -> rows, B = users -> columns): a lane holds 16 item
+//     scores of ONE user, so the running k-th best score tau of that user is one VGPR and the
+//     common case is: max of 16 registers, one compare, one ballot per 32x32 tile.
+//   * only tiles that contain a score above tau take the slow path: scores are staged to LDS,
+//     each candidate is checked against the masks (bitmap bit, rated list) and inserted into
+//     the user's sorted list in LDS by the whole wave (topk_list.h).  Expected slow-path
+//     events per user are ~ k*ln(range/k), against range/32 tiles.
+//   * the grid is (user groups) x (item-range splits); block b works on split b % S so that
+//     the blocks of one XCD (b % 8) stream the same item rows through that XCD's L2.
+//     Partial lists are merged by merge_topk with the same canonical key, so the result does
+//     not depend on S, on the tiling or (after the all-gather) on the GPU count.
+#include <stdarg.h>
+
+#include "crh_common.h"
+#include "topk_list.h"
+
+namespace {
+
+struct ScoreArgs {
+    const float* user_emb;
+    const int32_t* users;
+    int64_t n_users;
+    const float* item_emb;
+    int64_t n_items;
+    const int64_t* rated_rowptr;
+    const int32_t* rated_col;
+    const uint32_t* bitmap;
+    int k;
+    int64_t item_base;
+    int n_splits;
+    int64_t n_ugroups;
+    float* out_score;   // [n_splits][n_users][k]
+    int32_t* out_idx;
+};
+
+// in : lane (i,0) holds k = 8q+0..3 of row i, lane (i,1) holds k = 8q+4..7
+// out: .x = {8q | 8q+1}, .z = {8q+2 | 8q+3}, .y = {8q+4 | 8q+5}, .w = {8q+6 | 8q+7}  (low | high half)
+// v_permlane32_swap vdst, src exchanges lanes 32-63 of vdst with lanes 0-31 of src.
+// NOTE (hipcc 7.2): keep the swap on the integer vector.  A helper taking float& x, float& y and
+// bit-casting the two scalar results separately is miscompiled (the second result is replaced
+// by the first: v_mov y, x after the swap) -- found by reading the ISA, would fail parity.
+__device__ __forceinline__ void chunk_swap(f32x4& cf) {
+    u32x4 c = __builtin_bit_cast(u32x4, cf);
+    const u32x2 r0 = __builtin_amdgcn_permlane32_swap(c.x, c.y, false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane32_swap(c.z, c.w, false, false);
+    u32x4 o;
+    o.x = r0[0];
+    o.y = r0[1];
+    o.z = r1[0];
+    o.w = r1[1];
+    cf = __builtin_bit_cast(f32x4, o);
+}
+
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int UPW>
+struct WaveLds {
+    float* ls;       // [UPW][K]
+    int* li;         // [UPW][K]
+    int* cnt;        // [UPW]
+    float* scratch;  // [16][64]
+};
+
+template <int UPW>
+__host__ __device__ constexpr size_t wave_lds_bytes(int K) {
+    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + 16 * 64 * 4;
+}
+
+// Slow path for one 32x32 accumulator tile (rare).  acc[r] = score of item row
+// (r&3) + 8*(r>>2) + 4*(lane>>5) for user column lane&31.
+template <int UPW>
+__device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg, const WaveLds<UPW>& w,
+                                               int K, int ucol0, int64_t slot0, const ScoreArgs& a,
+                                               int64_t item0, int64_t split_end, int lane) {
+    unsigned cm = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        w.scratch[r * 64 + lane] = acc[r];
+        cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
+    }
+    unsigned long long lanes = __ballot(cm != 0u);
+    while (lanes) {
+        const int L = __builtin_ctzll(lanes);
+        lanes &= lanes - 1;
+        unsigned cmL = __builtin_amdgcn_readlane(cm, L);
+        const int jl = L & 31, hh = L >> 5;
+        const int64_t slot = slot0 + jl;
+        if (slot >= a.n_users) continue;
+        const int ul = ucol0 + jl;
+        float* lsu = w.ls + ul * K;
+        int* liu = w.li + ul * K;
+        while (cmL) {
+            const int r = __builtin_ctz(cmL);
+            cmL &= cmL - 1;
+            const int64_t il = item0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (il >= split_end) continue;   // clamped duplicate rows of the tail tile
+            float sc = __builtin_bit_cast(
+                float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.scratch[r * 64 + L])));
+            const int gi = (int)(a.item_base + il);
+            const int n = __builtin_amdgcn_readfirstlane(w.cnt[ul]);
+            if (wave_list_rejects(lsu, liu, n, K, sc, gi)) continue;
+            if (wave_is_masked(gi, slot, a.rated_rowptr, a.rated_col, a.bitmap, lane)) sc = CRH_MASKED_SCORE;
+            wave_list_insert(lsu, liu, w.cnt + ul, K, sc, gi, lane);
+        }
+    }
+    const int my = ucol0 + (lane & 31);
+    tau_reg = wave_list_tau(w.ls + my * K, w.cnt[my], K);
+}
+
+template <int D, int UW, int WPW>
+__global__ __launch_bounds__(64 * WPW) void score_topk_kernel(ScoreArgs a) {
+    constexpr int NCH = D / 8;
+    constexpr int UPW = 32 * UW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t vb = (int64_t)blockIdx.x * WPW + wave;
+    const int S = a.n_splits;
+    const int split = (int)(vb % S);
+    const int64_t ug = vb / S;
+    if (ug >= a.n_ugroups) return;
+    const int K = a.k;
+    const int i = lane & 31, h = lane >> 5;
+
+    WaveLds<UPW> w;
+    {
+        char* base = smem + (size_t)wave * wave_lds_bytes<UPW>(K);
+        w.ls = reinterpret_cast<float*>(base);
+        w.li = reinterpret_cast<int*>(w.ls + UPW * K);
+        w.cnt = w.li + UPW * K;
+        w.scratch = reinterpret_cast<float*>(w.cnt + UPW);
+    }
+    for (int j = lane; j < UPW; j += 64) w.cnt[j] = 0;
+
+    // ---- hot user block -> registers (B fragments, already pair-swapped)
+    f32x4 b[UW][NCH];
+    float tau[UW];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        int64_t slot = ug * UPW + 32 * u + i;
+        if (slot >= a.n_users) slot = a.n_users - 1;
+        const int64_t row = a.users ? (int64_t)a.users[slot] : slot;
+        const float* up = a.user_emb + row * D + 4 * h;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            b[u][q] = load4(up + 8 * q);
+            chunk_swap(b[u][q]);
+        }
+        tau[u] = CRH_NEG_INF;
+    }
+
+    // ---- item range of this split, in tiles of 32 rows
+    const int64_t T = (a.n_items + 31) >> 5;
+    const int64_t t0 = T * split / S, t1 = T * (split + 1) / S;
+    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
+
+    // Two register tiles: while tile t is multiplied out of one, tile t+1 lands in the other
+    // (issued a whole tile = NCH*4*UW MFMAs ahead, pinned there by sched_barrier; left to
+    // itself hipcc sinks the loads behind the MFMAs and waits vmcnt(0) at the loop head).
+    auto load_tile = [&](f32x4(&dst)[NCH], int64_t t) {
+        int64_t row = (t << 5) + i;
+        if (row >= split_end) row = split_end - 1;
+        const float* vp = a.item_emb + row * D + 4 * h;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) dst[q] = load4(vp + 8 * q);
+    };
+    auto do_tile = [&](f32x4(&src)[NCH], int64_t t) {
+        f32x16 acc[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            f32x4 c = src[q];
+            chunk_swap(c);
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, b[u][q].x, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, b[u][q].z, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, b[u][q].y, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b[u][q].w, acc[u], 0, 0, 0);
+        }
+        // selection: one compare per lane and accumulator in the common case
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            float m = acc[u][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
+            if (__ballot(m > tau[u]) != 0ull)
+                tile_slow_path<UPW>(acc[u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a, t << 5, split_end,
+                                    lane);
+        }
+    };
+
+    if (t0 < t1) {
+        f32x4 ta[NCH], tb[NCH];
+        load_tile(ta, t0);
+        for (int64_t t = t0; t < t1; t += 2) {
+            load_tile(tb, t + 1);   // rows past the split end are clamped: always a valid address
+            __builtin_amdgcn_sched_barrier(0);
+            do_tile(ta, t);
+            if (t + 1 >= t1) break;
+            load_tile(ta, t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            do_tile(tb, t + 1);
+        }
+    }
+
+    // ---- write this split's lists: [split][slot][k], padded with (-inf, PAD)
+    for (int j = 0; j < UPW; ++j) {
+        const int64_t slot = ug * UPW + j;
+        if (slot >= a.n_users) break;
+        const int n = __builtin_amdgcn_readfirstlane(w.cnt[j]);
+        if (lane < K) {
+            const int64_t o = ((int64_t)split * a.n_users + slot) * K + lane;
+            a.out_score[o] = lane < n ? w.ls[j * K + lane] : CRH_NEG_INF;
+            a.out_idx[o] = lane < n ? w.li[j * K + lane] : CRH_PAD_IDX;
+        }
+    }
+}
+
+template <int D, int UW, int WPW>
+int launch_score(const ScoreArgs& a, hipStream_t stream) {
+    constexpr int UPW = 32 * UW;
+    const size_t lds = wave_lds_bytes<UPW>(a.k) * WPW;
+    auto kern = score_topk_kernel<D, UW, WPW>;
+    if (lds > 64 * 1024)
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t vblocks = a.n_ugroups * a.n_splits;
+    const int64_t blocks = (vblocks + WPW - 1) / WPW;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WPW), lds, stream, a);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+constexpr int users_per_wave(int d) { return d >= 256 ? 32 : (d >= 128 ? 64 : 128); }
+
+int pick_splits(int64_t n_ugroups, int64_t n_items) {
+    // aim at ~one wave per SIMD (256 CUs x 4) with power-of-two splits, >= 64 tiles per split
+    const int64_t target = 1024;
+    int s = 1;
+    while (s < 64 && n_ugroups * (s * 2) <= target && n_items / (s * 2) >= 64 * 32) s *= 2;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int crh_score_topk_supports_dim(int d) {
+    return d == 8 || d == 16 || d == 32 || d == 64 || d == 128 || d == 256;
+}
+
+extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
+    (void)n_items;
+    (void)d;
+    if (n_users <= 0 || k <= 0) return 0;
+    return (size_t)64 * (size_t)n_users * (size_t)k * 8;   // worst case: 64 splits of (score, idx)
+}
+
+extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n_users,
+                                     const float* item_emb, int64_t n_items, int d,
+                                     const int64_t* rated_rowptr, const int32_t* rated_col,
+                                     const uint32_t* cand_bitmap, int k, int64_t item_base,
+                                     float* out_score, int32_t* out_idx, void* workspace,
+                                     size_t workspace_bytes, void* stream, int n_splits,
+                                     void* ev_kernel_start, void* ev_kernel_stop) {
+    CRH_CHECK_ARG(user_emb && item_emb && out_score && out_idx, "crh_score_topk_f32: NULL table/output pointer");
+    CRH_CHECK_ARG(n_users > 0 && n_items > 0, "crh_score_topk_f32: empty block (n_users=%lld, n_items=%lld)",
+                  (long long)n_users, (long long)n_items);
+    CRH_CHECK_ARG(k >= 1 && k <= CRH_MAX_K, "crh_score_topk_f32: k=%d outside 1..%d", k, CRH_MAX_K);
+    CRH_CHECK_ARG(crh_score_topk_supports_dim(d), "crh_score_topk_f32: d=%d unsupported (pad the tables to 8/16/32/64/128/256)", d);
+    CRH_CHECK_ARG(((uintptr_t)user_emb & 15) == 0 && ((uintptr_t)item_emb & 15) == 0,
+                  "crh_score_topk_f32: tables must be 16-byte aligned");
+    CRH_CHECK_ARG((rated_rowptr == nullptr) == (rated_col == nullptr) || rated_rowptr != nullptr,
+                  "crh_score_topk_f32: rated_col given without rated_rowptr");
+    CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "crh_score_topk_f32: item ids exceed int32");
+    CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "crh_score_topk_f32: n_splits=%d outside 0..64", n_splits);
+
+    const int upw = users_per_wave(d);
+    ScoreArgs a;
+    a.user_emb = user_emb;
+    a.users = users;
+    a.n_users = n_users;
+    a.item_emb = item_emb;
+    a.n_items = n_items;
+    a.rated_rowptr = rated_rowptr;
+    a.rated_col = rated_col;
+    a.bitmap = cand_bitmap;
+    a.k = k;
+    a.item_base = item_base;
+    a.n_ugroups = (n_users + upw - 1) / upw;
+    a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items);
+    const int64_t T = (n_items + 31) / 32;
+    if (a.n_splits > T) a.n_splits = (int)T;
+
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.n_splits == 1) {
+        a.out_score = out_score;
+        a.out_idx = out_idx;
+    } else {
+        const size_t need = (size_t)a.n_splits * n_users * k * 8;
+        if (!workspace || workspace_bytes < need) {
+            crh_set_error("crh_score_topk_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+            return CRH_ERR_WS;
+        }
+        a.out_score = reinterpret_cast<float*>(workspace);
+        a.out_idx = reinterpret_cast<int32_t*>(a.out_score + (size_t)a.n_splits * n_users * k);
+    }
+    int rc;
+    if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
+    switch (d) {
+        case 8: rc = launch_score<8, 4, 1>(a, st); break;
+        case 16: rc = launch_score<16, 4, 1>(a, st); break;
+        case 32: rc = launch_score<32, 4, 1>(a, st); break;
+        case 64: rc = launch_score<64, 4, 1>(a, st); break;
+        case 128: rc = launch_score<128, 2, 1>(a, st); break;
+        default: rc = launch_score<256, 1, 1>(a, st); break;
+    }
+    if (rc != CRH_OK) return rc;
+    if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
+    if (a.n_splits > 1)
+        return crh_merge_topk(a.out_score, a.out_idx, a.n_splits, n_users, k, k, out_score, out_idx, stream);
+    return CRH_OK;
+}
+
+extern "C" int crh_score_topk_f32(const float* user_emb, const int32_t* users, int64_t n_users,
+                                  const float* item_emb, int64_t n_items, int d,
+                                  const int64_t* rated_rowptr, const int32_t* rated_col,
+                                  const uint32_t* cand_bitmap, int k, int64_t item_base,
+                                  float* out_score, int32_t* out_idx, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    return crh_score_topk_f32_ex(user_emb, users, n_users, item_emb, n_items, d, rated_rowptr, rated_col,
+                                 cand_bitmap, k, item_base, out_score, out_idx, workspace, workspace_bytes,
+                                 stream, 0, nullptr, nullptr);
+}

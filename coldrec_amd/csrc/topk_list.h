@@ -1,0 +1,71 @@
+// Wave-cooperative per-user top-k lists kept in LDS (one wave = 64 lanes owns its lists, so
+// there is no cross-wave synchronisation anywhere).  Lists are sorted best-first by the
+// canonical key; lane t holds entry t during an insertion, hence k <= 64.
+#pragma once
+#include "crh_common.h"
+
+// All 64 lanes call with wave-uniform (sc, gi).  lsu/liu: this user's k-entry list, cntp its fill.
+__device__ __forceinline__ void wave_list_insert(float* lsu, int* liu, int* cntp, int K, float sc,
+                                                 int gi, int lane) {
+    const int n = __builtin_amdgcn_readfirstlane(*cntp);
+    float es = CRH_NEG_INF;
+    int ei = CRH_PAD_IDX;
+    if (lane < n) {
+        es = lsu[lane];
+        ei = liu[lane];
+    }
+    const bool ahead = lane < n && crh_better(es, ei, sc, gi);
+    const int p = __popcll(__ballot(ahead));
+    if (p < K) {
+        if (lane >= p && lane < n && lane + 1 < K) {
+            lsu[lane + 1] = es;
+            liu[lane + 1] = ei;
+        }
+        if (lane == 0) {
+            lsu[p] = sc;
+            liu[p] = gi;
+            *cntp = n < K ? n + 1 : K;
+        }
+    }
+}
+
+// true when the candidate cannot enter a FULL list even at its best possible value
+// (the masked value -1e9 may exceed a raw score below -1e9, hence the max)
+__device__ __forceinline__ bool wave_list_rejects(const float* lsu, const int* liu, int n, int K,
+                                                  float sc, int gi) {
+    if (n < K) return false;
+    const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lsu[K - 1])));
+    const int ki = __builtin_amdgcn_readfirstlane(liu[K - 1]);
+    const float ub = fmaxf(sc, CRH_MASKED_SCORE);
+    return !crh_better(ub, gi, ks, ki);
+}
+
+// Is global item gi masked for block slot `slot`?  bitmap bit or membership in the user's
+// ascending rated list (wave-parallel scan, 64 entries per step).  Wave-uniform result.
+__device__ __forceinline__ bool wave_is_masked(int gi, int64_t slot, const int64_t* rated_rowptr,
+                                               const int32_t* rated_col, const uint32_t* bitmap,
+                                               int lane) {
+    if (bitmap) {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(bitmap[gi >> 5]);
+        if ((w >> (gi & 31)) & 1u) return true;
+    }
+    if (rated_rowptr) {
+        const int64_t lo = rated_rowptr[slot];
+        const int64_t hi = rated_rowptr[slot + 1];
+        for (int64_t base = lo; base < hi; base += 64) {
+            const int64_t e = base + lane;
+            const int v = e < hi ? rated_col[e] : CRH_PAD_IDX;
+            if (__ballot(v == gi) != 0ull) return true;
+            if (__ballot(v > gi) != 0ull) break;   // ascending: no later match
+        }
+    }
+    return false;
+}
+
+// fast-path threshold for a list: its k-th score once full, but never above what a masked
+// (-1e9) candidate could beat, so that skipping `raw <= tau` stays exact
+__device__ __forceinline__ float wave_list_tau(const float* lsu, int n, int K) {
+    if (n < K) return CRH_NEG_INF;
+    const float t = lsu[K - 1];
+    return t >= CRH_MASKED_SCORE ? t : CRH_NEG_INF;
+}

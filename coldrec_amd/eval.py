@@ -1,0 +1,53 @@
+"""Full-catalogue evaluation over a row-sharded item table.
+
+GPU g owns item rows [g*I/G, (g+1)*I/G); the user table, the rated CSR and the candidate bitmap
+are replicated.  Each rank runs the fused scoring/top-k kernel over its shard (global ids via
+``item_base``), then ONE all-gather of the packed per-shard top-k (k scores + k ids per user,
+8*k bytes) and the canonical merge -- so the result is independent of G.  With G == 1 there is
+no collective at all.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range of ``rank`` (same rule everywhere: bench, trainer, tests)."""
+    return rank * n_items // world, (rank + 1) * n_items // world
+
+
+class ShardedTopK:
+    def __init__(self, item_shard: torch.Tensor, item_base: int, n_items_global: int, k: int,
+                 world: int = 1, rank: int = 0, group=None,
+                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None):
+        self.items = item_shard
+        self.item_base = int(item_base)
+        self.n_items_global = int(n_items_global)
+        self.k = int(k)
+        self.world, self.rank, self.group = world, rank, group
+        # injectable for the CPU (gloo) plumbing tests; the product path is the HIP ops
+        self._local_topk = local_topk or ops.score_topk
+        self._merge = merge or ops.merge_topk
+
+    def topk(self, user_emb, users, rated_rowptr=None, rated_col=None, cand_bitmap=None, n_splits: int = 0,
+             kernel_events=None):
+        kw = {}
+        if kernel_events is not None:
+            kw["kernel_events"] = kernel_events
+        if n_splits:
+            kw["n_splits"] = n_splits
+        s, i = self._local_topk(user_emb, users, self.items, self.k, rated_rowptr, rated_col, cand_bitmap,
+                                item_base=self.item_base, **kw)
+        if self.world == 1:
+            return s, i
+        import torch.distributed as dist
+        packed = torch.cat([s.view(torch.int32), i], dim=1).contiguous()          # (Bu, 2k) int32
+        gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int32, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        gs = gathered[:, :, :self.k].contiguous().view(torch.float32)
+        gi = gathered[:, :, self.k:].contiguous()
+        return self._merge(gs, gi, self.k)

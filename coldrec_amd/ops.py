@@ -1,0 +1,142 @@
+"""Torch-tensor front ends of the C ABI (include/coldrec_hip.h).  Device memory and streams
+come from PyTorch-ROCm; all arithmetic happens in libcoldrec_hip.so.  No CPU fallback."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SUPPORTED_DIMS = (8, 16, 32, 64, 128, 256)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("coldrec_amd ops need tensors on the MI355X (cuda device); there is no CPU path")
+
+
+def pad_dim(table: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the embedding width to the next width the MFMA kernel is built for.
+    Trailing zeros are exact no-ops of the fp32 fma chain (fma(0,0,s) == s, s never -0)."""
+    d = table.shape[1]
+    if d in SUPPORTED_DIMS:
+        return table
+    for w in SUPPORTED_DIMS:
+        if w > d:
+            out = torch.zeros((table.shape[0], w), dtype=table.dtype, device=table.device)
+            out[:, :d] = table
+            return out
+    raise RuntimeError(f"embedding width {d} > 256 is not supported by score_topk")
+
+
+def make_bitmap(n_items_global: int, masked_ids, device) -> Optional[torch.Tensor]:
+    """uint32 words (stored as int32), bit (gi & 31) of word gi >> 5 set => item gi is masked."""
+    if masked_ids is None or len(masked_ids) == 0:
+        return None
+    words = np.zeros((n_items_global + 31) // 32 + 1, dtype=np.uint32)
+    ids = np.asarray(masked_ids, dtype=np.int64)
+    np.bitwise_or.at(words, ids >> 5, np.uint32(1) << (ids & 31).astype(np.uint32))
+    return torch.from_numpy(words.view(np.int32)).to(device)
+
+
+def rated_csr(rated_lists, device) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Per-slot ascending int32 global item ids + int64 row offsets from a list of id arrays."""
+    lens = np.fromiter((0 if r is None else len(r) for r in rated_lists), dtype=np.int64,
+                       count=len(rated_lists))
+    if lens.sum() == 0:
+        return None, None
+    rowptr = np.zeros(len(rated_lists) + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    col = np.empty(int(rowptr[-1]), np.int32)
+    for r, ids in enumerate(rated_lists):
+        if lens[r]:
+            col[rowptr[r]:rowptr[r + 1]] = np.sort(np.asarray(ids, dtype=np.int64))
+    return torch.from_numpy(rowptr).to(device), torch.from_numpy(col).to(device)
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def score_topk(user_emb: torch.Tensor, users: Optional[torch.Tensor], item_emb: torch.Tensor, k: int,
+               rated_rowptr: Optional[torch.Tensor] = None, rated_col: Optional[torch.Tensor] = None,
+               cand_bitmap: Optional[torch.Tensor] = None, item_base: int = 0, n_splits: int = 0,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kernel_events=None):
+    """Fused ``user_emb[users] @ item_emb.T`` -> masks -> top-k (model/MF.py:58-63 +
+    model/BaseRecommender.py:175-182).  Returns (scores fp32, global item ids int32), each
+    (n_users, k), canonical order.  ``users`` int32 rows of user_emb or None for all rows.
+    ``kernel_events``: optional (hipEvent_t, hipEvent_t) raw handles recorded around the scoring
+    kernel alone (bench.py's roofline measurement)."""
+    _need_cuda(user_emb, users, item_emb, rated_rowptr, rated_col, cand_bitmap)
+    if user_emb.dtype != torch.float32 or item_emb.dtype != torch.float32:
+        raise RuntimeError("score_topk: fp32 tables expected")
+    if user_emb.shape[1] != item_emb.shape[1]:
+        raise RuntimeError("score_topk: user/item embedding widths differ")
+    user_emb, item_emb = pad_dim(user_emb.contiguous()), pad_dim(item_emb.contiguous())
+    if users is not None:
+        users = users.to(torch.int32).contiguous()
+    n_users = user_emb.shape[0] if users is None else users.shape[0]
+    n_items, d = item_emb.shape
+    if rated_rowptr is not None:
+        assert rated_rowptr.dtype == torch.int64 and rated_col.dtype == torch.int32
+        assert rated_rowptr.shape[0] == n_users + 1
+    if cand_bitmap is not None:
+        assert cand_bitmap.dtype == torch.int32
+    dev = user_emb.device
+    if out is None:
+        out = (torch.empty((n_users, k), dtype=torch.float32, device=dev),
+               torch.empty((n_users, k), dtype=torch.int32, device=dev))
+    L = _lib.lib()
+    ws_bytes = L.crh_score_topk_workspace_bytes(n_users, n_items, d, k)
+    ws = _workspace(ws_bytes, dev)
+    rc = L.crh_score_topk_f32_ex(_lib.ptr(user_emb), _lib.ptr(users), n_users, _lib.ptr(item_emb), n_items, d,
+                                 _lib.ptr(rated_rowptr), _lib.ptr(rated_col), _lib.ptr(cand_bitmap), k,
+                                 item_base, _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(ws), ws.numel(),
+                                 _lib.current_stream(), n_splits,
+                                 kernel_events[0] if kernel_events else None,
+                                 kernel_events[1] if kernel_events else None)
+    _lib.check(rc, "crh_score_topk_f32")
+    return out
+
+
+def mask_topk(scores: torch.Tensor, k: int, rated_rowptr=None, rated_col=None, cand_bitmap=None,
+              item_base: int = 0, write_back: bool = True):
+    """Masks + top-k over a dense (n_users, n_items) fp32 block (model/BaseRecommender.py:175-183)."""
+    _need_cuda(scores, rated_rowptr, rated_col, cand_bitmap)
+    assert scores.dtype == torch.float32 and scores.dim() == 2 and scores.stride(1) == 1
+    n_users, n_items = scores.shape
+    dev = scores.device
+    out = (torch.empty((n_users, k), dtype=torch.float32, device=dev),
+           torch.empty((n_users, k), dtype=torch.int32, device=dev))
+    rc = _lib.lib().crh_mask_topk_f32(_lib.ptr(scores), n_users, n_items, scores.stride(0),
+                                      _lib.ptr(rated_rowptr), _lib.ptr(rated_col), _lib.ptr(cand_bitmap), k,
+                                      item_base, 1 if write_back else 0, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                      _lib.current_stream())
+    _lib.check(rc, "crh_mask_topk_f32")
+    return out
+
+
+def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k_out: int):
+    """Canonical merge of (n_lists, n_users, k_in) partial lists -> (n_users, k_out)."""
+    _need_cuda(scores, idx)
+    assert scores.dtype == torch.float32 and idx.dtype == torch.int32
+    scores, idx = scores.contiguous(), idx.contiguous()
+    n_lists, n_users, k_in = scores.shape
+    dev = scores.device
+    out = (torch.empty((n_users, k_out), dtype=torch.float32, device=dev),
+           torch.empty((n_users, k_out), dtype=torch.int32, device=dev))
+    rc = _lib.lib().crh_merge_topk(_lib.ptr(scores), _lib.ptr(idx), n_lists, n_users, k_in, k_out,
+                                   _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.current_stream())
+    _lib.check(rc, "crh_merge_topk")
+    return out

@@ -1,0 +1,101 @@
+/*
+ * coldrec_hip.h -- C ABI of libcoldrec_hip.so (MI355X / gfx950).
+ *
+ * The upstream project (YuanchenBei/ColdRec) is pure Python and has NO FFI of its own; the
+ * hot path is a handful of PyTorch calls.  Each entry point below names the reference call
+ * site it replaces (file:line relative to the upstream repository); INTEGRATION.md shows the
+ * ctypes binding a ColdRec maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - nothing is allocated or freed here: the caller owns every buffer (PyTorch's caching
+ *     allocator in our host layer); scratch is passed in after a *_workspace_bytes() query;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - return 0 on success, <0 on error; crh_last_error() gives the thread-local message;
+ *   - item / user ids are int32 (catalogues up to 2^31-2 rows); row offsets are int64.
+ *   - top-k lists are ordered by the CANONICAL key (score descending, global item index
+ *     ascending); lists with fewer than k candidates are padded with (-inf, CRH_PAD_IDX).
+ */
+#ifndef COLDREC_HIP_H
+#define COLDREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRH_OK 0
+#define CRH_ERR_ARG (-1)     /* bad argument (NULL, unsupported d / k, misaligned pointer) */
+#define CRH_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define CRH_ERR_WS (-3)      /* workspace too small */
+#define CRH_PAD_IDX 0x7fffffff
+#define CRH_MASKED_SCORE (-1.0e9f) /* -10e8, model/BaseRecommender.py:177,180 */
+#define CRH_MAX_K 64
+
+const char* crh_last_error(void);
+int crh_version(void);
+/* 1 when the embedding width is handled by the MFMA kernel without padding (8,16,32,64,128,256) */
+int crh_score_topk_supports_dim(int d);
+
+/*
+ * Fused full-catalogue scoring + masking + top-k for one block of users against one item shard.
+ * Replaces, per user block of BaseColdStartTrainer._evaluate (model/BaseRecommender.py:172-183):
+ *     batch_predict:  user_emb[users] @ item_emb.T            model/MF.py:58-63 (+21 copies)
+ *     S[j, rated_j] = -10e8 ; S[:, candidate_mask] = -10e8    model/BaseRecommender.py:175-180
+ *     torch.topk(S, max_N, dim=1, largest=True, sorted=True)  model/BaseRecommender.py:182
+ * without materialising S.  score(u,i) is the fp32 k-ascending fma chain (exact fp32 MFMA).
+ *
+ *   user_emb   (n_user_rows, d) fp32 row-major, 16-byte aligned
+ *   users      (n_users) int32 rows of user_emb for the block, or NULL for rows 0..n_users-1
+ *   item_emb   (n_items, d) fp32: rows [item_base, item_base+n_items) of the item table
+ *   rated_rowptr (n_users+1) int64 / rated_col int32: per block slot, the GLOBAL ids of the
+ *              user's training items, ascending within a row; both NULL = nothing rated
+ *   cand_bitmap  bit (gi & 31) of word gi>>5 set => global item gi is masked; NULL = none
+ *   k          1..CRH_MAX_K;  out_score/out_idx (n_users, k), idx are GLOBAL item ids
+ *   workspace  crh_score_topk_workspace_bytes(...) bytes
+ */
+size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k);
+int crh_score_topk_f32(const float* user_emb, const int32_t* users, int64_t n_users,
+                       const float* item_emb, int64_t n_items, int d,
+                       const int64_t* rated_rowptr, const int32_t* rated_col,
+                       const uint32_t* cand_bitmap, int k, int64_t item_base,
+                       float* out_score, int32_t* out_idx,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Tuning / test / measurement hook: same as above with the item-range split count forced
+ * (0 = automatic; results are identical for every split count, canonical merge) and two
+ * optional hipEvent_t (as void*, may be NULL) recorded on `stream` immediately before and
+ * after the scoring kernel itself, so a caller can time that kernel apart from the merge. */
+int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n_users,
+                          const float* item_emb, int64_t n_items, int d,
+                          const int64_t* rated_rowptr, const int32_t* rated_col,
+                          const uint32_t* cand_bitmap, int k, int64_t item_base,
+                          float* out_score, int32_t* out_idx,
+                          void* workspace, size_t workspace_bytes, void* stream, int n_splits,
+                          void* ev_kernel_start, void* ev_kernel_stop);
+
+/*
+ * Mask + top-k over an already materialised dense score block (any batch_predict, e.g.
+ * model/VBPR.py:68-75, model/ALDI.py:149-160): model/BaseRecommender.py:175-183.
+ * scores (n_users, row_stride) fp32; masked entries are also written back as -1e9 when
+ * write_back != 0 (the reference mutates the block in place).
+ */
+int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items, int64_t row_stride,
+                      const int64_t* rated_rowptr, const int32_t* rated_col,
+                      const uint32_t* cand_bitmap, int k, int64_t item_base, int write_back,
+                      float* out_score, int32_t* out_idx, void* stream);
+
+/*
+ * Canonical merge of n_lists partial top-k lists per user, layout [list][user][k_in]
+ * (item-range splits inside one GPU; shards after the all-gather).
+ * n_lists <= 64, k_out <= CRH_MAX_K.
+ */
+int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, int64_t n_users,
+                   int k_in, int k_out, float* out_score, int32_t* out_idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLDREC_HIP_H */

@@ -1,0 +1,217 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP scoring/top-k path, called through
+the C ABI, against the CPU oracle (bit-exact scores and indices) and against the golden
+vectors captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as orc
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _gpu_score_topk(U, users, V, k, rowptr=None, col=None, bitmap_ids=None, item_base=0, n_splits=0,
+                    n_items_global=None):
+    from coldrec_amd import ops
+    dev = _dev()
+    tU = torch.from_numpy(np.ascontiguousarray(U, np.float32)).to(dev)
+    tV = torch.from_numpy(np.ascontiguousarray(V, np.float32)).to(dev)
+    tu = None if users is None else torch.from_numpy(np.asarray(users, np.int32)).to(dev)
+    rp = rc = None
+    if rowptr is not None:
+        srp, src = orc.sort_rated(rowptr, col)
+        rp, rc = torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev)
+    ng = n_items_global if n_items_global is not None else item_base + V.shape[0]
+    bm = ops.make_bitmap(ng, bitmap_ids, dev)
+    s, i = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=item_base, n_splits=n_splits)
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
+def _oracle(U, users, V, k, rowptr=None, col=None, bitmap_ids=None, item_base=0, n_items_global=None):
+    ng = n_items_global if n_items_global is not None else item_base + V.shape[0]
+    bm = orc.make_bitmap(ng, bitmap_ids) if bitmap_ids is not None and len(bitmap_ids) else None
+    return orc.score_topk(U, users, V, k, rowptr, col, bm, item_base=item_base)
+
+
+def _same(got, want):
+    gs, gi = got
+    ws, wi = want
+    assert np.array_equal(gi, wi), f"indices differ at {np.argwhere(gi != wi)[:5]}"
+    assert np.array_equal(gs.view(np.uint32), ws.view(np.uint32)), "scores not bit-identical"
+
+
+@pytest.mark.parametrize("fix", ["item_cont", "item_fine", "item_quant", "user_cont", "user_fine", "small"])
+@pytest.mark.parametrize("t", ["all", "warm", "cold"])
+def test_golden_eval_fixtures(fix, t):
+    g = load_golden(f"g6_eval_{fix}.npz")
+    k = int(g["k"])
+    args = (g["U"], g[f"{t}_users_int"], g["V"], k, g[f"{t}_rated_rowptr"], g[f"{t}_rated_col"], g[f"{t}_cand"])
+    got = _gpu_score_topk(*args)
+    _same(got, _oracle(*args))
+    # against the reference itself: exact indices wherever it returned an unmasked score
+    # (tie fixtures: only the strictly-above-threshold set is order-defined)
+    real = g[f"{t}_score"] > -1e8
+    if fix != "item_quant":
+        assert np.array_equal(got[1][real], g[f"{t}_idx"][real])
+        np.testing.assert_allclose(got[0], g[f"{t}_score"], rtol=1e-5, atol=1e-6)
+    else:
+        np.testing.assert_array_equal(got[0], g[f"{t}_score"])
+
+
+def _random_case(rng, n_user_rows, n_users, n_items, d, rated_mean, frac_bitmap, dup_items=False, scale=0.5):
+    U = (rng.standard_normal((n_user_rows, d)) * scale).astype(np.float32)
+    V = (rng.standard_normal((n_items, d)) * scale).astype(np.float32)
+    if dup_items and n_items > 8:
+        V[rng.integers(0, n_items, n_items // 3)] = V[rng.integers(0, n_items, n_items // 3)]
+    users = rng.permutation(n_user_rows)[:n_users].astype(np.int64)
+    rated = [np.unique(rng.integers(0, n_items, rng.poisson(rated_mean))) if rated_mean else np.zeros(0, np.int64)
+             for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64) if len(rated) else np.zeros(0, np.int64)
+    bm = np.where(rng.random(n_items) < frac_bitmap)[0] if frac_bitmap else None
+    return U, users, V, rowptr, col, bm
+
+
+@pytest.mark.parametrize("d", [8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("n_users,n_items,k", [(1, 1, 1), (3, 31, 20), (33, 33, 20), (130, 1000, 20),
+                                               (257, 4097, 64), (64, 20000, 10)])
+def test_random_ragged_shapes_bit_exact(d, n_users, n_items, k):
+    rng = np.random.default_rng(1000 * d + n_users + n_items)
+    U, users, V, rowptr, col, bm = _random_case(rng, max(n_users, 40), n_users, n_items, d, 12, 0.2,
+                                                dup_items=True)
+    for splits in (0, 1, 5):
+        got = _gpu_score_topk(U, users, V, k, rowptr, col, bm, n_splits=splits)
+        _same(got, _oracle(U, users, V, k, rowptr, col, bm))
+
+
+def test_unsupported_width_is_zero_padded_exactly():
+    rng = np.random.default_rng(2)
+    U, users, V, rowptr, col, bm = _random_case(rng, 50, 50, 2000, 100, 10, 0.1)   # d=100 -> 128
+    _same(_gpu_score_topk(U, users, V, 20, rowptr, col, bm), _oracle(U, users, V, 20, rowptr, col, bm))
+
+
+def test_no_masks_identity_users_and_item_base():
+    rng = np.random.default_rng(3)
+    U, _, V, rowptr, col, bm = _random_case(rng, 70, 70, 3000, 64, 20, 0.1)
+    _same(_gpu_score_topk(U, None, V, 20), _oracle(U, None, V, 20))
+    # a shard in the middle of a larger catalogue: global ids, masks in global coordinates
+    base, ng = 5000, 9000
+    col_g = col + base
+    bm_g = bm + base
+    got = _gpu_score_topk(U, None, V, 20, rowptr, col_g, bm_g, item_base=base, n_items_global=ng)
+    _same(got, _oracle(U, None, V, 20, rowptr, col_g, bm_g, item_base=base, n_items_global=ng))
+    assert got[1].min() >= base
+
+
+def test_adversarial_orders_and_ties():
+    rng = np.random.default_rng(4)
+    d, n_items = 32, 6000
+    V = np.zeros((n_items, d), np.float32)
+    V[:, 0] = np.arange(n_items) / 64.0            # scores strictly increasing with the index:
+    U = np.zeros((40, d), np.float32)              # every item beats the running threshold
+    U[:, 0] = 1.0
+    U[20:, 0] = -1.0                               # ... and strictly decreasing for the other half
+    _same(_gpu_score_topk(U, None, V, 20, n_splits=1), _oracle(U, None, V, 20))
+    # heavy ties: 2^-2 grid, d=8 -> few distinct scores; canonical order must hold bit for bit
+    Uq = rng.integers(-2, 3, (50, 8)).astype(np.float32) / 4
+    Vq = rng.integers(-2, 3, (5000, 8)).astype(np.float32) / 4
+    for splits in (1, 4, 9):
+        _same(_gpu_score_topk(Uq, None, Vq, 20, n_splits=splits), _oracle(Uq, None, Vq, 20))
+    # all scores equal (zeros): the k lowest indices
+    Z = np.zeros((5, 16), np.float32)
+    s, i = _gpu_score_topk(Z, None, np.zeros((300, 16), np.float32), 20)
+    assert np.array_equal(i, np.tile(np.arange(20, dtype=np.int32), (5, 1))) and (s == 0).all()
+
+
+def test_everything_masked_and_fewer_items_than_k():
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((9, 16)).astype(np.float32)
+    V = rng.standard_normal((12, 16)).astype(np.float32)
+    rowptr = np.arange(0, 9 * 12 + 1, 12).astype(np.int64)
+    col = np.tile(np.arange(12), 9).astype(np.int64)
+    got = _gpu_score_topk(U, None, V, 20, rowptr, col)
+    _same(got, _oracle(U, None, V, 20, rowptr, col))
+    assert (got[0][:, :12] == np.float32(-1e9)).all() and np.isinf(got[0][:, 12:]).all()
+    assert (got[1][:, 12:] == 0x7FFFFFFF).all()
+    # scores below the mask value: a masked (-1e9) item must outrank an unmasked -3.2e9 one
+    U2 = np.full((2, 8), 1.0, np.float32)
+    V2 = np.full((200, 8), -4e8, np.float32)
+    rp2 = np.array([0, 3, 3], np.int64)
+    c2 = np.array([150, 7, 199], np.int64)
+    got = _gpu_score_topk(U2, None, V2, 5, rp2, c2)
+    _same(got, _oracle(U2, None, V2, 5, rp2, c2))
+    assert got[1][0].tolist()[:3] == [7, 150, 199]
+
+
+def test_merge_and_mask_topk_match_oracle():
+    from coldrec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(6)
+    U, users, V, rowptr, col, bm = _random_case(rng, 90, 90, 7000, 32, 15, 0.15, dup_items=True)
+    want = _oracle(U, users, V, 20, rowptr, col, bm)
+    # shards of unequal size merged on the GPU == unsharded
+    cuts = [0, 13, 2048, 2049, 6999, 7000]
+    ps, pi = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        s, i = _gpu_score_topk(U, users, V[lo:hi], 20, rowptr, col, bm, item_base=lo, n_items_global=7000)
+        ps.append(s); pi.append(i)
+    ms, mi = ops.merge_topk(torch.from_numpy(np.stack(ps)).to(dev), torch.from_numpy(np.stack(pi)).to(dev), 20)
+    _same((ms.cpu().numpy(), mi.cpu().numpy()), want)
+    # dense block path
+    S = orc.scores_dense(U, users, V)
+    srp, src = orc.sort_rated(rowptr, col)
+    tS = torch.from_numpy(S).to(dev)
+    ds, di = ops.mask_topk(tS, 20, torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev),
+                           ops.make_bitmap(7000, bm, dev), write_back=True)
+    _same((ds.cpu().numpy(), di.cpu().numpy()), want)
+    S_ref = S.copy()
+    orc.mask_topk(S_ref, 20, rowptr, col, orc.make_bitmap(7000, bm), write_back=True)
+    np.testing.assert_array_equal(tS.cpu().numpy(), S_ref)       # block mutated like the reference
+    # without write-back the block is untouched and the result identical
+    tS2 = torch.from_numpy(S).to(dev)
+    ds2, di2 = ops.mask_topk(tS2, 20, torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev),
+                             ops.make_bitmap(7000, bm, dev), write_back=False)
+    _same((ds2.cpu().numpy(), di2.cpu().numpy()), want)
+    np.testing.assert_array_equal(tS2.cpu().numpy(), S)
+
+
+def test_full_size_properties_eval_config():
+    """BASELINE config 4 shape on one GPU, scaled to what a test may take: 4096 users x 1M items,
+    d=128.  Size-independent properties: (1) independent of the item-range split count,
+    (2) shard + merge == whole, (3) sampled users equal the oracle bit for bit, (4) sorted."""
+    from coldrec_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n_users, n_items, d, k = 4096, 1_000_000, 128, 20
+    U = ((torch.rand((n_users, d), generator=g) * 2 - 1) * (6.0 / (n_users + d)) ** 0.5)
+    V = ((torch.rand((n_items, d), generator=g) * 2 - 1) * (6.0 / (n_items + d)) ** 0.5)
+    tU, tV = U.to(dev), V.to(dev)
+    rng = np.random.default_rng(8)
+    rated = [np.unique(rng.integers(0, n_items, 50)) for _ in range(n_users)]
+    rp, rc = ops.rated_csr(rated, dev)
+    cold = np.where(rng.random(n_items) < 0.2)[0]
+    bm = ops.make_bitmap(n_items, cold, dev)
+    s0, i0 = ops.score_topk(tU, None, tV, k, rp, rc, bm)
+    s1, i1 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=1)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    half = n_items // 2 + 77
+    sa, ia = ops.score_topk(tU, None, tV[:half], k, rp, rc, bm, item_base=0)
+    sb, ib = ops.score_topk(tU, None, tV[half:], k, rp, rc, bm, item_base=half)
+    sm, im = ops.merge_topk(torch.stack([sa, sb]), torch.stack([ia, ib]), k)
+    assert torch.equal(im, i0) and torch.equal(sm, s0)
+    s0n, i0n = s0.cpu().numpy(), i0.cpu().numpy()
+    assert (np.diff(s0n, axis=1) <= 0).all()
+    sample = rng.choice(n_users, 12, replace=False)
+    rpn = np.concatenate([[0], np.cumsum([len(rated[u]) for u in sample])]).astype(np.int64)
+    rcn = np.concatenate([rated[u] for u in sample]).astype(np.int64)
+    ws, wi = orc.score_topk(U.numpy(), sample.astype(np.int64), V.numpy(), k, rpn, rcn,
+                            orc.make_bitmap(n_items, cold))
+    assert np.array_equal(i0n[sample], wi)
+    assert np.array_equal(s0n[sample].view(np.uint32), ws.view(np.uint32))
