@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/...) into small summaries under profiles/.
+
+    python tools/prof_summary.py <tag> <stats_dir> [<pmc_dir> ...]
+
+Writes profiles/<tag>_kernel_stats.csv (the --stats table, our kernels first) and
+profiles/<tag>_pmc.json (per kernel: mean of every collected counter per launch).
+Counter corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950
+FETCH_SIZE reads half of a 16-B/lane stream, so hbm_read_bytes = FETCH_SIZE*1024*2.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    os.makedirs("profiles", exist_ok=True)
+    for f in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(f)))
+        head, body = rows[0], rows[1:]
+        body.sort(key=lambda r: (0 if ("score_topk" in r[0] or "crh" in r[0] or "anonymous namespace)::" in r[0][:40]) else 1,
+                                 -float(r[2])))
+        with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as o:
+            w = csv.writer(o)
+            w.writerow(head)
+            w.writerows(body[:25])
+    out = {}
+    for d in pmc_dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            agg = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in csv.DictReader(open(f)):
+                name = r["Kernel_Name"]
+                if "at::native" in name or "rocprim" in name:
+                    continue
+                agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                agg[name]["_duration_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                for key in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"):
+                    agg[name]["_" + key] = [float(r[key])]
+            for name, cs in agg.items():
+                o = out.setdefault(name, {})
+                for c, v in cs.items():
+                    o[c] = sum(v) / len(v)
+                    if not c.startswith("_"):
+                        o[c + "_launches"] = len(v)
+    for name, o in out.items():
+        if "FETCH_SIZE" in o:
+            o["hbm_read_bytes_corrected"] = o["FETCH_SIZE"] * 1024 * 2
+        if "WRITE_SIZE" in o:
+            o["hbm_write_bytes"] = o["WRITE_SIZE"] * 1024
+    with open(f"profiles/{tag}_pmc.json", "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True)[:3000])
+
+
+if __name__ == "__main__":
+    main()
