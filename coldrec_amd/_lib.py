@@ -21,6 +21,7 @@ MAX_K = 64
 _lib = None
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+_f64 = ctypes.c_double
 
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
 SIGNATURES = {
@@ -34,6 +35,19 @@ SIGNATURES = {
                                      _vp, _sz, _vp, _i32, _vp, _vp]),
     "crh_mask_topk_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "crh_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "crh_bpr_workspace_bytes": (_sz, [_i64]),
+    "crh_bpr_fwd_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp,
+                                   _sz, _vp]),
+    "crh_adam_dense_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
+                                  _i64, _i32, _vp]),
+    "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp]),
+    "crh_sampler_create": (_vp, [_vp, _vp, _i64, _i32, _i32]),
+    "crh_sampler_destroy": (None, [_vp]),
+    "crh_sampler_seed": (_i32, [_vp, ctypes.c_uint32]),
+    "crh_sampler_set_state": (_i32, [_vp, _vp, _i32]),
+    "crh_sampler_get_state": (_i32, [_vp, _vp, _vp]),
+    "crh_sampler_num_records": (_i64, [_vp]),
+    "crh_sampler_epoch": (_i32, [_vp, _i64, _vp, _vp, _vp]),
 }
 
 

@@ -1,0 +1,289 @@
+// BPR-MF training step for gfx950: gather + BPR/L2 forward + backward scatter-add, dense Adam.
+//
+// Replaces, per optimiser step of the reference trainers (model/MF.py:19-27,
+// model/LightGCN.py:21-28):
+//   gather      rec_user_emb[user_idx], rec_item_emb[pos_idx], rec_item_emb[neg_idx]   (aten::index)
+//   bpr_loss    util/utils.py:25-29      mean(-log(1e-5 + sigmoid(u.p - u.n)))
+//   l2_reg_loss util/utils.py:44-48      reg * (|U_B|_F + |P_B|_F + |N_B|_F) / B
+//   backward    autograd: index_put_(accumulate=True) into dense table gradients
+//   Adam        torch.optim.Adam defaults (torch/optim/adam.py _single_tensor_adam): EVERY element
+//               of both tables moves every step
+//
+// All of it is HBM/L2-bound row traffic: rows are read with 16 B per lane (one row of d=128 is
+// one 512-B transaction of a half-wave), reductions are wave shuffles, and the three Frobenius
+// norms -- a grid-wide dependency of the backward pass -- are carried as per-block partials that
+// every backward block re-reduces in the same fixed order (deterministic, no atomics, no memset).
+// Row gradients are accumulated with hardware fp32 atomics (global_atomic_add_f32).
+#include <math.h>
+
+#include <type_traits>
+
+#include "crh_common.h"
+
+namespace {
+
+constexpr int BPR_THREADS = 256;
+constexpr int BPR_MAX_BLOCKS = 1024;
+
+struct BprArgs {
+    const float* tu;   // user-side table      (rows x d)
+    const float* tp;   // positive-item table
+    const float* tn;   // negative-item table (== tp for MF / LightGCN)
+    const int32_t* iu; // row ids per triple, NULL = identity (already gathered tensors)
+    const int32_t* ip;
+    const int32_t* in_;
+    int64_t B;
+    int d;
+    float reg;
+    float* gu;         // dense gradient tables (accumulated into), may be NULL for forward only
+    float* gp;
+    float* gn;
+    float* xbuf;       // [B] pos-neg score difference
+    float* partials;   // [nblocks][4]: sum u^2, sum p^2, sum n^2, sum loss
+    float* loss_out;   // [2]: bpr, l2   (may be NULL)
+    int nblocks_fwd;
+};
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // deterministic: wave butterfly then fixed-order sum of the 4 wave results
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int G>
+__global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(BprArgs a) {
+    __shared__ float red[4];
+    const int lig = threadIdx.x % G;                 // lane in group
+    const int64_t gid = (int64_t)blockIdx.x * (BPR_THREADS / G) + threadIdx.x / G;
+    const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
+    const int nvec = a.d >> 2;
+    float su = 0.f, sp = 0.f, sn = 0.f, sl = 0.f;
+    for (int64_t b = gid; b < a.B; b += gstride) {
+        const int64_t ru = a.iu ? a.iu[b] : b, rp = a.ip ? a.ip[b] : b, rn = a.in_ ? a.in_[b] : b;
+        const f32x4* pu = reinterpret_cast<const f32x4*>(a.tu + ru * a.d);
+        const f32x4* pp = reinterpret_cast<const f32x4*>(a.tp + rp * a.d);
+        const f32x4* pn = reinterpret_cast<const f32x4*>(a.tn + rn * a.d);
+        float dp = 0.f, dn = 0.f;
+        for (int c = lig; c < nvec; c += G) {
+            const f32x4 u = pu[c], p = pp[c], n = pn[c];
+            dp += u.x * p.x + u.y * p.y + u.z * p.z + u.w * p.w;
+            dn += u.x * n.x + u.y * n.y + u.z * n.z + u.w * n.w;
+            su += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+            sp += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+            sn += n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w;
+        }
+        dp = group_sum<G>(dp);
+        dn = group_sum<G>(dn);
+        if (lig == 0) {
+            const float x = dp - dn;                          // pos_score - neg_score
+            a.xbuf[b] = x;
+            const float sig = 1.0f / (1.0f + expf(-x));
+            sl += -logf(1e-5f + sig);                       // 10e-6 literal of the reference
+        }
+    }
+    su = block_sum(su, red);
+    sp = block_sum(sp, red);
+    sn = block_sum(sn, red);
+    sl = block_sum(sl, red);
+    if (threadIdx.x == 0) {
+        float* o = a.partials + (size_t)blockIdx.x * 4;
+        o[0] = su; o[1] = sp; o[2] = sn; o[3] = sl;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_kernel(BprArgs a) {
+    __shared__ float red[4];
+    __shared__ float tot[4];
+    // every block reduces the forward partials in the same order -> identical, deterministic totals
+    for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) s += a.partials[(size_t)i * 4 + q];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) tot[q] = s;
+    }
+    __syncthreads();
+    const float invB = 1.0f / (float)a.B;
+    const float nu = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) {
+        a.loss_out[0] = tot[3] * invB;
+        a.loss_out[1] = a.reg * (nu * invB + np_ * invB + nn * invB);
+    }
+    if (!a.gu) return;
+    // d(reg*|X|_F/B)/dX = reg * X / (B*|X|_F)   (0 at X = 0, as autograd returns)
+    const float cu = nu > 0.f ? a.reg * invB / nu : 0.f;
+    const float cp = np_ > 0.f ? a.reg * invB / np_ : 0.f;
+    const float cn = nn > 0.f ? a.reg * invB / nn : 0.f;
+
+    const int lig = threadIdx.x % G;
+    const int64_t gid = (int64_t)blockIdx.x * (BPR_THREADS / G) + threadIdx.x / G;
+    const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
+    const int nvec = a.d >> 2;
+    for (int64_t b = gid; b < a.B; b += gstride) {
+        const int64_t ru = a.iu ? a.iu[b] : b, rp = a.ip ? a.ip[b] : b, rn = a.in_ ? a.in_[b] : b;
+        const float x = a.xbuf[b];
+        const float sig = 1.0f / (1.0f + expf(-x));
+        const float g = -invB * sig * (1.0f - sig) / (1e-5f + sig);
+        const f32x4* pu = reinterpret_cast<const f32x4*>(a.tu + ru * a.d);
+        const f32x4* pp = reinterpret_cast<const f32x4*>(a.tp + rp * a.d);
+        const f32x4* pn = reinterpret_cast<const f32x4*>(a.tn + rn * a.d);
+        float* gu = a.gu + ru * a.d;
+        float* gp = a.gp + rp * a.d;
+        float* gn = a.gn + rn * a.d;
+        for (int c = lig; c < nvec; c += G) {
+            const f32x4 u = pu[c], p = pp[c], n = pn[c];
+            const int o = c * 4;
+            unsafeAtomicAdd(gu + o + 0, g * (p.x - n.x) + cu * u.x);
+            unsafeAtomicAdd(gu + o + 1, g * (p.y - n.y) + cu * u.y);
+            unsafeAtomicAdd(gu + o + 2, g * (p.z - n.z) + cu * u.z);
+            unsafeAtomicAdd(gu + o + 3, g * (p.w - n.w) + cu * u.w);
+            unsafeAtomicAdd(gp + o + 0, g * u.x + cp * p.x);
+            unsafeAtomicAdd(gp + o + 1, g * u.y + cp * p.y);
+            unsafeAtomicAdd(gp + o + 2, g * u.z + cp * p.z);
+            unsafeAtomicAdd(gp + o + 3, g * u.w + cp * p.w);
+            unsafeAtomicAdd(gn + o + 0, -g * u.x + cn * n.x);
+            unsafeAtomicAdd(gn + o + 1, -g * u.y + cn * n.y);
+            unsafeAtomicAdd(gn + o + 2, -g * u.z + cn * n.z);
+            unsafeAtomicAdd(gn + o + 3, -g * u.w + cn * n.w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dense Adam (+ zero the gradient)
+struct AdamSeg {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    int64_t n4;   // elements / 4
+};
+
+__global__ __launch_bounds__(256) void adam_dense_kernel(AdamSeg s0, AdamSeg s1, float one_minus_b1, float b2,
+                                                         float one_minus_b2, float bc2_sqrt, float eps,
+                                                         float neg_step_size, int zero_grad) {
+    const int64_t total = s0.n4 + s1.n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const bool first = i < s0.n4;
+        const AdamSeg& s = first ? s0 : s1;
+        const int64_t j = first ? i : i - s0.n4;
+        f32x4* P = reinterpret_cast<f32x4*>(s.p) + j;
+        f32x4* G = reinterpret_cast<f32x4*>(s.g) + j;
+        f32x4* M = reinterpret_cast<f32x4*>(s.m) + j;
+        f32x4* V = reinterpret_cast<f32x4*>(s.v) + j;
+        f32x4 p = *P, g = *G, m = *M, v = *V;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            m[c] = m[c] + one_minus_b1 * (g[c] - m[c]);                 // exp_avg.lerp_(grad, 1-b1)
+            v[c] = v[c] * b2 + (one_minus_b2 * g[c]) * g[c];             // mul_(b2).addcmul_(g, g, 1-b2)
+            const float denom = sqrtf(v[c]) / bc2_sqrt + eps;            // sqrt()/bc2_sqrt + eps
+            p[c] = p[c] + neg_step_size * (m[c] / denom);                // addcdiv_(m, denom, -step_size)
+        }
+        *P = p; *M = m; *V = v;
+        if (zero_grad) *G = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+int pick_group(int d) {
+    const int nvec = d / 4;
+    int g = 1;
+    while (g < nvec && g < 64) g <<= 1;
+    return g;
+}
+
+template <typename F>
+int dispatch_group(int g, F&& f) {
+    switch (g) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 4: return f(std::integral_constant<int, 4>());
+        case 8: return f(std::integral_constant<int, 8>());
+        case 16: return f(std::integral_constant<int, 16>());
+        case 32: return f(std::integral_constant<int, 32>());
+        default: return f(std::integral_constant<int, 64>());
+    }
+}
+
+}  // namespace
+
+extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
+    if (batch <= 0) return 0;
+    return (size_t)batch * 4 + (size_t)BPR_MAX_BLOCKS * 16 + 256;
+}
+
+extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table,
+                                   int d, const int32_t* user_idx, const int32_t* pos_idx,
+                                   const int32_t* neg_idx, int64_t batch, float reg, float* grad_user,
+                                   float* grad_pos, float* grad_neg, float* loss_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    CRH_CHECK_ARG(user_table && pos_table && neg_table, "crh_bpr_fwd_bwd_f32: NULL table");
+    CRH_CHECK_ARG(batch > 0, "crh_bpr_fwd_bwd_f32: empty batch");
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_bpr_fwd_bwd_f32: d=%d must be a positive multiple of 4", d);
+    CRH_CHECK_ARG((grad_user == nullptr) == (grad_pos == nullptr) && (grad_pos == nullptr) == (grad_neg == nullptr),
+                  "crh_bpr_fwd_bwd_f32: give all three gradient tables or none");
+    CRH_CHECK_ARG((((uintptr_t)user_table | (uintptr_t)pos_table | (uintptr_t)neg_table | (uintptr_t)grad_user |
+                    (uintptr_t)grad_pos | (uintptr_t)grad_neg) & 15) == 0,
+                  "crh_bpr_fwd_bwd_f32: tables must be 16-byte aligned");
+    if (!workspace || workspace_bytes < crh_bpr_workspace_bytes(batch)) {
+        crh_set_error("crh_bpr_fwd_bwd_f32: workspace %zu < %zu bytes", workspace_bytes, crh_bpr_workspace_bytes(batch));
+        return CRH_ERR_WS;
+    }
+    BprArgs a;
+    a.tu = user_table; a.tp = pos_table; a.tn = neg_table;
+    a.iu = user_idx; a.ip = pos_idx; a.in_ = neg_idx;
+    a.B = batch; a.d = d; a.reg = reg;
+    a.gu = grad_user; a.gp = grad_pos; a.gn = grad_neg;
+    a.partials = reinterpret_cast<float*>(workspace);
+    a.xbuf = a.partials + (size_t)BPR_MAX_BLOCKS * 4;
+    a.loss_out = loss_out;
+    const int G = pick_group(d);
+    const int64_t per_block = BPR_THREADS / G;
+    int64_t blocks = (batch + per_block - 1) / per_block;
+    if (blocks > BPR_MAX_BLOCKS) blocks = BPR_MAX_BLOCKS;
+    a.nblocks_fwd = (int)blocks;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dispatch_group(G, [&](auto gc) -> int {
+        constexpr int GG = decltype(gc)::value;
+        hipLaunchKernelGGL(bpr_fwd_kernel<GG>, dim3((unsigned)blocks), dim3(BPR_THREADS), 0, st, a);
+        CRH_HIP(hipGetLastError());
+        const unsigned bwd_blocks = (grad_user || loss_out) ? (grad_user ? (unsigned)blocks : 1u) : 0u;
+        if (bwd_blocks) {
+            hipLaunchKernelGGL(bpr_bwd_kernel<GG>, dim3(bwd_blocks), dim3(BPR_THREADS), 0, st, a);
+            CRH_HIP(hipGetLastError());
+        }
+        return CRH_OK;
+    });
+}
+
+extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0, float* p1, float* g1,
+                                  float* m1, float* v1, int64_t n1, double lr, double beta1, double beta2,
+                                  double eps, int64_t step, int zero_grad, void* stream) {
+    CRH_CHECK_ARG(p0 && g0 && m0 && v0 && n0 > 0, "crh_adam_dense_f32: NULL / empty first tensor");
+    CRH_CHECK_ARG(n1 == 0 || (p1 && g1 && m1 && v1), "crh_adam_dense_f32: NULL second tensor");
+    CRH_CHECK_ARG(n0 % 4 == 0 && n1 % 4 == 0, "crh_adam_dense_f32: element counts must be multiples of 4");
+    CRH_CHECK_ARG(step >= 1, "crh_adam_dense_f32: step starts at 1");
+    // scalar factors in double like torch (python floats), then cast
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    AdamSeg s0{p0, g0, m0, v0, n0 / 4}, s1{p1, g1, m1, v1, n1 / 4};
+    const int64_t total = s0.n4 + s1.n4;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       s0, s1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
+                       (float)(-(lr / bc1)), zero_grad);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}

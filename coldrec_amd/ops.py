@@ -140,3 +140,59 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k_out: int):
                                    _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.current_stream())
     _lib.check(rc, "crh_merge_topk")
     return out
+
+
+# ------------------------------------------------------------------------------ training ops
+def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, reg: float,
+                grad_user=None, grad_pos=None, grad_neg=None, loss_out: Optional[torch.Tensor] = None):
+    """bpr_loss + l2_reg_loss and their dense table gradients for one batch of triples
+    (util/utils.py:25-29,44-48 + autograd at model/MF.py:22-26).  ``*_idx`` int32 device tensors or
+    None (tables are already gathered).  Gradients are ACCUMULATED into ``grad_*`` (all three or
+    none).  Returns ``loss_out`` = device tensor [bpr, l2]."""
+    _need_cuda(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, grad_user, grad_pos, grad_neg)
+    d = user_table.shape[1]
+    batch = user_idx.shape[0] if user_idx is not None else user_table.shape[0]
+    for t in (user_table, pos_table, neg_table):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == d
+    for ix in (user_idx, pos_idx, neg_idx):
+        assert ix is None or (ix.dtype == torch.int32 and ix.is_contiguous() and ix.shape[0] == batch)
+    dev = user_table.device
+    if loss_out is None:
+        loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws = _workspace(L.crh_bpr_workspace_bytes(batch), dev)   # same grow-only scratch as score_topk
+    rc = L.crh_bpr_fwd_bwd_f32(_lib.ptr(user_table), _lib.ptr(pos_table), _lib.ptr(neg_table), d,
+                               _lib.ptr(user_idx), _lib.ptr(pos_idx), _lib.ptr(neg_idx), batch, float(reg),
+                               _lib.ptr(grad_user), _lib.ptr(grad_pos), _lib.ptr(grad_neg), _lib.ptr(loss_out),
+                               _lib.ptr(ws), ws.numel(), _lib.current_stream())
+    _lib.check(rc, "crh_bpr_fwd_bwd_f32")
+    return loss_out
+
+
+def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+               zero_grad: bool = True, second=None):
+    """In-place dense Adam on (p, g, m, v) [and ``second`` = another such 4-tuple] -- model/MF.py:14,27."""
+    ts = (p, g, m, v) + (tuple(second) if second else ())
+    _need_cuda(*ts)
+    for t in ts:
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    n0 = p.numel()
+    s = second if second else (None, None, None, None)
+    n1 = s[0].numel() if second else 0
+    rc = _lib.lib().crh_adam_dense_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n0,
+                                       _lib.ptr(s[0]), _lib.ptr(s[1]), _lib.ptr(s[2]), _lib.ptr(s[3]), n1,
+                                       float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                                       1 if zero_grad else 0, _lib.current_stream())
+    _lib.check(rc, "crh_adam_dense_f32")
+
+
+def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0):
+    """P = A @ x; y = P; acc_out = (acc_in*s_in + P)*s_out  (model/LightGCN.py:88-93, fused layer sum)."""
+    _need_cuda(rowptr, col, val, x, y, acc_in, acc_out)
+    assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    n_rows, d = rowptr.shape[0] - 1, x.shape[1]
+    rc = _lib.lib().crh_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
+                                     _lib.ptr(y), _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
+                                     _lib.current_stream())
+    _lib.check(rc, "crh_spmm_csr_f32")

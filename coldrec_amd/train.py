@@ -1,0 +1,105 @@
+"""Device-resident training engines for the warm-embedding trainers (BPR-MF, LightGCN).
+
+State layout in HBM: ONE (user_num + item_num, d) fp32 buffer per quantity -- parameters E,
+gradient G, Adam moments M and V -- with the user rows first.  ``user_emb`` / ``item_emb`` are
+views, so LightGCN's torch.cat (model/LightGCN.py:87) costs nothing and Adam is one segment.
+A step is 3 kernel launches for MF (forward partials, backward scatter, Adam) and 3 + 2L + 1 for
+LightGCN; nothing is copied to the host unless the caller asks for the loss.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class _TableState:
+    def __init__(self, user0, item0, lr: float, reg: float, device):
+        u = torch.as_tensor(np.asarray(user0, np.float32) if not torch.is_tensor(user0) else user0.detach().float())
+        v = torch.as_tensor(np.asarray(item0, np.float32) if not torch.is_tensor(item0) else item0.detach().float())
+        assert u.shape[1] == v.shape[1] and u.shape[1] % 4 == 0, "embedding width must be a multiple of 4"
+        self.user_num, self.item_num, self.d = u.shape[0], v.shape[0], u.shape[1]
+        self.device = torch.device(device)
+        self.E = torch.cat([u, v], 0).to(self.device).contiguous()
+        self.G = torch.zeros_like(self.E)
+        self.M = torch.zeros_like(self.E)
+        self.V = torch.zeros_like(self.E)
+        self.lr, self.reg = float(lr), float(reg)
+        self.step_count = 0
+        self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+
+    @property
+    def user_emb(self):
+        return self.E[: self.user_num]
+
+    @property
+    def item_emb(self):
+        return self.E[self.user_num:]
+
+    def last_loss(self) -> float:
+        """bpr + l2 of the last step (device -> host sync; the reference prints it every 50 batches)."""
+        return float(self.loss.sum().item())
+
+
+class MFEngine(_TableState):
+    """model/MF.py:12-29 with the tables resident on the GPU."""
+
+    def step(self, user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor) -> None:
+        U = self.user_num
+        ops.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
+                        self.G[:U], self.G[U:], self.G[U:], self.loss)
+        self.step_count += 1
+        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True)
+
+    def forward(self):
+        return self.user_emb, self.item_emb
+
+
+class LGCNEngine(_TableState):
+    """model/LightGCN.py:14-29,86-96: full-graph L-layer propagation per batch and its backward."""
+
+    def __init__(self, user0, item0, rowptr, col, val, n_layers: int, lr: float, reg: float, device):
+        super().__init__(user0, item0, lr, reg, device)
+        assert n_layers >= 1
+        self.L = int(n_layers)
+        dev = self.device
+        self.rowptr = torch.as_tensor(np.asarray(rowptr, np.int64)).to(dev)
+        self.col = torch.as_tensor(np.asarray(col, np.int32)).to(dev)
+        self.val = torch.as_tensor(np.asarray(val, np.float32)).to(dev)
+        assert self.rowptr.shape[0] == self.E.shape[0] + 1
+        self.X = [torch.empty_like(self.E) for _ in range(2)]   # layer ping-pong
+        self.OUT = torch.empty_like(self.E)                     # mean of the layer outputs
+        self.dOUT = torch.zeros_like(self.E)
+
+    def _propagate(self, out: torch.Tensor) -> None:
+        c = 1.0 / (self.L + 1)
+        x = self.E
+        for k in range(self.L):
+            last = k == self.L - 1
+            y = None if last else self.X[k & 1]
+            ops.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
+                         acc_out=out, s_out=c if last else 1.0)
+            x = y
+
+    def forward(self):
+        self._propagate(self.OUT)
+        return self.OUT[: self.user_num], self.OUT[self.user_num:]
+
+    def step(self, user_idx, pos_idx, neg_idx) -> None:
+        U, c = self.user_num, 1.0 / (self.L + 1)
+        self._propagate(self.OUT)
+        self.dOUT.zero_()
+        ops.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
+                        self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], self.loss)
+        # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
+        x = self.dOUT
+        for j in range(self.L):
+            dst = self.G if j == self.L - 1 else self.X[j & 1]
+            ops.spmm_csr(self.rowptr, self.col, self.val, x, y=None, acc_in=self.dOUT,
+                         s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0)
+            x = dst
+        self.step_count += 1
+        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False)

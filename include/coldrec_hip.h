@@ -95,6 +95,65 @@ int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items, int64_t r
 int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, int64_t n_users,
                    int k_in, int k_out, float* out_score, int32_t* out_idx, void* stream);
 
+/*
+ * One BPR training step's loss + gradients (everything but the optimiser).
+ * Replaces model/MF.py:21-26 / model/LightGCN.py:23-27:
+ *     u, p, n = user_tab[user_idx], pos_tab[pos_idx], neg_tab[neg_idx]        (list-index gather)
+ *     loss    = bpr_loss(u,p,n) + l2_reg_loss(reg,u,p,n)      util/utils.py:25-29,44-48
+ *     loss.backward()      (index backward = index_put_(accumulate=True) into dense gradients)
+ * tables (rows, d) fp32, d % 4 == 0, 16-byte aligned; *_idx (batch) int32 or NULL (= rows 0..batch-1,
+ * i.e. the tensors are already gathered: this is then bpr_loss/l2_reg_loss on (B,d) tensors).
+ * grad_* are dense tables the gradients are ACCUMULATED into (zero them first; pos and neg may be the
+ * same table); pass all three NULL for forward only.  loss_out[0] = bpr, loss_out[1] = l2 (device).
+ */
+size_t crh_bpr_workspace_bytes(int64_t batch);
+int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
+                        const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                        int64_t batch, float reg, float* grad_user, float* grad_pos, float* grad_neg,
+                        float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * torch.optim.Adam(lr) defaults, dense, for up to two tensors in one launch (model/MF.py:14,27:
+ * user table then item table, equal step counters).  Mirrors torch/optim/adam.py
+ * _single_tensor_adam op for op; scalar factors are evaluated in double.  step starts at 1.
+ * zero_grad != 0 also clears g (the next optimizer.zero_grad()).  n0, n1 multiples of 4; n1 may be 0.
+ */
+int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0,
+                       float* p1, float* g1, float* m1, float* v1, int64_t n1,
+                       double lr, double beta1, double beta2, double eps, int64_t step, int zero_grad,
+                       void* stream);
+
+/*
+ * CSR SpMM with the LightGCN layer sum fused (model/LightGCN.py:88-93 and its autograd):
+ *     P = A * x ;  y = P (if y) ;  acc_out = (acc_in * s_in + P) * s_out (if acc_out; acc_in NULL = 0)
+ * rowptr (n_rows+1) int64, col int32 ascending per row, val fp32 (util/databuilder.py:220-254,953-962
+ * produce exactly this matrix, as COO); x, y, acc_* are (n_rows, d) fp32, d % 4 == 0.
+ * acc_out may alias acc_in; outputs must not alias x.
+ */
+int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                     const float* x, int d, float* y, const float* acc_in, float s_in,
+                     float* acc_out, float s_out, void* stream);
+
+/*
+ * HOST-side negative sampler reproducing util/utils.py:123-157 (next_batch_pairwise) and NumPy's
+ * legacy MT19937 stream bit for bit (np.random.seed / shuffle / choice), on internal ids.
+ * All pointers are HOST pointers.  rec_* are the training records in file order; n_items_seen =
+ * len(data.item) (negatives are drawn from every id in the item table, cold ones included).
+ * crh_sampler_epoch fills one epoch (n_records triples, batches concatenated, last one short) and
+ * keeps the cumulative in-place shuffle of the reference across epochs.
+ * set/get_state exchange the 624-word key + position with np.random.get_state()/set_state().
+ */
+typedef struct crh_sampler crh_sampler;
+crh_sampler* crh_sampler_create(const int32_t* rec_user_host, const int32_t* rec_item_host,
+                                int64_t n_records, int32_t n_users, int32_t n_items_seen);
+void crh_sampler_destroy(crh_sampler* s);
+int crh_sampler_seed(crh_sampler* s, uint32_t seed);
+int crh_sampler_set_state(crh_sampler* s, const uint32_t* key624_host, int pos);
+int crh_sampler_get_state(const crh_sampler* s, uint32_t* key624_host, int* pos_host);
+int64_t crh_sampler_num_records(const crh_sampler* s);
+int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host,
+                      int32_t* pos_out_host, int32_t* neg_out_host);
+
 #ifdef __cplusplus
 }
 #endif

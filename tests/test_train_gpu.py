@@ -1,0 +1,228 @@
+"""GPU parity tests for the training path (BPR fwd/bwd, dense Adam, CSR SpMM, MF / LightGCN steps)
+through the C ABI, against the oracle and the reference's golden vectors.  Floating point:
+1e-5 relative on losses and embedding norms (north_star), looser elementwise where Adam's
+normalisation amplifies rounding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as orc
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(DEV)
+
+
+def _bpr_gpu(U, V, ui, pi, ni, reg):
+    from coldrec_amd import ops
+    tU, tV = t(U, torch.float32), t(V, torch.float32)
+    gU, gV = torch.zeros_like(tU), torch.zeros_like(tV)
+    loss = ops.bpr_fwd_bwd(tU, tV, tV, t(ui, torch.int32), t(pi, torch.int32), t(ni, torch.int32), reg, gU, gV, gV)
+    torch.cuda.synchronize()
+    return loss.cpu().numpy(), gU.cpu().numpy(), gV.cpu().numpy()
+
+
+@pytest.mark.parametrize("d,B,rows", [(4, 1, 3), (8, 5, 4), (16, 64, 40), (64, 1000, 300), (128, 4096, 5000),
+                                      (200, 513, 100), (256, 2048, 900)])
+def test_bpr_fwd_bwd_vs_oracle(d, B, rows):
+    rng = np.random.default_rng(d * 7 + B)
+    U = (rng.standard_normal((rows, d)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((rows + 11, d)) * 0.3).astype(np.float32)
+    ui, pi, ni = rng.integers(0, rows, B), rng.integers(0, rows + 11, B), rng.integers(0, rows + 11, B)
+    reg = 0.01
+    loss, gU, gV = _bpr_gpu(U, V, ui, pi, ni, reg)
+    bpr, l2, wU, wV, _ = orc.bpr_l2_fwd_bwd(U, V, ui, pi, ni, reg)
+    np.testing.assert_allclose(loss[0], bpr, rtol=1e-5)
+    np.testing.assert_allclose(loss[1], l2, rtol=1e-5)
+    sc = max(np.abs(wU).max(), np.abs(wV).max())
+    np.testing.assert_allclose(gU, wU, rtol=1e-4, atol=2e-6 * sc)
+    np.testing.assert_allclose(gV, wV, rtol=1e-4, atol=2e-6 * sc)
+
+
+@pytest.mark.parametrize("case", ["rand", "reg", "sat"])
+def test_bpr_golden_g2_gathered_tensors(case):
+    """bpr_loss / l2_reg_loss on already gathered (B,d) tensors: identity indices (NULL)."""
+    from coldrec_amd import ops
+    g = load_golden("g2_loss.npz")
+    u, p, n = (t(g[f"{case}_{k}"]) for k in "upn")
+    gu, gp, gn = torch.zeros_like(u), torch.zeros_like(p), torch.zeros_like(n)
+    loss = ops.bpr_fwd_bwd(u, p, n, None, None, None, float(g[f"{case}_reg"]), gu, gp, gn).cpu().numpy()
+    np.testing.assert_allclose(loss[0], g[f"{case}_bpr"], rtol=1e-5)
+    np.testing.assert_allclose(loss[1], g[f"{case}_l2"], rtol=1e-5)
+    sc = np.abs(g[f"{case}_gu"]).max()
+    for got, k in ((gu, "gu"), (gp, "gp"), (gn, "gn")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[f"{case}_{k}"], rtol=1e-4, atol=2e-6 * sc)
+
+
+def test_bpr_golden_g2_duplicate_rows():
+    g = load_golden("g2_loss.npz")
+    loss, gU, gV = _bpr_gpu(g["dup_U"], g["dup_V"], g["dup_ui"], g["dup_pi"], g["dup_ni"], float(g["dup_reg"]))
+    np.testing.assert_allclose(loss.sum(), g["dup_loss"], rtol=1e-5)
+    np.testing.assert_allclose(gU, g["dup_gU"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(gV, g["dup_gV"], rtol=1e-4, atol=1e-7)
+
+
+def test_forward_only_and_zero_norm():
+    from coldrec_amd import ops
+    u = torch.zeros((8, 16), device=DEV)
+    loss = ops.bpr_fwd_bwd(u, u, u, None, None, None, 0.1).cpu().numpy()
+    np.testing.assert_allclose(loss[0], -np.log(1e-5 + 0.5), rtol=1e-6)
+    assert loss[1] == 0.0
+    g = torch.zeros_like(u)
+    ops.bpr_fwd_bwd(u, u, u, None, None, None, 0.1, g, g, g)
+    assert torch.isfinite(g).all() and (g == 0).all()      # grad of |0|_F is 0, as autograd returns
+
+
+@pytest.mark.parametrize("n", [4, 1000, 6040 * 128 + 3706 * 128])
+def test_adam_dense_vs_oracle(n):
+    from coldrec_amd import ops
+    rng = np.random.default_rng(n)
+    p = rng.standard_normal(n).astype(np.float32) * 0.05
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    tp, tm, tv = t(p), t(m), t(v)
+    for step in range(1, 6):
+        g = (rng.standard_normal(n) * 1e-3).astype(np.float32)
+        g[rng.random(n) < 0.6] = 0.0                    # rows without gradient still move (dense Adam)
+        tg = t(g)
+        ops.adam_dense(tp, tg, tm, tv, step, lr=1e-3)
+        p, m, v = orc.adam_dense(p, g, m, v, step, lr=1e-3)
+        assert (tg == 0).all()                          # zero_grad fused
+    np.testing.assert_allclose(tp.cpu().numpy(), p, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(tm.cpu().numpy(), m, rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(tv.cpu().numpy(), v, rtol=1e-5, atol=1e-13)
+
+
+def test_adam_two_tensors_equals_two_calls():
+    from coldrec_amd import ops
+    rng = np.random.default_rng(1)
+    a = [t(rng.standard_normal(400).astype(np.float32)) for _ in range(4)]
+    b = [t(rng.standard_normal(1200).astype(np.float32)) for _ in range(4)]
+    for x in (a, b):
+        x[3].abs_()
+    a2, b2 = [x.clone() for x in a], [x.clone() for x in b]
+    ops.adam_dense(*a, 3, second=b, zero_grad=False)
+    ops.adam_dense(*a2, 3, zero_grad=False)
+    ops.adam_dense(*b2, 3, zero_grad=False)
+    for x, y in zip(a + b, a2 + b2):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("d", [16, 64])
+def test_mf_training_golden_g3(d):
+    """50 optimiser steps on the reference's own triples: per-step loss and table norms within 1e-5."""
+    from coldrec_amd.train import MFEngine
+    g = load_golden("g3_mf.npz")
+    eng = MFEngine(g[f"d{d}_U0"], g[f"d{d}_V0"], float(g["lr"]), float(g["reg"]), DEV)
+    off = np.concatenate([[0], np.cumsum(g["sizes"])])
+    tu, ti, tj = t(g["u"], torch.int32), t(g["i"], torch.int32), t(g["j"], torch.int32)
+    for s in range(50):
+        sl = slice(int(off[s]), int(off[s + 1]))
+        eng.step(tu[sl], ti[sl], tj[sl])
+        np.testing.assert_allclose(eng.last_loss(), g[f"d{d}_loss"][s], rtol=1e-5)
+        if s + 1 in (1, 10, 50):
+            for got, want in ((eng.user_emb, g[f"d{d}_U_step{s+1}"]), (eng.item_emb, g[f"d{d}_V_step{s+1}"])):
+                got = got.cpu().numpy()
+                np.testing.assert_allclose(np.linalg.norm(got), np.linalg.norm(want), rtol=1e-5)
+                assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
+
+
+def _graph():
+    g4 = load_golden("g4_graph.npz")
+    return g4["indptr"], g4["indices"].astype(np.int32), g4["data"]
+
+
+@pytest.mark.parametrize("d", [4, 32, 128, 200])
+def test_spmm_bit_exact_vs_oracle(d):
+    from coldrec_amd import ops
+    rowptr, col, val = _graph()
+    n = len(rowptr) - 1
+    rng = np.random.default_rng(d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Z = rng.standard_normal((n, d)).astype(np.float32)
+    tX, tZ = t(X), t(Z)
+    Y, A = torch.empty_like(tX), torch.empty_like(tX)
+    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y, acc_in=tZ, s_in=0.5, acc_out=A, s_out=0.25)
+    want = orc.spmm(rowptr, col, val, X)
+    np.testing.assert_array_equal(Y.cpu().numpy(), want)            # same fmaf order as the oracle
+    np.testing.assert_allclose(A.cpu().numpy(), (Z * np.float32(0.5) + want) * np.float32(0.25), rtol=1e-6, atol=1e-7)
+
+
+def test_lgcn_forward_golden_g5_and_training():
+    from coldrec_amd.train import LGCNEngine
+    g5 = load_golden("g5_lgcn.npz")
+    rowptr, col, val = _graph()
+    for L in (1, 2, 3):
+        eng = LGCNEngine(g5["U0"], g5["V0"], rowptr, col, val, L, 1e-3, 1e-4, DEV)
+        uo, io = eng.forward()
+        np.testing.assert_allclose(uo.cpu().numpy(), g5[f"L{L}_user_out"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(io.cpu().numpy(), g5[f"L{L}_item_out"], rtol=1e-5, atol=1e-7)
+    eng = LGCNEngine(g5["U0"], g5["V0"], rowptr, col, val, 3, float(g5["lr"]), float(g5["reg"]), DEV)
+    off = np.concatenate([[0], np.cumsum(g5["train_sizes"])])
+    tu, ti, tj = (t(g5[k], torch.int32) for k in ("train_u", "train_i", "train_j"))
+    for s in range(20):
+        sl = slice(int(off[s]), int(off[s + 1]))
+        eng.step(tu[sl], ti[sl], tj[sl])
+        if s == 0:
+            sc = np.abs(g5["train_gU_step1"]).max()
+            np.testing.assert_allclose(eng.G[: eng.user_num].cpu().numpy(), g5["train_gU_step1"], rtol=1e-4, atol=2e-6 * sc)
+            np.testing.assert_allclose(eng.G[eng.user_num:].cpu().numpy(), g5["train_gV_step1"], rtol=1e-4, atol=2e-6 * sc)
+        np.testing.assert_allclose(eng.last_loss(), g5["train_loss"][s], rtol=1e-5)
+    for got, want in ((eng.user_emb, g5["train_U_end"]), (eng.item_emb, g5["train_V_end"])):
+        np.testing.assert_allclose(np.linalg.norm(got.cpu().numpy()), np.linalg.norm(want), rtol=1e-5)
+
+
+def test_full_size_mf_and_lgcn_steps_vs_oracle():
+    """BASELINE configs 2 and 3 at their real sizes (S-ML 6040x3706 d=128 B=4096; S-CUL 5551x16980,
+    L=3, d=128): one full step against the numpy/C oracle, plus linearity of the propagation."""
+    from coldrec_amd.train import MFEngine, LGCNEngine
+    rng = np.random.default_rng(0)
+    U, I, d, B = 6040, 3706, 128, 4096
+    U0 = (rng.uniform(-1, 1, (U, d)) * (6 / (U + d)) ** 0.5).astype(np.float32)
+    V0 = (rng.uniform(-1, 1, (I, d)) * (6 / (I + d)) ** 0.5).astype(np.float32)
+    ui, pi, ni = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    eng = MFEngine(U0, V0, 1e-3, 1e-4, DEV)
+    eng.step(t(ui, torch.int32), t(pi, torch.int32), t(ni, torch.int32))
+    bpr, l2, gU, gV, _ = orc.bpr_l2_fwd_bwd(U0, V0, ui, pi, ni, 1e-4)
+    np.testing.assert_allclose(eng.last_loss(), bpr + l2, rtol=1e-5)
+    z = np.zeros_like
+    wU, _, _ = orc.adam_dense(U0, gU, z(U0), z(U0), 1)
+    wV, _, _ = orc.adam_dense(V0, gV, z(V0), z(V0), 1)
+    np.testing.assert_allclose(np.linalg.norm(eng.user_emb.cpu().numpy()), np.linalg.norm(wU), rtol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(eng.item_emb.cpu().numpy()), np.linalg.norm(wV), rtol=1e-5)
+    assert (eng.G == 0).all()
+    # S-CUL graph
+    U, I, nnz = 5551, 16980, 130_000
+    key = np.unique(rng.integers(0, U * I, nnz))
+    ru, ri = key // I, key % I
+    rowptr, col, val = orc.norm_adj_csr(ru, ri, U, I)
+    U0 = (rng.uniform(-1, 1, (U, d)) * 0.03).astype(np.float32)
+    V0 = (rng.uniform(-1, 1, (I, d)) * 0.03).astype(np.float32)
+    eng = LGCNEngine(U0, V0, rowptr, col, val, 3, 1e-3, 1e-4, DEV)
+    uo, io = eng.forward()
+    wu, wi = orc.lgcn_forward(rowptr, col, val, U0, V0, 3)
+    np.testing.assert_allclose(uo.cpu().numpy(), wu, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(io.cpu().numpy(), wi, rtol=1e-5, atol=1e-8)
+    ui, pi, ni = ru[:B], ri[:B], rng.integers(0, I, B)
+    eng.step(t(ui, torch.int32), t(pi, torch.int32), t(ni, torch.int32))
+    bpr, l2, gOu, gOi, _ = orc.bpr_l2_fwd_bwd(wu, wi, ui, pi, ni, 1e-4)
+    np.testing.assert_allclose(eng.last_loss(), bpr + l2, rtol=1e-5)
+    gU, gV = orc.lgcn_backward(rowptr, col, val, gOu.astype(np.float32), gOi.astype(np.float32), 3)
+    sc = max(np.abs(gU).max(), np.abs(gV).max())
+    np.testing.assert_allclose(eng.G[:U].cpu().numpy(), gU, rtol=1e-4, atol=2e-6 * sc)
+    np.testing.assert_allclose(eng.G[U:].cpu().numpy(), gV, rtol=1e-4, atol=2e-6 * sc)
+    # linearity (size-independent property): A(2x + y) == 2 A x + A y up to rounding
+    from coldrec_amd import ops
+    x, y = torch.randn_like(eng.E), torch.randn_like(eng.E)
+    ax, ay, axy = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    ops.spmm_csr(eng.rowptr, eng.col, eng.val, x, y=ax)
+    ops.spmm_csr(eng.rowptr, eng.col, eng.val, y, y=ay)
+    ops.spmm_csr(eng.rowptr, eng.col, eng.val, 2 * x + y, y=axy)
+    torch.testing.assert_close(axy, 2 * ax + ay, rtol=1e-4, atol=1e-5)
