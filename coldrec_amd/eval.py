@@ -46,8 +46,10 @@ class ShardedTopK:
             return s, i
         import torch.distributed as dist
         packed = torch.cat([s.view(torch.int32), i], dim=1).contiguous()          # (Bu, 2k) int32
-        gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int32, device=packed.device)
-        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        flat = torch.empty((self.world * packed.shape[0], packed.shape[1]), dtype=torch.int32,
+                           device=packed.device)                                   # rank-major concatenation
+        dist.all_gather_into_tensor(flat, packed, group=self.group)
+        gathered = flat.view(self.world, packed.shape[0], packed.shape[1])
         gs = gathered[:, :, :self.k].contiguous().view(torch.float32)
         gi = gathered[:, :, self.k:].contiguous()
         return self._merge(gs, gi, self.k)

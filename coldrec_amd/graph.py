@@ -1,0 +1,76 @@
+"""Sparse adjacency handle that lets unmodified model files hit the HIP SpMM.
+
+Model plugins do ``adj = TorchGraphInterface.convert_sparse_mat_to_tensor(norm_adj).to(device)`` once
+and ``torch.sparse.mm(adj, dense)`` per layer (model/LightGCN.py:76,90; also NGCF, SimGCL, CGRC,
+FSGNN).  ``HipSparseAdj`` is a ``torch.Tensor`` subclass around the same coalesced COO tensor the
+reference builds (util/databuilder.py:953-962); through ``__torch_function__`` it answers
+``torch.sparse.mm`` with crh_spmm_csr_f32 when the dense operand lives on the GPU (autograd
+included: d/dX (A X) = A^T G, CSR of A^T kept alongside), and forwards everything else to the
+COO tensor untouched.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import ops
+
+
+class _SpmmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, adj: "HipSparseAdj", dense: torch.Tensor):
+        ctx.adj = adj
+        x = dense.contiguous().float()
+        y = torch.empty((adj.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        rp, col, val = adj.csr(x.device)
+        ops.spmm_csr(rp, col, val, x, y=y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = grad_out.contiguous().float()
+        rp, col, val = ctx.adj.csr(g.device, transposed=True)
+        gx = torch.empty((ctx.adj.shape[1], g.shape[1]), dtype=torch.float32, device=g.device)
+        ops.spmm_csr(rp, col, val, g, y=gx)
+        return None, gx
+
+
+class HipSparseAdj(torch.Tensor):
+    @staticmethod
+    def from_scipy(X) -> "HipSparseAdj":
+        coo = sp.coo_matrix(X)
+        idx = torch.from_numpy(np.vstack((coo.row, coo.col)).astype(np.int64))
+        coo_t = torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data.astype(np.float32)), coo.shape).coalesce()
+        return HipSparseAdj._wrap(coo_t, sp.csr_matrix(X, dtype=np.float32))
+
+    @staticmethod
+    def _wrap(coo_t: torch.Tensor, csr_host) -> "HipSparseAdj":
+        out = torch.Tensor._make_subclass(HipSparseAdj, coo_t)
+        out._coo = coo_t
+        out._csr_host = csr_host
+        out._dev = {}
+        return out
+
+    def csr(self, device, transposed: bool = False):
+        key = (str(device), transposed)
+        if key not in self._dev:
+            m = self._csr_host.T.tocsr() if transposed else self._csr_host
+            m.sort_indices()
+            self._dev[key] = (torch.from_numpy(m.indptr.astype(np.int64)).to(device),
+                              torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                              torch.from_numpy(m.data.astype(np.float32)).to(device))
+        return self._dev[key]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.sparse.mm and len(args) == 2 and isinstance(args[0], HipSparseAdj) \
+                and isinstance(args[1], torch.Tensor) and args[1].is_cuda and args[1].shape[1] % 4 == 0:
+            return _SpmmFn.apply(args[0], args[1])
+        if func in (torch.Tensor.to, torch.Tensor.cuda, torch.Tensor.cpu) and isinstance(args[0], HipSparseAdj):
+            moved = func(args[0]._coo, *args[1:], **kwargs)
+            return HipSparseAdj._wrap(moved, args[0]._csr_host)
+        plain = [a._coo if isinstance(a, HipSparseAdj) else a for a in args]
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*plain, **kwargs)

@@ -1,0 +1,253 @@
+"""Trainer base class with the reference's plugin contract (model/BaseRecommender.py:13-370) and a
+fused GPU evaluation path.
+
+Subclasses implement ``train / predict / batch_predict / save`` and publish ``self.user_emb`` /
+``self.item_emb``; they inherit ``fast_evaluation`` (per-epoch validation, strict-NDCG early stop),
+``valid / test / full_evaluation / run`` and the attribute names listed in SURVEY.md Appendix B.
+
+Evaluation (``_evaluate``, reference lines 153-188) never materialises the (users x items) score
+block when the plugin's ``batch_predict`` is the stock ``user_emb[users] @ item_emb.T``: users,
+rated-item CSR and the warm/cold candidate bitmap are cached on the GPU per (set, type) and one
+call of crh_score_topk_f32 returns the masked top-k.  Any other ``batch_predict`` (VBPR, ALDI, ...)
+is honoured: its dense block goes through crh_mask_topk_f32.  Either way the order is the canonical
+(score desc, index asc) one, and the metrics are computed on arrays (util/evaluator.py).
+"""
+from __future__ import annotations
+
+import inspect
+import math
+import re
+import time
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..util.evaluator import format_measure, ranking_metrics, truth_csr
+
+_STOCK_PREDICT = re.compile(
+    r"score=torch\.matmul\(self\.user_emb\[users\],self\.item_emb\.transpose\(0,1\)\)returnscore$")
+
+
+def _is_stock_batch_predict(fn) -> bool:
+    """True when ``batch_predict`` is the 22-fold copy of model/MF.py:58-63."""
+    try:
+        src = re.sub(r"\s+", "", inspect.getsource(fn))
+    except (OSError, TypeError):
+        return False
+    return bool(_STOCK_PREDICT.search(src)) and src.count("matmul") == 1
+
+
+class BaseColdStartTrainer(ABC):
+    fused_eval = None     # subclasses may force True / False; None = detect from batch_predict's source
+
+    def __init__(self, config):
+        self.config = config
+        self.args = config.args
+        self.data = config.data
+        self.device = config.device
+        a = self.args
+        self.bestPerformance = []
+        self.topN = [int(x) for x in a.topN.split(',')]
+        self.max_N = max(self.topN)
+        self.model_name, self.dataset_name = a.model, a.dataset
+        self.emb_size, self.maxEpoch, self.batch_size = a.emb_size, a.epochs, a.bs
+        self.lr, self.reg = a.lr, a.reg
+        self.result = []
+        self.early_stop_flag = a.early_stop != 0
+        if self.early_stop_flag:
+            self.early_stop_patience = self.max_early_stop_patience = a.early_stop
+        self.epochs_ran = 0
+        self.eval_every = max(1, int(getattr(a, 'eval_every', 1)))
+        self._eval_cache: Dict[Any, Dict[str, Any]] = {}
+
+    # ------------------------------------------------------------------ plugin contract
+    @abstractmethod
+    def train(self) -> None: ...
+
+    @abstractmethod
+    def predict(self, u): ...
+
+    @abstractmethod
+    def batch_predict(self, users): ...
+
+    @abstractmethod
+    def save(self) -> None: ...
+
+    def print_basic_info(self):
+        print('*' * 80)
+        for label, v in (('Model: ', self.model_name), ('Dataset: ', self.dataset_name),
+                         ('Embedding Dimension:', self.emb_size), ('Maximum Epoch:', self.maxEpoch),
+                         ('Learning Rate:', self.lr), ('Batch Size:', self.batch_size)):
+            print(label, v)
+        print('*' * 80)
+
+    def timer(self, start=True):
+        if start:
+            self.train_start_time = time.time()
+        else:
+            self.train_end_time = time.time()
+
+    # ------------------------------------------------------------------ evaluation
+    def _sets(self, kind: str, which: str) -> Dict:
+        table = {'warm': f'warm_{kind}_set', 'cold': f'cold_{kind}_set', 'all': f'overall_{kind}_set'}
+        if which not in table:
+            raise ValueError(f'Invalid {"valid" if kind == "valid" else kind} type!')
+        return getattr(self.data, table[which])
+
+    def _get_eval_cache(self, data_set: Dict, data_type: str) -> Dict[str, Any]:
+        key = (id(data_set), data_type, str(self.device), self.args.cold_object)
+        hit = self._eval_cache.get(key)
+        if hit is not None:
+            return hit
+        d = self.data
+        users, gt_rowptr, gt_items = truth_csr(data_set, item_of=d.item)
+        uint = d.get_user_id_list(users)
+        lens = d.rated_rowptr[uint + 1] - d.rated_rowptr[uint]
+        rowptr = np.zeros(len(users) + 1, np.int64)
+        np.cumsum(lens, out=rowptr[1:])
+        take = np.repeat(d.rated_rowptr[uint] - rowptr[:-1], lens) + np.arange(int(rowptr[-1]))
+        col = d.rated_col[take]
+        masked = None
+        if self.args.cold_object == 'item':           # reference lines 130-143
+            if data_type == 'warm':
+                masked = np.asarray(d.mapped_cold_item_idx)
+            elif data_type == 'cold':
+                masked = np.asarray(d.mapped_warm_item_idx)
+        dev = self.device
+        hit = {
+            'users': users, 'users_int': torch.from_numpy(uint.astype(np.int32)).to(dev),
+            'rated_rowptr': torch.from_numpy(rowptr).to(dev) if rowptr[-1] else None,
+            'rated_col': torch.from_numpy(np.ascontiguousarray(col)).to(dev) if rowptr[-1] else None,
+            'bitmap': ops.make_bitmap(d.item_num, masked, dev),
+            'gt_rowptr': gt_rowptr, 'gt_items': gt_items,
+        }
+        self._eval_cache[key] = hit
+        return hit
+
+    def _topk_arrays(self, data_set: Dict, data_type: str):
+        """(users, scores (n,k) float32, internal item ids (n,k)) on the host, canonical order."""
+        c = self._get_eval_cache(data_set, data_type)
+        fused = self.fused_eval
+        if fused is None:
+            fused = _is_stock_batch_predict(type(self).batch_predict)
+        ue, ie = getattr(self, 'user_emb', None), getattr(self, 'item_emb', None)
+        fused = fused and torch.is_tensor(ue) and torch.is_tensor(ie) and ue.is_cuda and ue.dim() == 2
+        if fused:
+            s, i = ops.score_topk(ue.detach().float(), c['users_int'], ie.detach().float(), self.max_N,
+                                  c['rated_rowptr'], c['rated_col'], c['bitmap'])
+        else:
+            parts_s, parts_i = [], []
+            for lo in range(0, len(c['users']), self.batch_size):
+                hi = min(lo + self.batch_size, len(c['users']))
+                block = self.batch_predict(c['users'][lo:hi])
+                block = torch.as_tensor(block, device=self.device).float().contiguous()
+                rp = rc = None
+                if c['rated_rowptr'] is not None:
+                    rp = (c['rated_rowptr'][lo:hi + 1] - c['rated_rowptr'][lo]).contiguous()
+                    rc = c['rated_col'][int(c['rated_rowptr'][lo]):int(c['rated_rowptr'][hi])].contiguous()
+                s, i = ops.mask_topk(block, self.max_N, rp, rc, c['bitmap'], write_back=True)
+                parts_s.append(s)
+                parts_i.append(i)
+            s, i = torch.cat(parts_s), torch.cat(parts_i)
+        return c, s.cpu().numpy(), i.cpu().numpy()
+
+    def _evaluate(self, data_set: Dict, data_type: str = 'all') -> Dict[Any, List[Tuple[Any, float]]]:
+        c, s, i = self._topk_arrays(data_set, data_type)
+        names = self.data.item_keys[np.minimum(i, len(self.data.item_keys) - 1)]
+        return {u: list(zip(names[r].tolist(), s[r])) for r, u in enumerate(c['users'])}
+
+    def valid(self, valid_type: str = 'all'):
+        return self._evaluate(self._sets('valid', valid_type), valid_type)
+
+    def test(self, test_type: str = 'all'):
+        return self._evaluate(self._sets('test', test_type), test_type)
+
+    def _metrics(self, data_set: Dict, data_type: str, topn):
+        c, _s, i = self._topk_arrays(data_set, data_type)
+        return ranking_metrics(c['gt_rowptr'], c['gt_items'], i, topn)
+
+    def full_evaluation(self, rec_list=None, test_type: str = 'warm') -> None:
+        """Prints and stores the test metrics.  ``rec_list`` (the dict ``test()`` returns) is accepted
+        for API compatibility; the numbers are computed from the same top-k on arrays."""
+        test_set = self._sets('test', test_type)
+        if rec_list is not None and len(rec_list) != len(test_set):
+            print(f"ground-truth set size: {len(test_set)}, predicted set size: {len(rec_list)}")
+            print('The Lengths of ground-truth set and predicted set do not match!')
+            exit(-1)
+        perf = self._metrics(test_set, test_type, self.topN)
+        self.result = format_measure(perf, self.topN)
+        setattr(self, {'warm': 'warm_test_results', 'cold': 'cold_test_results',
+                       'all': 'overall_test_results'}[test_type], perf)
+        print('*' * 80)
+        print(f'[{test_type} setting] The result of %s:\n%s' % (self.model_name, ''.join(self.result)))
+
+    @staticmethod
+    def _metrics_dict_from_measure(measure: List[str]) -> Dict[str, float]:
+        return {k: float(v) for k, v in (m.strip().split(':') for m in measure[1:])}
+
+    @staticmethod
+    def _metrics_all_finite(performance: Dict[str, float]) -> bool:
+        return all(math.isfinite(v) for v in performance.values())
+
+    def fast_evaluation(self, epoch: int, valid_type: str = 'all') -> List[str]:
+        """Validation at max(topN); strict NDCG improvement saves and resets patience, anything else
+        (equal, worse, non-finite) costs one unit of patience (reference lines 268-351)."""
+        valid_set = self._sets('valid', valid_type)
+        print(f'Evaluating the model under the {valid_type} setting...')
+        measure = format_measure(self._metrics(valid_set, valid_type, [self.max_N]), [self.max_N])
+        performance = self._metrics_dict_from_measure(measure)
+        finite = self._metrics_all_finite(performance)
+        improved = False
+        if not self.bestPerformance:
+            if finite:
+                self.bestPerformance = [epoch + 1, performance]
+                self.save()
+                improved = None                       # first checkpoint: patience untouched
+            else:
+                print('Warning: first validation has non-finite metrics; best checkpoint not initialized yet.')
+        elif not finite:
+            print('Warning: validation metrics are non-finite; early-stop patience decreased, '
+                  'best checkpoint unchanged.')
+        elif performance['NDCG'] > self.bestPerformance[1]['NDCG']:
+            self.bestPerformance = [epoch + 1, performance]
+            self.save()
+            improved = True
+        if self.early_stop_flag and improved is not None:
+            if improved:
+                self.early_stop_patience = self.max_early_stop_patience
+            else:
+                self.early_stop_patience -= 1
+
+        print('-' * 120)
+        print('Performance ' + ' (Top-' + str(self.max_N) + ' Recommendation)')
+        measure_lines = [m.strip() for m in measure[1:]]
+        print('*Current Performance*')
+        print('Epoch:', str(epoch + 1) + ',', '  |  '.join(measure_lines))
+        if self.bestPerformance:
+            bp = '  |  '.join(f'{k}:{self.bestPerformance[1][k]}' for k in ('Hit Ratio', 'Precision', 'Recall', 'NDCG'))
+            print(f'*Best {valid_type} Performance* ')
+            print('Epoch:', str(self.bestPerformance[0]) + ',', bp)
+        else:
+            print(f'*Best {valid_type} Performance* not initialized (waiting for finite validation).')
+        if self.early_stop_flag:
+            if self.early_stop_patience <= 0:
+                print(f"Stopping early at epoch {epoch + 1}.")
+            else:
+                print(f"Early stopping patience left: {self.early_stop_patience}.")
+        print('-' * 120)
+        return measure_lines
+
+    def run(self) -> None:
+        self.print_basic_info()
+        print('Training Model...')
+        self.train()
+        if getattr(self, 'epochs_ran', 0) == 0 and self.maxEpoch > 0:
+            self.epochs_ran = self.maxEpoch
+        for test_type in ['all', 'cold', 'warm']:
+            print('*' * 80)
+            print(f'Testing under [{test_type}] setting...')
+            print(f'Evaluating under [{test_type}] setting...')
+            self.full_evaluation(None, test_type=test_type)

@@ -1,0 +1,86 @@
+"""BPR-MF warm-embedding trainer on the MI355X (reference: model/MF.py).
+
+Same loop, same random streams (torch CPU generator for the xavier tables, NumPy global MT19937
+for the triples), same early-stopping and checkpoint semantics -- including the reference's
+non-cloning ``save()`` (model/MF.py:48-50: the "best" tables alias the live parameters, SURVEY.md
+F5) -- with every optimiser step executed by three HIP kernels on device-resident tables
+(coldrec_amd/train.py).  An epoch's triples are sampled on the host in one call and uploaded once.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from ..train import MFEngine
+from ..util.utils import epoch_triples
+from .BaseRecommender import BaseColdStartTrainer
+
+
+def _require_gpu(device):
+    if torch.device(device).type != 'cuda':
+        raise RuntimeError('coldrec_amd trainers run on the MI355X only (--use_gpu true); there is no CPU path')
+
+
+class Matrix_Factorization(object):
+    """Two xavier-uniform tables drawn exactly like model/MF.py:72-79 (user table first)."""
+
+    def __init__(self, data, emb_size):
+        self.data, self.latent_size = data, emb_size
+        init = nn.init.xavier_uniform_
+        self.user0 = init(torch.empty(data.user_num, emb_size))
+        self.item0 = init(torch.empty(data.item_num, emb_size))
+
+
+class MF(BaseColdStartTrainer):
+    fused_eval = True
+
+    def __init__(self, config):
+        super(MF, self).__init__(config)
+        self.model = Matrix_Factorization(self.data, self.emb_size)
+        self.engine = None
+
+    def _make_engine(self):
+        return MFEngine(self.model.user0, self.model.item0, self.lr, self.reg, self.device)
+
+    def train(self):
+        _require_gpu(self.device)
+        eng = self.engine = self._make_engine()
+        self.timer(start=True)
+        epoch = -1
+        for epoch in range(self.maxEpoch):
+            u, i, j = (torch.from_numpy(x).to(self.device) for x in epoch_triples(self.data, self.batch_size))
+            for n, lo in enumerate(range(0, u.shape[0], self.batch_size)):
+                hi = min(lo + self.batch_size, u.shape[0])
+                eng.step(u[lo:hi], i[lo:hi], j[lo:hi])
+                if n % 50 == 0:
+                    print('training:', epoch + 1, 'batch', n, 'batch_loss:', eng.last_loss())
+            self.user_emb, self.item_emb = eng.forward()
+            if epoch % self.eval_every == 0:
+                self.fast_evaluation(epoch, valid_type='all')
+                if self.early_stop_flag and self.early_stop_patience <= 0:
+                    break
+        self.epochs_ran = (epoch + 1) if self.maxEpoch > 0 else 0
+        self.timer(start=False)
+        self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb
+        if self.args.save_emb:
+            self._save_tables()
+
+    def _save_tables(self, as_parameter=True):
+        a = self.args
+        os.makedirs('./emb', exist_ok=True)
+        wrap = (lambda t: nn.Parameter(t.detach().clone())) if as_parameter else (lambda t: t.detach().clone())
+        stem = f"./emb/{a.dataset}_cold_{a.cold_object}_{a.model}"
+        torch.save(wrap(self.user_emb), stem + "_user_emb.pt")
+        torch.save(wrap(self.item_emb), stem + "_item_emb.pt")
+
+    def save(self):
+        # model/MF.py:48-50 stores the live parameters, not a copy
+        self.best_user_emb, self.best_item_emb = self.engine.forward()
+
+    def predict(self, u):
+        u = self.data.get_user_id(u)
+        return (self.item_emb @ self.user_emb[u]).cpu().numpy()
+
+    def batch_predict(self, users):
+        users = torch.as_tensor(self.data.get_user_id_list(users), device=self.device)
+        return self.user_emb[users] @ self.item_emb.T
