@@ -103,6 +103,111 @@ def cpu_baseline(U_cpu, V_cpu, rowptr, col, cold_ids, k, reps):
     return U_cpu.shape[0] * V_cpu.shape[0] / dt
 
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _time_steps(fn, n_steps, warm):
+    for s in range(warm):
+        fn(s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for s in range(n_steps):
+        fn(warm + s)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n_steps
+
+
+def train_legs(dev, with_cpu):
+    """Secondary metric of BASELINE.json: BPR triples/s (train), configs[1] (BPR-MF, MovieLens shape,
+    d=128) and configs[2] (LightGCN L=3, CiteULike shape, d=128), one epoch each, triples pre-sampled
+    by the host sampler and resident in HBM; Adam dense as in the reference."""
+    from coldrec_amd.data.synth import make_dataset
+    from coldrec_amd.sampler import PairwiseSampler
+    from coldrec_amd.train import LGCNEngine, MFEngine
+    from oracle import oracle_np as orc
+    out = {}
+    B, d = 4096, 128
+    for name, shape, layers in (("train_mf", "movielens", 0), ("train_lightgcn", "citeulike", 3)):
+        split = make_dataset(shape, "item", seed=1 if layers == 0 else 2, with_content=False)
+        tr = split.warm_train
+        ukeys, ru = np.unique(tr[:, 0], return_inverse=True)
+        ikeys, ri = np.unique(tr[:, 1], return_inverse=True)
+        n_u, n_i, n = split.user_num, split.item_num, tr.shape[0]
+        t0 = time.perf_counter()
+        smp = PairwiseSampler(ru, ri, n_u, n_i)
+        smp.seed(2024)
+        u, i, j = smp.epoch(B)
+        t_sample = time.perf_counter() - t0
+        g = torch.Generator().manual_seed(2024)
+        U0 = torch.nn.init.xavier_uniform_(torch.empty(n_u, d), generator=g)
+        V0 = torch.nn.init.xavier_uniform_(torch.empty(n_i, d), generator=g)
+        if layers:
+            rowptr, col, val = orc.norm_adj_csr(ru, ri, n_u, n_i)     # input preparation only
+            eng = LGCNEngine(U0, V0, rowptr, col, val, layers, 1e-3, 1e-4, dev)
+        else:
+            eng = MFEngine(U0, V0, 1e-3, 1e-4, dev)
+        tu, ti, tj = (torch.from_numpy(x).to(dev) for x in (u, i, j))
+        steps = [(lo, min(lo + B, n)) for lo in range(0, n, B)]
+
+        def one(s):
+            lo, hi = steps[s % len(steps)]
+            eng.step(tu[lo:hi], ti[lo:hi], tj[lo:hi])
+
+        sec = _time_steps(one, len(steps), 3)
+        N, nnz = n_u + n_i, (len(val) if layers else 0)
+        bytes_step = 24 * d * B + 32 * N * d                          # SURVEY.md 8(d): MF step
+        if layers:                                                     # + 2L SpMM + layer mean fwd/bwd + dOUT zero
+            bytes_step += 2 * layers * (nnz * 8 + (N + 1) * 8 + 2 * N * d * 4) + 2 * (layers + 2) * N * d * 4
+        leg = {"metric": "BPR triples/sec (train)", "value": B / sec * (n / (len(steps) * B)), "unit": "triples/s",
+               "ms_per_step": sec * 1e3, "steps_per_epoch": len(steps),
+               "config": {"workload": "configs[%d] %s, %s-shaped synthetic (%d users x %d items, %d train triples), "
+                                      "d=%d, B=%d, dense Adam" % (2 if layers else 1, "LightGCN L=3" if layers else "BPR-MF",
+                                                                  shape, n_u, n_i, n, d, B)},
+               "host_sampler_s_per_epoch": t_sample,
+               "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
+                            "traffic": None, "note": "whole step (all kernels of one optimiser step)"}}
+        if with_cpu:
+            from oracle import ref_port
+
+            def make_port():
+                if layers:
+                    return ref_port.LGCNPort(U0.numpy(), V0.numpy(), ref_port.coo_adj(rowptr, col, val), layers, 1e-3, 1e-4)
+                return ref_port.MFPort(U0.numpy(), V0.numpy(), 1e-3, 1e-4)
+
+            def cpu_steps(port, count):
+                t0 = time.perf_counter()
+                for s in range(count):
+                    lo, hi = steps[s % len(steps)]
+                    port.step(u[lo:hi], i[lo:hi], j[lo:hi])
+                return (time.perf_counter() - t0) / count
+
+            # tiny ATen ops do not scale to every core: take the best of a few thread counts, bounded time
+            best = None
+            for th in sorted({os.cpu_count(), min(32, os.cpu_count()), min(8, os.cpu_count())}):
+                torch.set_num_threads(th)
+                port = make_port()
+                cpu_steps(port, 1)
+                dt = cpu_steps(port, 2)
+                if best is None or dt < best[0]:
+                    best = (dt, th)
+            torch.set_num_threads(best[1])
+            port = make_port()
+            cpu_steps(port, 1)
+            n_cpu = int(max(2, min(60, 8.0 / best[0])))
+            dt = cpu_steps(port, n_cpu)
+            torch.set_num_threads(os.cpu_count())
+            leg["cpu_baseline"] = {"value": B / dt, "unit": "triples/s", "cores": best[1], "kind": "port",
+                                   "sample": "%d optimiser steps of the same epoch (torch autograd + Adam%s) on %d threads "
+                                             "(best of 8/32/all), sampler excluded"
+                                             % (n_cpu, ", torch.sparse.mm COO" if layers else "", best[1])}
+        out[name] = leg
+        del eng
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +220,7 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--n-splits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary train legs (N=1 only)")
     ap.add_argument("--cpu-sample-users", type=int, default=256)
     ap.add_argument("--cpu-sample-items", type=int, default=2_500_000)
     args = ap.parse_args()
@@ -206,9 +312,12 @@ def main():
             "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
                       "%d threads, 2 reps" % (nu, ni, torch.__version__, os.cpu_count())}
+    if rank == 0 and world == 1 and not args.no_train:
+        del V, U, engine
+        torch.cuda.empty_cache()
+        result.update(train_legs(dev, not args.no_cpu_baseline))
     if rank == 0:
         print(json.dumps(result), flush=True)
-    del out
     if world > 1:
         dist.destroy_process_group()
 

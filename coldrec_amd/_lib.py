@@ -40,7 +40,8 @@ SIGNATURES = {
                                    _sz, _vp]),
     "crh_adam_dense_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
                                   _i64, _i32, _vp]),
-    "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp]),
+    "crh_spmm_heavy_degree": (_i32, []),
+    "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _i32, _vp]),
     "crh_sampler_create": (_vp, [_vp, _vp, _i64, _i32, _i32]),
     "crh_sampler_destroy": (None, [_vp]),
     "crh_sampler_seed": (_i32, [_vp, ctypes.c_uint32]),

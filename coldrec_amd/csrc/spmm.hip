@@ -16,6 +16,8 @@
 
 namespace {
 
+constexpr int SPMM_HEAVY_DEG = 512;   // rows with more edges than this get a whole block
+
 struct SpmmArgs {
     const int64_t* rowptr;
     const int32_t* col;
@@ -27,7 +29,66 @@ struct SpmmArgs {
     const float* acc_in;
     float* acc_out;
     float s_in, s_out;
+    const int32_t* heavy_rows;   // rows handled by spmm_heavy_kernel (skipped by the row kernel)
+    int n_heavy;
 };
+
+__device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
+    acc.x = fmaf(v, x.x, acc.x);
+    acc.y = fmaf(v, x.y, acc.y);
+    acc.z = fmaf(v, x.z, acc.z);
+    acc.w = fmaf(v, x.w, acc.w);
+}
+
+__device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc) {
+    if (a.Y) *reinterpret_cast<f32x4*>(a.Y + o) = acc;
+    if (a.acc_out) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
+        f32x4 r;
+        r.x = (z.x * a.s_in + acc.x) * a.s_out;
+        r.y = (z.y * a.s_in + acc.y) * a.s_out;
+        r.z = (z.z * a.s_in + acc.z) * a.s_out;
+        r.w = (z.w * a.s_in + acc.w) * a.s_out;
+        *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
+    }
+}
+
+// Accumulate edges [e0, e1) of one row into acc for this lane's 16-B column slice, in edge order.
+// The edge list is read G entries at a time (one per lane) and broadcast by shuffles; neighbour rows
+// are fetched 4 at a time before the dependent fma chain so several loads are in flight per group.
+template <int G>
+__device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t e1, int c, bool on, int lig,
+                                          f32x4& acc) {
+    for (int64_t base = e0; base < e1; base += G) {
+        const int64_t e = base + lig;
+        const int my_col = e < e1 ? a.col[e] : 0;
+        const float my_val = e < e1 ? a.val[e] : 0.f;       // padded entries multiply by 0 -> exact no-op
+        const int cnt = (int)((e1 - base) < G ? (e1 - base) : G);
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {
+            int cc[4];
+            float vv[4];
+            f32x4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cc[q] = __shfl(my_col, t + q, G);
+                vv[q] = __shfl(my_val, t + q, G);
+            }
+            if (on) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = reinterpret_cast<const f32x4*>(a.X + (int64_t)cc[q] * a.d)[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fma4(acc, vv[q], x[q]);
+            }
+        }
+        for (; t < cnt; ++t) {
+            const int cc = __shfl(my_col, t, G);
+            const float vv = __shfl(my_val, t, G);
+            if (on) fma4(acc, vv, reinterpret_cast<const f32x4*>(a.X + (int64_t)cc * a.d)[c]);
+        }
+    }
+}
 
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
@@ -37,72 +98,98 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     const int nvec = a.d >> 2;
     for (int64_t row = row0; row < a.n_rows; row += rstride) {
         const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
-        for (int c0 = 0; c0 < nvec; c0 += G) {          // one pass when d <= 4*G
+        if (a.n_heavy && e1 - e0 > SPMM_HEAVY_DEG) continue;     // done by spmm_heavy_kernel
+        for (int c0 = 0; c0 < nvec; c0 += G) {                  // one pass when d <= 4*G
             const int c = c0 + lig;
             const bool on = c < nvec;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int64_t base = e0; base < e1; base += G) {
-                const int64_t e = base + lig;
-                const int my_col = e < e1 ? a.col[e] : 0;
-                const float my_val = e < e1 ? a.val[e] : 0.f;
-                const int cnt = (int)((e1 - base) < G ? (e1 - base) : G);
-                for (int t = 0; t < cnt; ++t) {
-                    const int cc = __shfl(my_col, t, G);
-                    const float vv = __shfl(my_val, t, G);
-                    if (on) {
-                        const f32x4 x = reinterpret_cast<const f32x4*>(a.X + (int64_t)cc * a.d)[c];
-                        acc.x = fmaf(vv, x.x, acc.x);
-                        acc.y = fmaf(vv, x.y, acc.y);
-                        acc.z = fmaf(vv, x.z, acc.z);
-                        acc.w = fmaf(vv, x.w, acc.w);
-                    }
-                }
-            }
-            if (on) {
-                const int64_t o = row * a.d + (int64_t)c * 4;
-                if (a.Y) *reinterpret_cast<f32x4*>(a.Y + o) = acc;
-                if (a.acc_out) {
-                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    if (a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
-                    f32x4 r;
-                    r.x = (z.x * a.s_in + acc.x) * a.s_out;
-                    r.y = (z.y * a.s_in + acc.y) * a.s_out;
-                    r.z = (z.z * a.s_in + acc.z) * a.s_out;
-                    r.w = (z.w * a.s_in + acc.w) * a.s_out;
-                    *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
-                }
-            }
+            row_edges<G>(a, e0, e1, c, on, lig, acc);
+            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
         }
     }
 }
 
+// One block per heavy row: the 256/G lane groups take the row's G-edge chunks round-robin, and their
+// partial sums are combined through LDS in group order (deterministic; differs from the pure
+// edge-order chain only in association, well inside the 1e-5 budget of SURVEY.md A6).
+template <int G>
+__global__ __launch_bounds__(256) void spmm_heavy_kernel(SpmmArgs a) {
+    constexpr int NG = 256 / G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* part = reinterpret_cast<f32x4*>(smem);                // [NG][nvec]
+    const int lig = threadIdx.x % G, grp = threadIdx.x / G;
+    const int nvec = a.d >> 2;
+    for (int h = blockIdx.x; h < a.n_heavy; h += gridDim.x) {
+        const int64_t row = a.heavy_rows[h];
+        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+        for (int c0 = 0; c0 < nvec; c0 += G) {
+            const int c = c0 + lig;
+            const bool on = c < nvec;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int64_t base = e0 + (int64_t)grp * G; base < e1; base += (int64_t)NG * G) {
+                const int64_t end = base + G < e1 ? base + G : e1;
+                row_edges<G>(a, base, end, c, on, lig, acc);
+            }
+            if (on) part[grp * nvec + c] = acc;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < nvec; c += 256) {
+            f32x4 acc = part[c];
+            for (int g = 1; g < NG; ++g) {
+                const f32x4 p = part[g * nvec + c];
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            store_row(a, row * a.d + (int64_t)c * 4, acc);
+        }
+        __syncthreads();
+    }
+}
+
+template <int G>
+int launch_spmm(const SpmmArgs& a, hipStream_t st) {
+    const int64_t rows_per_block = 256 / G;
+    int64_t blocks = (a.n_rows + rows_per_block - 1) / rows_per_block;
+    if (blocks > 65535 * 4) blocks = 65535 * 4;
+    hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    CRH_HIP(hipGetLastError());
+    if (a.n_heavy) {
+        const size_t lds = (size_t)(256 / G) * (a.d / 4) * 16;
+        if (lds > 64 * 1024)
+            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_heavy_kernel<G>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int hb = a.n_heavy < 4096 ? a.n_heavy : 4096;
+        hipLaunchKernelGGL(spmm_heavy_kernel<G>, dim3((unsigned)hb), dim3(256), lds, st, a);
+        CRH_HIP(hipGetLastError());
+    }
+    return CRH_OK;
+}
+
 }  // namespace
+
+extern "C" int crh_spmm_heavy_degree(void) { return SPMM_HEAVY_DEG; }
 
 extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                                 const float* x, int d, float* y, const float* acc_in, float s_in,
-                                float* acc_out, float s_out, void* stream) {
+                                float* acc_out, float s_out, const int32_t* heavy_rows, int n_heavy,
+                                void* stream) {
     CRH_CHECK_ARG(rowptr && x && n_rows > 0, "crh_spmm_csr_f32: NULL pointer / empty matrix");
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_spmm_csr_f32: d=%d must be a positive multiple of 4", d);
     CRH_CHECK_ARG(y || acc_out, "crh_spmm_csr_f32: nothing to write (y and acc_out both NULL)");
     CRH_CHECK_ARG(y != x && acc_out != x, "crh_spmm_csr_f32: outputs must not alias x");
     CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out) & 15) == 0,
                   "crh_spmm_csr_f32: dense operands must be 16-byte aligned");
-    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out};
+    CRH_CHECK_ARG(n_heavy >= 0 && (n_heavy == 0 || heavy_rows), "crh_spmm_csr_f32: heavy row list missing");
+    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, heavy_rows, n_heavy};
     int G = 1;
     while (G < d / 4 && G < 64) G <<= 1;
-    const int64_t rows_per_block = 256 / G;
-    int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
-    if (blocks > 65535 * 4) blocks = 65535 * 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (G) {
-        case 1: hipLaunchKernelGGL(spmm_csr_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(spmm_csr_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(spmm_csr_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL(spmm_csr_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        case 16: hipLaunchKernelGGL(spmm_csr_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        case 32: hipLaunchKernelGGL(spmm_csr_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(spmm_csr_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case 1: return launch_spmm<1>(a, st);
+        case 2: return launch_spmm<2>(a, st);
+        case 4: return launch_spmm<4>(a, st);
+        case 8: return launch_spmm<8>(a, st);
+        case 16: return launch_spmm<16>(a, st);
+        case 32: return launch_spmm<32>(a, st);
+        default: return launch_spmm<64>(a, st);
     }
-    CRH_HIP(hipGetLastError());
-    return CRH_OK;
 }

@@ -23,16 +23,16 @@ class _SpmmFn(torch.autograd.Function):
         ctx.adj = adj
         x = dense.contiguous().float()
         y = torch.empty((adj.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-        rp, col, val = adj.csr(x.device)
-        ops.spmm_csr(rp, col, val, x, y=y)
+        rp, col, val, heavy = adj.csr(x.device)
+        ops.spmm_csr(rp, col, val, x, y=y, heavy_rows=heavy)
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
         g = grad_out.contiguous().float()
-        rp, col, val = ctx.adj.csr(g.device, transposed=True)
+        rp, col, val, heavy = ctx.adj.csr(g.device, transposed=True)
         gx = torch.empty((ctx.adj.shape[1], g.shape[1]), dtype=torch.float32, device=g.device)
-        ops.spmm_csr(rp, col, val, g, y=gx)
+        ops.spmm_csr(rp, col, val, g, y=gx, heavy_rows=heavy)
         return None, gx
 
 
@@ -59,7 +59,8 @@ class HipSparseAdj(torch.Tensor):
             m.sort_indices()
             self._dev[key] = (torch.from_numpy(m.indptr.astype(np.int64)).to(device),
                               torch.from_numpy(m.indices.astype(np.int32)).to(device),
-                              torch.from_numpy(m.data.astype(np.float32)).to(device))
+                              torch.from_numpy(m.data.astype(np.float32)).to(device),
+                              ops.heavy_rows_of(m.indptr, device))
         return self._dev[key]
 
     @classmethod

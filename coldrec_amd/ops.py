@@ -186,7 +186,15 @@ def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps:
     _lib.check(rc, "crh_adam_dense_f32")
 
 
-def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0):
+def heavy_rows_of(rowptr, device) -> Optional[torch.Tensor]:
+    """int32 device list of the rows crh_spmm_csr_f32 should give a whole workgroup (built once per graph)."""
+    rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
+    rows = np.nonzero(np.diff(rp) > _lib.lib().crh_spmm_heavy_degree())[0].astype(np.int32)
+    return torch.from_numpy(rows).to(device) if rows.size else None
+
+
+def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0,
+             heavy_rows: Optional[torch.Tensor] = None):
     """P = A @ x; y = P; acc_out = (acc_in*s_in + P)*s_out  (model/LightGCN.py:88-93, fused layer sum)."""
     _need_cuda(rowptr, col, val, x, y, acc_in, acc_out)
     assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
@@ -194,5 +202,6 @@ def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_ou
     n_rows, d = rowptr.shape[0] - 1, x.shape[1]
     rc = _lib.lib().crh_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                      _lib.ptr(y), _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
+                                     _lib.ptr(heavy_rows), 0 if heavy_rows is None else int(heavy_rows.shape[0]),
                                      _lib.current_stream())
     _lib.check(rc, "crh_spmm_csr_f32")

@@ -129,10 +129,15 @@ int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0,
  * rowptr (n_rows+1) int64, col int32 ascending per row, val fp32 (util/databuilder.py:220-254,953-962
  * produce exactly this matrix, as COO); x, y, acc_* are (n_rows, d) fp32, d % 4 == 0.
  * acc_out may alias acc_in; outputs must not alias x.
+ * heavy_rows (n_heavy int32, may be NULL/0): the rows with more than crh_spmm_heavy_degree() edges,
+ * listed once per graph by the caller; each gets a whole workgroup (popular items of a Zipf
+ * catalogue have thousands of edges).  Every row with more edges than that MUST be listed when
+ * n_heavy > 0; with n_heavy == 0 all rows take the one-lane-group-per-row path.
  */
+int crh_spmm_heavy_degree(void);
 int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                      const float* x, int d, float* y, const float* acc_in, float s_in,
-                     float* acc_out, float s_out, void* stream);
+                     float* acc_out, float s_out, const int32_t* heavy_rows, int n_heavy, void* stream);
 
 /*
  * HOST-side negative sampler reproducing util/utils.py:123-157 (next_batch_pairwise) and NumPy's
