@@ -208,6 +208,28 @@ def train_legs(dev, with_cpu):
     return out
 
 
+def train_xl(dev, steps, warm):
+    """HBM-roofline case for the training kernels: tables far beyond every cache."""
+    from coldrec_amd.train import MFEngine
+    n_u, n_i, d, B = 1_000_000, 10_000_000, 128, 65536
+    eng = MFEngine.__new__(MFEngine)
+    eng.user_num, eng.item_num, eng.d, eng.device = n_u, n_i, d, dev
+    eng.E = xavier_(n_u + n_i, d, 1, dev, n_i)
+    eng.G, eng.M, eng.V = (torch.zeros_like(eng.E) for _ in range(3))
+    eng.lr, eng.reg, eng.step_count = 1e-3, 1e-4, 0
+    eng.loss = torch.zeros(2, dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    tri = [(torch.randint(0, n_u, (B,), generator=g, device=dev, dtype=torch.int32),
+            torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32),
+            torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32)) for _ in range(4)]
+    sec = _time_steps(lambda s: eng.step(*tri[s % 4]), steps, warm)
+    bytes_step = 24 * d * B + 32 * (n_u + n_i) * d
+    return {"metric": "BPR triples/sec (train)", "value": B / sec, "unit": "triples/s", "ms_per_step": sec * 1e3,
+            "config": {"workload": "S-TRAIN-XL: BPR-MF, 1M users x 10M items, d=128, B=65536, dense Adam"},
+            "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,12 +237,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--users", type=int, default=1_000_000, help="rows of the user table")
-    ap.add_argument("--users-per-step", type=int, default=16384)
+    ap.add_argument("--users-per-step", type=int, default=32768)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--n-splits", type=int, default=0)
+    ap.add_argument("--masks", choices=["warm", "none"], default="warm",
+                    help="'warm' = rated CSR + 20%% cold-item bitmap (default); 'none' = diagnostic run without masks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary train legs (N=1 only)")
+    ap.add_argument("--train-xl", action="store_true",
+                    help="only run the S-TRAIN-XL roofline case of SURVEY.md 8(d) (1M users x 10M items, d=128, "
+                         "B=65536 MF steps; 22.5 GB of state) and print its JSON line")
     ap.add_argument("--cpu-sample-users", type=int, default=256)
     ap.add_argument("--cpu-sample-items", type=int, default=2_500_000)
     args = ap.parse_args()
@@ -240,6 +267,10 @@ def main():
 
     from coldrec_amd import ops
     from coldrec_amd.eval import ShardedTopK
+
+    if args.train_xl:
+        print(json.dumps(train_xl(dev, args.steps, args.warmup)), flush=True)
+        return
 
     I, d, k, Bu = args.items, args.dim, args.k, args.users_per_step
     lo, hi = rank * I // world, (rank + 1) * I // world
@@ -262,6 +293,8 @@ def main():
 
     def step(b, ev=None):
         users, rp, rc = blocks[b]
+        if args.masks == "none":
+            return engine.topk(U, users, None, None, None, n_splits=args.n_splits, kernel_events=ev)
         return engine.topk(U, users, rp, rc, bitmap, n_splits=args.n_splits, kernel_events=ev)
 
     def barrier():

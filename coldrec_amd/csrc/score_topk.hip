@@ -24,7 +24,9 @@
 //     the blocks of one XCD (b % 8) stream the same item rows through that XCD's L2.
 //     Partial lists are merged by merge_topk with the same canonical key, so the result does
 //     not depend on S, on the tiling or (after the all-gather) on the GPU count.
+#include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "crh_common.h"
 #include "topk_list.h"
@@ -46,6 +48,7 @@ struct ScoreArgs {
     int64_t n_ugroups;
     float* out_score;   // [n_splits][n_users][k]
     int32_t* out_idx;
+    int ablate;         // measurement only (CRH_SCORE_ABLATE): 1 = skip the selection epilogue
 };
 
 // in : lane (i,0) holds k = 8q+0..3 of row i, lane (i,1) holds k = 8q+4..7
@@ -122,8 +125,13 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
     tau_reg = wave_list_tau(w.ls + my * K, w.cnt[my], K);
 }
 
-template <int D, int UW, int WPW>
-__global__ __launch_bounds__(64 * WPW) void score_topk_kernel(ScoreArgs a) {
+// OCC = waves per SIMD the kernel is built for:
+//   1: two register tiles (A double-buffered), ~320 VGPR+AGPR, one wave per SIMD;
+//   2: one register tile reloaded chunk by chunk right behind its last use, <= 256 registers, so a
+//      second wave on the SIMD fills the matrix pipe while this one selects / waits / inserts.
+template <int D, int UW, int OCC>
+__global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
+    constexpr int WPW = 1;
     constexpr int NCH = D / 8;
     constexpr int UPW = 32 * UW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(64 * WPW) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) dst[q] = load4(vp + 8 * q);
     };
-    auto do_tile = [&](f32x4(&src)[NCH], int64_t t) {
+    auto do_tile = [&](f32x4(&src)[NCH], int64_t t, const float* vnext) {
         f32x16 acc[UW];
 #pragma unroll
         for (int u = 0; u < UW; ++u)
@@ -202,6 +210,19 @@ __global__ __launch_bounds__(64 * WPW) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
             for (int u = 0; u < UW; ++u)
                 acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b[u][q].w, acc[u], 0, 0, 0);
+            if (OCC > 1) {   // ring: the chunk just consumed is refilled with the next tile's rows
+                src[q] = load4(vnext + 8 * q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (a.ablate & 1) {   // keep the products live, skip selection (roofline ablation, results invalid)
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(acc[u]));
+#endif
+            }
+            return;
         }
         // selection: one compare per lane and accumulator in the common case
 #pragma unroll
@@ -216,16 +237,26 @@ __global__ __launch_bounds__(64 * WPW) void score_topk_kernel(ScoreArgs a) {
     };
 
     if (t0 < t1) {
-        f32x4 ta[NCH], tb[NCH];
-        load_tile(ta, t0);
-        for (int64_t t = t0; t < t1; t += 2) {
-            load_tile(tb, t + 1);   // rows past the split end are clamped: always a valid address
-            __builtin_amdgcn_sched_barrier(0);
-            do_tile(ta, t);
-            if (t + 1 >= t1) break;
-            load_tile(ta, t + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            do_tile(tb, t + 1);
+        if constexpr (OCC == 1) {
+            f32x4 ta[NCH], tb[NCH];
+            load_tile(ta, t0);
+            for (int64_t t = t0; t < t1; t += 2) {
+                load_tile(tb, t + 1);   // rows past the split end are clamped: always a valid address
+                __builtin_amdgcn_sched_barrier(0);
+                do_tile(ta, t, nullptr);
+                if (t + 1 >= t1) break;
+                load_tile(ta, t + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                do_tile(tb, t + 1, nullptr);
+            }
+        } else {
+            f32x4 ta[NCH];
+            load_tile(ta, t0);
+            for (int64_t t = t0; t < t1; ++t) {
+                int64_t nrow = ((t + 1) << 5) + i;
+                if (nrow >= split_end) nrow = split_end - 1;
+                do_tile(ta, t, a.item_emb + nrow * D + 4 * h);
+            }
         }
     }
 
@@ -242,11 +273,12 @@ __global__ __launch_bounds__(64 * WPW) void score_topk_kernel(ScoreArgs a) {
     }
 }
 
-template <int D, int UW, int WPW>
+template <int D, int UW, int OCC>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
     constexpr int UPW = 32 * UW;
+    constexpr int WPW = 1;
     const size_t lds = wave_lds_bytes<UPW>(a.k) * WPW;
-    auto kern = score_topk_kernel<D, UW, WPW>;
+    auto kern = score_topk_kernel<D, UW, OCC>;
     if (lds > 64 * 1024)
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -259,12 +291,28 @@ int launch_score(const ScoreArgs& a, hipStream_t stream) {
 
 constexpr int users_per_wave(int d) { return d >= 256 ? 32 : (d >= 128 ? 64 : 128); }
 
-int pick_splits(int64_t n_ugroups, int64_t n_items) {
-    // aim at ~one wave per SIMD (256 CUs x 4) with power-of-two splits, >= 64 tiles per split
-    const int64_t target = 1024;
-    int s = 1;
-    while (s < 64 && n_ugroups * (s * 2) <= target && n_items / (s * 2) >= 64 * 32) s *= 2;
-    return s;
+// Item-range split count.  Workgroups are single waves that all take the same time, and the
+// dispatcher packs them occ-per-SIMD CU by CU (measured: a grid of half the capacity runs on half
+// the CUs), so the grid should fill a whole number of "rounds" of capacity = 256 CUs x 4 SIMDs x occ.
+// Every extra split costs extra slow-path inserts (~k*ln(range/k) per user and split); the model
+// below (5700*S/T relative overhead, fitted on the 10M-item run) trades that against idle slots.
+int pick_splits(int64_t n_ugroups, int64_t n_items, int occ) {
+    const double cap = 1024.0 * occ;
+    const int64_t T = (n_items + 31) / 32;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && T / s < 64) break;                       // keep >= 64 tiles per split
+        const double w = (double)n_ugroups * s;
+        const double rounds = ceil(w / cap);
+        const double eff = w / (rounds * cap);
+        const double cost = (1.0 + 5700.0 * s / (double)T) / eff;
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
 }
 
 }  // namespace
@@ -312,7 +360,13 @@ extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users
     a.k = k;
     a.item_base = item_base;
     a.n_ugroups = (n_users + upw - 1) / upw;
-    a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items);
+    static const int ablate = getenv("CRH_SCORE_ABLATE") ? atoi(getenv("CRH_SCORE_ABLATE")) : 0;
+    a.ablate = ablate;
+    // d=128: two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured);
+    // CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD build (tuning hook)
+    static const int variant = getenv("CRH_SCORE_OCC") ? atoi(getenv("CRH_SCORE_OCC")) : 2;
+    const int occ = (variant == 2 && d == 128) ? 2 : 1;
+    a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items, occ);
     const int64_t T = (n_items + 31) / 32;
     if (a.n_splits > T) a.n_splits = (int)T;
 
@@ -336,7 +390,7 @@ extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users
         case 16: rc = launch_score<16, 4, 1>(a, st); break;
         case 32: rc = launch_score<32, 4, 1>(a, st); break;
         case 64: rc = launch_score<64, 4, 1>(a, st); break;
-        case 128: rc = launch_score<128, 2, 1>(a, st); break;
+        case 128: rc = occ == 2 ? launch_score<128, 2, 2>(a, st) : launch_score<128, 2, 1>(a, st); break;
         default: rc = launch_score<256, 1, 1>(a, st); break;
     }
     if (rc != CRH_OK) return rc;
