@@ -150,10 +150,16 @@ def train_legs(dev, with_cpu):
             eng = MFEngine(U0, V0, 1e-3, 1e-4, dev)
         tu, ti, tj = (torch.from_numpy(x).to(dev) for x in (u, i, j))
         steps = [(lo, min(lo + B, n)) for lo in range(0, n, B)]
+        from coldrec_amd import ops as _ops
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plans = _ops.build_plans_device(tu, ti, tj, B)       # reverse indices of the epoch's batches
+        torch.cuda.synchronize()
+        t_plans = time.perf_counter() - t0
 
         def one(s):
             lo, hi = steps[s % len(steps)]
-            eng.step(tu[lo:hi], ti[lo:hi], tj[lo:hi])
+            eng.step(tu[lo:hi], ti[lo:hi], tj[lo:hi], plans[s % len(steps)])
 
         sec = _time_steps(one, len(steps), 3)
         N, nnz = n_u + n_i, (len(val) if layers else 0)
@@ -165,7 +171,7 @@ def train_legs(dev, with_cpu):
                "config": {"workload": "configs[%d] %s, %s-shaped synthetic (%d users x %d items, %d train triples), "
                                       "d=%d, B=%d, dense Adam" % (2 if layers else 1, "LightGCN L=3" if layers else "BPR-MF",
                                                                   shape, n_u, n_i, n, d, B)},
-               "host_sampler_s_per_epoch": t_sample,
+               "host_sampler_s_per_epoch": t_sample, "device_plan_s_per_epoch": t_plans,
                "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                             "traffic": None, "note": "whole step (all kernels of one optimiser step)"}}

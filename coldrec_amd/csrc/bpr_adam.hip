@@ -16,7 +16,9 @@
 // Row gradients are accumulated with hardware fp32 atomics (global_atomic_add_f32).
 #include <math.h>
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "crh_common.h"
 
@@ -42,6 +44,7 @@ struct BprArgs {
     float* partials;   // [nblocks][4]: sum u^2, sum p^2, sum n^2, sum loss
     float* loss_out;   // [2]: bpr, l2   (may be NULL)
     int nblocks_fwd;
+    const int32_t* plan;   // reverse index of the batch (crh_bpr_plan_build_host) or NULL
 };
 
 template <int G>
@@ -161,6 +164,94 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_kernel(BprArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- deterministic backward (no atomics)
+// Reverse index of one batch ("plan", int32, built on the host next to the sampler):
+//   [0] nu  [1] ni  [2] L = layout batch size (>= the batch; one stride for all batches of an epoch)
+//   [3 .. 3+L)  user rows touched (ascending), then (L+1) offsets into the user list, L triple ids
+//   grouped by user row; then 2L item rows, (2L+1) offsets, 2L entries  b | (role << 30)
+//   (role 0 = positive, 1 = negative).
+// One lane group owns one touched row and sums its contributions in list order, then STORES the
+// row of the dense gradient table (which is zero everywhere else): no atomics, bit-reproducible.
+__host__ __device__ inline int64_t plan_ints(int64_t L) { return 3 + (3 * L + 1) + (6 * L + 1); }
+
+template <int G>
+__global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a) {
+    __shared__ float red[4];
+    __shared__ float tot[4];
+    for (int q = 0; q < 4; ++q) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) s += a.partials[(size_t)i * 4 + q];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) tot[q] = s;
+    }
+    __syncthreads();
+    const float invB = 1.0f / (float)a.B;
+    const float nu_ = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) {
+        a.loss_out[0] = tot[3] * invB;
+        a.loss_out[1] = a.reg * (nu_ * invB + np_ * invB + nn * invB);
+    }
+    const float cu = nu_ > 0.f ? a.reg * invB / nu_ : 0.f;
+    const float cp = np_ > 0.f ? a.reg * invB / np_ : 0.f;
+    const float cn = nn > 0.f ? a.reg * invB / nn : 0.f;
+
+    const int32_t* pl = a.plan;
+    const int n_u = pl[0], n_i = pl[1];
+    const int64_t L = pl[2];
+    const int32_t* urow = pl + 3;
+    const int32_t* uptr = urow + L;
+    const int32_t* ulist = uptr + (L + 1);
+    const int32_t* irow = ulist + L;
+    const int32_t* iptr = irow + 2 * L;
+    const int32_t* ilist = iptr + (2 * L + 1);
+
+    const int lig = threadIdx.x % G;
+    const int64_t gid = (int64_t)blockIdx.x * (BPR_THREADS / G) + threadIdx.x / G;
+    const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
+    const int nvec = a.d >> 2;
+    for (int64_t w = gid; w < (int64_t)n_u + n_i; w += gstride) {
+        const bool user_side = w < n_u;
+        const int64_t row = user_side ? urow[w] : irow[w - n_u];
+        const int e0 = user_side ? uptr[w] : iptr[w - n_u];
+        const int e1 = user_side ? uptr[w + 1] : iptr[w - n_u + 1];
+        for (int c = lig; c < nvec; c += G) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int e = e0; e < e1; ++e) {
+                const int ent = user_side ? ulist[e] : ilist[e];
+                const int b = ent & 0x3fffffff;
+                const int role = ent >> 30;
+                const float x = a.xbuf[b];
+                const float sig = 1.0f / (1.0f + expf(-x));
+                const float g = -invB * sig * (1.0f - sig) / (1e-5f + sig);
+                const int64_t ru = a.iu[b], rp = a.ip[b], rn = a.in_[b];
+                const f32x4 u = reinterpret_cast<const f32x4*>(a.tu + ru * a.d)[c];
+                if (user_side) {
+                    const f32x4 p = reinterpret_cast<const f32x4*>(a.tp + rp * a.d)[c];
+                    const f32x4 n = reinterpret_cast<const f32x4*>(a.tn + rn * a.d)[c];
+                    acc.x += g * (p.x - n.x) + cu * u.x;
+                    acc.y += g * (p.y - n.y) + cu * u.y;
+                    acc.z += g * (p.z - n.z) + cu * u.z;
+                    acc.w += g * (p.w - n.w) + cu * u.w;
+                } else if (role == 0) {
+                    const f32x4 p = reinterpret_cast<const f32x4*>(a.tp + rp * a.d)[c];
+                    acc.x += g * u.x + cp * p.x;
+                    acc.y += g * u.y + cp * p.y;
+                    acc.z += g * u.z + cp * p.z;
+                    acc.w += g * u.w + cp * p.w;
+                } else {
+                    const f32x4 n = reinterpret_cast<const f32x4*>(a.tn + rn * a.d)[c];
+                    acc.x += -g * u.x + cn * n.x;
+                    acc.y += -g * u.y + cn * n.y;
+                    acc.z += -g * u.z + cn * n.z;
+                    acc.w += -g * u.w + cn * n.w;
+                }
+            }
+            float* dst = (user_side ? a.gu : a.gp) + row * a.d + c * 4;
+            *reinterpret_cast<f32x4*>(dst) = acc;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- dense Adam (+ zero the gradient)
 struct AdamSeg {
     float* p;
@@ -218,6 +309,52 @@ int dispatch_group(int g, F&& f) {
 
 }  // namespace
 
+extern "C" int64_t crh_bpr_plan_ints(int64_t batch) { return batch > 0 ? plan_ints(batch) : 0; }
+
+// HOST function: reverse index of one batch of triples (see bpr_bwd_rows_kernel).  Item-side
+// gradients of positives and negatives land in the SAME table (grad_pos == grad_neg).
+extern "C" int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx_host,
+                                       const int32_t* neg_idx_host, int64_t batch, int64_t layout_batch,
+                                       int32_t* plan_out_host) {
+    CRH_CHECK_ARG(user_idx_host && pos_idx_host && neg_idx_host && plan_out_host && batch > 0,
+                  "crh_bpr_plan_build_host: bad arguments");
+    CRH_CHECK_ARG(layout_batch >= batch && layout_batch < (1 << 30), "crh_bpr_plan_build_host: bad layout batch");
+    const int64_t B = batch, L = layout_batch;
+    int32_t* pl = plan_out_host;
+    pl[2] = (int32_t)L;
+    int32_t* urow = pl + 3;
+    int32_t* uptr = urow + L;
+    int32_t* ulist = uptr + (L + 1);
+    int32_t* irow = ulist + L;
+    int32_t* iptr = irow + 2 * L;
+    int32_t* ilist = iptr + (2 * L + 1);
+    std::vector<uint64_t> keys((size_t)2 * B);
+    for (int64_t b = 0; b < B; ++b) keys[b] = ((uint64_t)(uint32_t)user_idx_host[b] << 32) | (uint32_t)b;
+    std::sort(keys.begin(), keys.begin() + B);
+    int nu = 0;
+    for (int64_t e = 0; e < B; ++e) {
+        const int32_t row = (int32_t)(keys[e] >> 32);
+        if (e == 0 || row != urow[nu - 1]) { urow[nu] = row; uptr[nu] = (int32_t)e; ++nu; }
+        ulist[e] = (int32_t)(keys[e] & 0xffffffffu);
+    }
+    uptr[nu] = (int32_t)B;
+    for (int64_t b = 0; b < B; ++b) {
+        keys[2 * b] = ((uint64_t)(uint32_t)pos_idx_host[b] << 32) | (uint32_t)b;
+        keys[2 * b + 1] = ((uint64_t)(uint32_t)neg_idx_host[b] << 32) | (uint32_t)b | (1u << 30);
+    }
+    std::sort(keys.begin(), keys.end());      // inside a row: positives (ascending b), then negatives
+    int ni = 0;
+    for (int64_t e = 0; e < 2 * B; ++e) {
+        const int32_t row = (int32_t)(keys[e] >> 32);
+        if (e == 0 || row != irow[ni - 1]) { irow[ni] = row; iptr[ni] = (int32_t)e; ++ni; }
+        ilist[e] = (int32_t)(keys[e] & 0xffffffffu);
+    }
+    iptr[ni] = (int32_t)(2 * B);
+    pl[0] = nu;
+    pl[1] = ni;
+    return CRH_OK;
+}
+
 extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
     if (batch <= 0) return 0;
     return (size_t)batch * 4 + (size_t)BPR_MAX_BLOCKS * 16 + 256;
@@ -226,8 +363,8 @@ extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
 extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table,
                                    int d, const int32_t* user_idx, const int32_t* pos_idx,
                                    const int32_t* neg_idx, int64_t batch, float reg, float* grad_user,
-                                   float* grad_pos, float* grad_neg, float* loss_out, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+                                   float* grad_pos, float* grad_neg, float* loss_out, const int32_t* plan,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     CRH_CHECK_ARG(user_table && pos_table && neg_table, "crh_bpr_fwd_bwd_f32: NULL table");
     CRH_CHECK_ARG(batch > 0, "crh_bpr_fwd_bwd_f32: empty batch");
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_bpr_fwd_bwd_f32: d=%d must be a positive multiple of 4", d);
@@ -236,6 +373,8 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
     CRH_CHECK_ARG((((uintptr_t)user_table | (uintptr_t)pos_table | (uintptr_t)neg_table | (uintptr_t)grad_user |
                     (uintptr_t)grad_pos | (uintptr_t)grad_neg) & 15) == 0,
                   "crh_bpr_fwd_bwd_f32: tables must be 16-byte aligned");
+    CRH_CHECK_ARG(!plan || (grad_user && user_idx && pos_idx && neg_idx && grad_pos == grad_neg && pos_table == neg_table),
+                  "crh_bpr_fwd_bwd_f32: a plan needs index arrays, gradient tables and one shared item table");
     if (!workspace || workspace_bytes < crh_bpr_workspace_bytes(batch)) {
         crh_set_error("crh_bpr_fwd_bwd_f32: workspace %zu < %zu bytes", workspace_bytes, crh_bpr_workspace_bytes(batch));
         return CRH_ERR_WS;
@@ -248,6 +387,7 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
     a.partials = reinterpret_cast<float*>(workspace);
     a.xbuf = a.partials + (size_t)BPR_MAX_BLOCKS * 4;
     a.loss_out = loss_out;
+    a.plan = plan;
     const int G = pick_group(d);
     const int64_t per_block = BPR_THREADS / G;
     int64_t blocks = (batch + per_block - 1) / per_block;
@@ -259,7 +399,12 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
         hipLaunchKernelGGL(bpr_fwd_kernel<GG>, dim3((unsigned)blocks), dim3(BPR_THREADS), 0, st, a);
         CRH_HIP(hipGetLastError());
         const unsigned bwd_blocks = (grad_user || loss_out) ? (grad_user ? (unsigned)blocks : 1u) : 0u;
-        if (bwd_blocks) {
+        if (plan) {
+            int64_t rb = (3 * batch + per_block - 1) / per_block;      // <= 3B touched rows
+            if (rb > BPR_MAX_BLOCKS) rb = BPR_MAX_BLOCKS;
+            hipLaunchKernelGGL(bpr_bwd_rows_kernel<GG>, dim3((unsigned)rb), dim3(BPR_THREADS), 0, st, a);
+            CRH_HIP(hipGetLastError());
+        } else if (bwd_blocks) {
             hipLaunchKernelGGL(bpr_bwd_kernel<GG>, dim3(bwd_blocks), dim3(BPR_THREADS), 0, st, a);
             CRH_HIP(hipGetLastError());
         }

@@ -11,6 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..train import MFEngine
 from ..util.utils import epoch_triples
 from .BaseRecommender import BaseColdStartTrainer
@@ -49,9 +50,10 @@ class MF(BaseColdStartTrainer):
         epoch = -1
         for epoch in range(self.maxEpoch):
             u, i, j = (torch.from_numpy(x).to(self.device) for x in epoch_triples(self.data, self.batch_size))
+            plans = ops.build_plans_device(u, i, j, self.batch_size)      # deterministic gradient rows
             for n, lo in enumerate(range(0, u.shape[0], self.batch_size)):
                 hi = min(lo + self.batch_size, u.shape[0])
-                eng.step(u[lo:hi], i[lo:hi], j[lo:hi])
+                eng.step(u[lo:hi], i[lo:hi], j[lo:hi], plans[n])
                 if n % 50 == 0:
                     print('training:', epoch + 1, 'batch', n, 'batch_loss:', eng.last_loss())
             self.user_emb, self.item_emb = eng.forward()

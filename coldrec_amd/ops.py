@@ -144,7 +144,8 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k_out: int):
 
 # ------------------------------------------------------------------------------ training ops
 def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, reg: float,
-                grad_user=None, grad_pos=None, grad_neg=None, loss_out: Optional[torch.Tensor] = None):
+                grad_user=None, grad_pos=None, grad_neg=None, loss_out: Optional[torch.Tensor] = None,
+                plan: Optional[torch.Tensor] = None):
     """bpr_loss + l2_reg_loss and their dense table gradients for one batch of triples
     (util/utils.py:25-29,44-48 + autograd at model/MF.py:22-26).  ``*_idx`` int32 device tensors or
     None (tables are already gathered).  Gradients are ACCUMULATED into ``grad_*`` (all three or
@@ -164,9 +165,76 @@ def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, re
     rc = L.crh_bpr_fwd_bwd_f32(_lib.ptr(user_table), _lib.ptr(pos_table), _lib.ptr(neg_table), d,
                                _lib.ptr(user_idx), _lib.ptr(pos_idx), _lib.ptr(neg_idx), batch, float(reg),
                                _lib.ptr(grad_user), _lib.ptr(grad_pos), _lib.ptr(grad_neg), _lib.ptr(loss_out),
-                               _lib.ptr(ws), ws.numel(), _lib.current_stream())
+                               _lib.ptr(plan), _lib.ptr(ws), ws.numel(), _lib.current_stream())
     _lib.check(rc, "crh_bpr_fwd_bwd_f32")
     return loss_out
+
+
+def build_plans(user_idx, pos_idx, neg_idx, batch_size: int) -> np.ndarray:
+    """Host: reverse indices ("plans") for every batch of an epoch of triples (int32 numpy arrays as the
+    sampler returns them).  Row b of the result is the plan of batch b (last batch: its own size)."""
+    L = _lib.lib()
+    u, p, n = (np.ascontiguousarray(x, dtype=np.int32) for x in (user_idx, pos_idx, neg_idx))
+    n_rec = u.shape[0]
+    n_batches = (n_rec + batch_size - 1) // batch_size
+    stride = int(L.crh_bpr_plan_ints(batch_size))
+    out = np.zeros((n_batches, stride), np.int32)
+    for b in range(n_batches):
+        lo, hi = b * batch_size, min((b + 1) * batch_size, n_rec)
+        rc = L.crh_bpr_plan_build_host(u[lo:hi].ctypes.data, p[lo:hi].ctypes.data, n[lo:hi].ctypes.data,
+                                       hi - lo, batch_size, out[b].ctypes.data)
+        _lib.check(rc, "crh_bpr_plan_build_host")
+    return out
+
+
+def build_plans_device(user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
+                       batch_size: int) -> torch.Tensor:
+    """Same plans as ``build_plans`` but assembled on the GPU once per epoch (device-side sort of the
+    epoch's triples batch by batch; pure index plumbing, ~1 ms per epoch at S-ML).  (n_batches, stride)."""
+    _need_cuda(user_idx, pos_idx, neg_idx)
+    dev, L = user_idx.device, int(batch_size)
+    n_rec = user_idx.numel()
+    nb = (n_rec + L - 1) // L
+    stride = int(_lib.lib().crh_bpr_plan_ints(L))
+    plans = torch.zeros((nb, stride), dtype=torch.int32, device=dev)
+    big = torch.iinfo(torch.int64).max
+    pad = nb * L - n_rec
+    bl = torch.arange(L, dtype=torch.int64, device=dev).repeat(nb)[: n_rec]
+
+    def side(rows_list, ents_list, width, off_rows):
+        rows = torch.cat([r.to(torch.int64) for r in rows_list])
+        ents = torch.cat(ents_list)
+        key = rows * (1 << 31) + ents
+        if pad:
+            # keep each batch contiguous: (batch, width) layout with the short last batch padded
+            parts = []
+            per = width // L
+            for q in range(per):
+                k = key[q * n_rec:(q + 1) * n_rec]
+                parts.append(torch.cat([k, torch.full((pad,), big, dtype=torch.int64, device=dev)]).view(nb, L))
+            key2 = torch.cat(parts, dim=1)
+        else:
+            per = width // L
+            key2 = torch.cat([key[q * n_rec:(q + 1) * n_rec].view(nb, L) for q in range(per)], dim=1)
+        key2, _ = torch.sort(key2, dim=1)
+        valid = key2 != big
+        srow = (key2 >> 31)
+        start = valid.clone()
+        start[:, 1:] &= srow[:, 1:] != srow[:, :-1]
+        rank = torch.cumsum(start, dim=1) - 1
+        t_idx, e_idx = torch.nonzero(start, as_tuple=True)
+        r_idx = rank[t_idx, e_idx]
+        plans[t_idx, off_rows + r_idx] = srow[t_idx, e_idx].to(torch.int32)
+        plans[t_idx, off_rows + width + r_idx] = e_idx.to(torch.int32)
+        nseg = start.sum(1)
+        plans[torch.arange(nb, device=dev), off_rows + width + nseg] = valid.sum(1).to(torch.int32)
+        plans[:, off_rows + 2 * width + 1: off_rows + 3 * width + 1] = (key2 & 0x7FFFFFFF).to(torch.int32)
+        return nseg.to(torch.int32)
+
+    plans[:, 2] = L
+    plans[:, 0] = side([user_idx], [bl], L, 3)
+    plans[:, 1] = side([pos_idx, neg_idx], [bl, bl + (1 << 30)], 2 * L, 3 + 3 * L + 1)
+    return plans
 
 
 def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,

@@ -47,10 +47,13 @@ class _TableState:
 class MFEngine(_TableState):
     """model/MF.py:12-29 with the tables resident on the GPU."""
 
-    def step(self, user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor) -> None:
+    def step(self, user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
+             plan: Optional[torch.Tensor] = None) -> None:
+        """``plan``: the batch's reverse index (ops.build_plans) -> deterministic gradient rows without
+        atomics; without it gradients are accumulated with fp32 atomics."""
         U = self.user_num
         ops.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
-                        self.G[:U], self.G[U:], self.G[U:], self.loss)
+                        self.G[:U], self.G[U:], self.G[U:], self.loss, plan=plan)
         self.step_count += 1
         ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True)
 
@@ -89,12 +92,12 @@ class LGCNEngine(_TableState):
         self._propagate(self.OUT)
         return self.OUT[: self.user_num], self.OUT[self.user_num:]
 
-    def step(self, user_idx, pos_idx, neg_idx) -> None:
+    def step(self, user_idx, pos_idx, neg_idx, plan: Optional[torch.Tensor] = None) -> None:
         U, c = self.user_num, 1.0 / (self.L + 1)
         self._propagate(self.OUT)
         self.dOUT.zero_()
         ops.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
-                        self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], self.loss)
+                        self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], self.loss, plan=plan)
         # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
         x = self.dOUT
         for j in range(self.L):

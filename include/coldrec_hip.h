@@ -105,12 +105,23 @@ int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, in
  * i.e. the tensors are already gathered: this is then bpr_loss/l2_reg_loss on (B,d) tensors).
  * grad_* are dense tables the gradients are ACCUMULATED into (zero them first; pos and neg may be the
  * same table); pass all three NULL for forward only.  loss_out[0] = bpr, loss_out[1] = l2 (device).
+ * plan (device int32, or NULL): the batch's reverse index -- [nu, ni, L, user rows[L], offsets[L+1],
+ * triple ids[L], item rows[2L], offsets[2L+1], entries[2L] = b | role<<30], L >= batch the layout size --
+ * built by crh_bpr_plan_build_host or on the device (coldrec_amd/train.py build_plans_device).  With a plan every touched gradient row is summed in a fixed order by one
+ * lane group and STORED (deterministic, no atomics; rows not touched are left as they are, i.e. zero);
+ * it requires pos_table == neg_table and grad_pos == grad_neg.  Without a plan rows are accumulated
+ * with fp32 atomics.
  */
 size_t crh_bpr_workspace_bytes(int64_t batch);
+int64_t crh_bpr_plan_ints(int64_t batch);
+int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx_host,
+                            const int32_t* neg_idx_host, int64_t batch, int64_t layout_batch,
+                            int32_t* plan_out_host);   /* crh_bpr_plan_ints(layout_batch) ints */
 int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
                         const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
                         int64_t batch, float reg, float* grad_user, float* grad_pos, float* grad_neg,
-                        float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+                        float* loss_out, const int32_t* plan, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /*
  * torch.optim.Adam(lr) defaults, dense, for up to two tensors in one launch (model/MF.py:14,27:

@@ -71,3 +71,28 @@ def test_negatives_never_rated_and_speed():
 def test_bad_records_rejected():
     with pytest.raises(RuntimeError, match="out of range"):
         PairwiseSampler(np.array([0, 5]), np.array([0, 1]), 3, 4)
+
+
+def test_host_plan_builder_reverse_index():
+    from coldrec_amd import ops
+    rng = np.random.default_rng(3)
+    B, L = 500, 512
+    u, p, n = (rng.integers(0, 60, B).astype(np.int32) for _ in range(3))
+    plan = ops.build_plans(u, p, n, L)[0]
+    nu, ni, lay = plan[:3]
+    assert lay == L
+    urow, uptr, ulist = plan[3:3 + L], plan[3 + L:4 + 2 * L], plan[4 + 2 * L:4 + 3 * L]
+    assert np.array_equal(urow[:nu], np.unique(u)) and uptr[nu] == B
+    for s in range(nu):
+        seg = ulist[uptr[s]:uptr[s + 1]]
+        assert (np.diff(seg) > 0).all() and (u[seg] == urow[s]).all()
+    o = 4 + 3 * L
+    irow, iptr, ilist = plan[o:o + 2 * L], plan[o + 2 * L:o + 4 * L + 1], plan[o + 4 * L + 1:o + 6 * L + 1]
+    assert np.array_equal(irow[:ni], np.unique(np.concatenate([p, n]))) and iptr[ni] == 2 * B
+    seen = 0
+    for s in range(ni):
+        for ent in ilist[iptr[s]:iptr[s + 1]]:
+            b, role = ent & 0x3FFFFFFF, ent >> 30
+            assert (n if role else p)[b] == irow[s]
+            seen += 1
+    assert seen == 2 * B

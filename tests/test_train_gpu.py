@@ -46,6 +46,49 @@ def test_bpr_fwd_bwd_vs_oracle(d, B, rows):
     np.testing.assert_allclose(gV, wV, rtol=1e-4, atol=2e-6 * sc)
 
 
+def _plan_views(plan):
+    nu, ni, L = int(plan[0]), int(plan[1]), int(plan[2])
+    urow, uptr, ulist = plan[3:3 + L], plan[3 + L:4 + 2 * L], plan[4 + 2 * L:4 + 3 * L]
+    o = 4 + 3 * L
+    irow, iptr, ilist = plan[o:o + 2 * L], plan[o + 2 * L:o + 4 * L + 1], plan[o + 4 * L + 1:o + 6 * L + 1]
+    return dict(urow=urow[:nu], uptr=uptr[:nu + 1], ulist=ulist[:uptr[nu]], irow=irow[:ni], iptr=iptr[:ni + 1],
+                ilist=ilist[:iptr[ni]])
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (37, 64), (4096, 4096)])
+def test_plan_backward_is_deterministic_and_exact(B, L):
+    """Reverse-index ("plan") backward: host and device builders agree, gradients equal the oracle,
+    two runs are bit-identical (no atomics), rows not touched stay zero."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(B)
+    rows, d = 300, 64
+    U = (rng.standard_normal((rows, d)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((rows + 50, d)) * 0.3).astype(np.float32)
+    ui = rng.integers(0, rows, B).astype(np.int32)
+    pi = rng.zipf(1.5, B).clip(1, rows + 50).astype(np.int32) - 1           # heavy duplicates
+    ni = rng.integers(0, rows + 50, B).astype(np.int32)
+    host = ops.build_plans(ui, pi, ni, L)[0]
+    devp = ops.build_plans_device(t(ui), t(pi), t(ni), L)
+    for k, v in _plan_views(host).items():
+        assert np.array_equal(v, _plan_views(devp[0].cpu().numpy())[k]), k
+    pv = _plan_views(host)
+    assert np.array_equal(pv["urow"], np.unique(ui)) and len(pv["ulist"]) == B and len(pv["ilist"]) == 2 * B
+    tU, tV = t(U), t(V)
+    outs = []
+    for _ in range(2):
+        gU, gV = torch.zeros_like(tU), torch.zeros_like(tV)
+        loss = ops.bpr_fwd_bwd(tU, tV, tV, t(ui), t(pi), t(ni), 0.01, gU, gV, gV, plan=devp[0])
+        outs.append((loss.clone(), gU, gV))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    bpr, l2, wU, wV, _ = orc.bpr_l2_fwd_bwd(U, V, ui, pi, ni, 0.01)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), [bpr, l2], rtol=1e-5)
+    sc = max(np.abs(wU).max(), np.abs(wV).max())
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), wU, rtol=1e-4, atol=2e-6 * sc)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), wV, rtol=1e-4, atol=2e-6 * sc)
+    untouched = np.setdiff1d(np.arange(rows), ui)
+    assert (outs[0][1].cpu().numpy()[untouched] == 0).all()
+
+
 @pytest.mark.parametrize("case", ["rand", "reg", "sat"])
 def test_bpr_golden_g2_gathered_tensors(case):
     """bpr_loss / l2_reg_loss on already gathered (B,d) tensors: identity indices (NULL)."""
@@ -123,9 +166,12 @@ def test_mf_training_golden_g3(d):
     eng = MFEngine(g[f"d{d}_U0"], g[f"d{d}_V0"], float(g["lr"]), float(g["reg"]), DEV)
     off = np.concatenate([[0], np.cumsum(g["sizes"])])
     tu, ti, tj = t(g["u"], torch.int32), t(g["i"], torch.int32), t(g["j"], torch.int32)
+    from coldrec_amd import ops
     for s in range(50):
         sl = slice(int(off[s]), int(off[s + 1]))
-        eng.step(tu[sl], ti[sl], tj[sl])
+        # odd steps through the deterministic plan path, even steps through the atomic path
+        plan = ops.build_plans_device(tu[sl], ti[sl], tj[sl], int(off[s + 1] - off[s]))[0] if s % 2 else None
+        eng.step(tu[sl], ti[sl], tj[sl], plan)
         np.testing.assert_allclose(eng.last_loss(), g[f"d{d}_loss"][s], rtol=1e-5)
         if s + 1 in (1, 10, 50):
             for got, want in ((eng.user_emb, g[f"d{d}_U_step{s+1}"]), (eng.item_emb, g[f"d{d}_V_step{s+1}"])):
