@@ -42,8 +42,9 @@ SIGNATURES = {
                                    _sz, _vp]),
     "crh_adam_dense_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
                                   _i64, _i32, _vp]),
-    "crh_spmm_heavy_degree": (_i32, []),
-    "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _i32, _vp]),
+    "crh_spmm_segment_edges": (_i32, []),
+    "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),
+    "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _sz, _vp]),
     "crh_sampler_create": (_vp, [_vp, _vp, _i64, _i32, _i32]),
     "crh_sampler_destroy": (None, [_vp]),
     "crh_sampler_seed": (_i32, [_vp, ctypes.c_uint32]),
@@ -52,6 +53,13 @@ SIGNATURES = {
     "crh_sampler_num_records": (_i64, [_vp]),
     "crh_sampler_epoch": (_i32, [_vp, _i64, _vp, _vp, _vp]),
 }
+
+
+class SpmmSched(ctypes.Structure):
+    """crh_spmm_sched of include/coldrec_hip.h."""
+    _fields_ = [("seg_row", _vp), ("seg_ptr", _vp), ("seg_slot", _vp), ("n_seg", _i64),
+                ("multi_row", _vp), ("multi_first", _vp), ("multi_count", _vp), ("n_multi", _i32),
+                ("n_partial", _i64)]
 
 
 def build(force: bool = False) -> str:

@@ -12,11 +12,13 @@
 // list is read coalesced (one (col,val) per lane) and broadcast by shuffles; each neighbour row is one
 // 16-B-per-lane read; products are accumulated in edge (ascending column) order with fmaf, which is
 // the oracle's order (oracle/topk_oracle.c orc_spmm_csr), so results are reproducible bit for bit.
+// Catalogues are Zipf-shaped (a popular item has thousands of edges, a user a few dozen), so the
+// caller may pass a SCHEDULE built once per graph: rows are cut into segments of <= 64 edges, every
+// segment is one work item, and the few rows with several segments are finished by a small combine
+// kernel that adds their partials in segment order (still deterministic, association differs).
 #include "crh_common.h"
 
 namespace {
-
-constexpr int SPMM_HEAVY_DEG = 512;   // rows with more edges than this get a whole block
 
 struct SpmmArgs {
     const int64_t* rowptr;
@@ -29,8 +31,8 @@ struct SpmmArgs {
     const float* acc_in;
     float* acc_out;
     float s_in, s_out;
-    const int32_t* heavy_rows;   // rows handled by spmm_heavy_kernel (skipped by the row kernel)
-    int n_heavy;
+    crh_spmm_sched sched;   // n_seg == 0: one lane group per row
+    float* partial;         // [n_partial][d] partial sums of the rows cut into several segments
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -63,7 +65,7 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
     for (int64_t base = e0; base < e1; base += G) {
         const int64_t e = base + lig;
         const int my_col = e < e1 ? a.col[e] : 0;
-        const float my_val = e < e1 ? a.val[e] : 0.f;       // padded entries multiply by 0 -> exact no-op
+        const float my_val = e < e1 ? a.val[e] : 0.f;
         const int cnt = (int)((e1 - base) < G ? (e1 - base) : G);
         int t = 0;
         for (; t + 4 <= cnt; t += 4) {
@@ -90,75 +92,63 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
     }
 }
 
+// Work item = one row (no schedule) or one segment of <= crh_spmm_segment_edges() edges of a row.
+// A row in one piece is finished here (bit-identical to the oracle's edge-order chain); a row cut
+// into several segments leaves one partial per segment and is finished by spmm_combine_kernel.
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     const int lig = threadIdx.x % G;
-    const int64_t row0 = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
-    const int64_t rstride = (int64_t)gridDim.x * (256 / G);
+    const int64_t w0 = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int64_t wstride = (int64_t)gridDim.x * (256 / G);
     const int nvec = a.d >> 2;
-    for (int64_t row = row0; row < a.n_rows; row += rstride) {
-        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
-        if (a.n_heavy && e1 - e0 > SPMM_HEAVY_DEG) continue;     // done by spmm_heavy_kernel
+    const bool seg = a.sched.n_seg > 0;
+    const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
+    for (int64_t w = w0; w < n_work; w += wstride) {
+        const int64_t row = seg ? a.sched.seg_row[w] : w;
+        const int64_t e0 = seg ? a.sched.seg_ptr[w] : a.rowptr[row];
+        const int64_t e1 = seg ? a.sched.seg_ptr[w + 1] : a.rowptr[row + 1];
+        const int slot = seg ? a.sched.seg_slot[w] : -1;
         for (int c0 = 0; c0 < nvec; c0 += G) {                  // one pass when d <= 4*G
             const int c = c0 + lig;
             const bool on = c < nvec;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             row_edges<G>(a, e0, e1, c, on, lig, acc);
-            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
+            if (on) {
+                if (slot < 0) store_row(a, row * a.d + (int64_t)c * 4, acc);
+                else *reinterpret_cast<f32x4*>(a.partial + (int64_t)slot * a.d + (int64_t)c * 4) = acc;
+            }
         }
     }
 }
 
-// One block per heavy row: the 256/G lane groups take the row's G-edge chunks round-robin, and their
-// partial sums are combined through LDS in group order (deterministic; differs from the pure
-// edge-order chain only in association, well inside the 1e-5 budget of SURVEY.md A6).
-template <int G>
-__global__ __launch_bounds__(256) void spmm_heavy_kernel(SpmmArgs a) {
-    constexpr int NG = 256 / G;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* part = reinterpret_cast<f32x4*>(smem);                // [NG][nvec]
-    const int lig = threadIdx.x % G, grp = threadIdx.x / G;
+// Rows cut into several segments: sum the partials in segment order (deterministic), then epilogue.
+__global__ __launch_bounds__(256) void spmm_combine_kernel(SpmmArgs a) {
     const int nvec = a.d >> 2;
-    for (int h = blockIdx.x; h < a.n_heavy; h += gridDim.x) {
-        const int64_t row = a.heavy_rows[h];
-        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
-        for (int c0 = 0; c0 < nvec; c0 += G) {
-            const int c = c0 + lig;
-            const bool on = c < nvec;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int64_t base = e0 + (int64_t)grp * G; base < e1; base += (int64_t)NG * G) {
-                const int64_t end = base + G < e1 ? base + G : e1;
-                row_edges<G>(a, base, end, c, on, lig, acc);
-            }
-            if (on) part[grp * nvec + c] = acc;
+    const int64_t total = (int64_t)a.sched.n_multi * nvec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / nvec), c = (int)(i - (int64_t)m * nvec);
+        const int first = a.sched.multi_first[m], cnt = a.sched.multi_count[m];
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.partial + (int64_t)first * a.d + c * 4);
+        for (int q = 1; q < cnt; ++q) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(a.partial + (int64_t)(first + q) * a.d + c * 4);
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
-        __syncthreads();
-        for (int c = threadIdx.x; c < nvec; c += 256) {
-            f32x4 acc = part[c];
-            for (int g = 1; g < NG; ++g) {
-                const f32x4 p = part[g * nvec + c];
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-            }
-            store_row(a, row * a.d + (int64_t)c * 4, acc);
-        }
-        __syncthreads();
+        store_row(a, (int64_t)a.sched.multi_row[m] * a.d + (int64_t)c * 4, acc);
     }
 }
 
 template <int G>
 int launch_spmm(const SpmmArgs& a, hipStream_t st) {
-    const int64_t rows_per_block = 256 / G;
-    int64_t blocks = (a.n_rows + rows_per_block - 1) / rows_per_block;
+    const int64_t per_block = 256 / G;
+    const int64_t n_work = a.sched.n_seg > 0 ? a.sched.n_seg : a.n_rows;
+    int64_t blocks = (n_work + per_block - 1) / per_block;
     if (blocks > 65535 * 4) blocks = 65535 * 4;
     hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     CRH_HIP(hipGetLastError());
-    if (a.n_heavy) {
-        const size_t lds = (size_t)(256 / G) * (a.d / 4) * 16;
-        if (lds > 64 * 1024)
-            CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_heavy_kernel<G>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int hb = a.n_heavy < 4096 ? a.n_heavy : 4096;
-        hipLaunchKernelGGL(spmm_heavy_kernel<G>, dim3((unsigned)hb), dim3(256), lds, st, a);
+    if (a.sched.n_seg > 0 && a.sched.n_multi > 0) {
+        int64_t cb = ((int64_t)a.sched.n_multi * (a.d / 4) + 255) / 256;
+        if (cb > 4096) cb = 4096;
+        hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)cb), dim3(256), 0, st, a);
         CRH_HIP(hipGetLastError());
     }
     return CRH_OK;
@@ -166,20 +156,38 @@ int launch_spmm(const SpmmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int crh_spmm_heavy_degree(void) { return SPMM_HEAVY_DEG; }
+extern "C" int crh_spmm_segment_edges(void) { return 64; }
+
+extern "C" size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d) {
+    return sched && sched->n_seg > 0 ? (size_t)sched->n_partial * (size_t)d * 4 : 0;
+}
 
 extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                                 const float* x, int d, float* y, const float* acc_in, float s_in,
-                                float* acc_out, float s_out, const int32_t* heavy_rows, int n_heavy,
-                                void* stream) {
+                                float* acc_out, float s_out, const crh_spmm_sched* sched, void* workspace,
+                                size_t workspace_bytes, void* stream) {
     CRH_CHECK_ARG(rowptr && x && n_rows > 0, "crh_spmm_csr_f32: NULL pointer / empty matrix");
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_spmm_csr_f32: d=%d must be a positive multiple of 4", d);
     CRH_CHECK_ARG(y || acc_out, "crh_spmm_csr_f32: nothing to write (y and acc_out both NULL)");
     CRH_CHECK_ARG(y != x && acc_out != x, "crh_spmm_csr_f32: outputs must not alias x");
-    CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out) & 15) == 0,
+    CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out | (uintptr_t)workspace) & 15) == 0,
                   "crh_spmm_csr_f32: dense operands must be 16-byte aligned");
-    CRH_CHECK_ARG(n_heavy >= 0 && (n_heavy == 0 || heavy_rows), "crh_spmm_csr_f32: heavy row list missing");
-    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, heavy_rows, n_heavy};
+    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr};
+    if (sched && sched->n_seg > 0) {
+        CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "crh_spmm_csr_f32: incomplete schedule");
+        CRH_CHECK_ARG(sched->n_multi == 0 || (sched->multi_row && sched->multi_first && sched->multi_count),
+                      "crh_spmm_csr_f32: incomplete schedule (multi-segment rows)");
+        const size_t need = crh_spmm_workspace_bytes(sched, d);
+        if (need && (!workspace || workspace_bytes < need)) {
+            crh_set_error("crh_spmm_csr_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+            return CRH_ERR_WS;
+        }
+        a.sched = *sched;
+        a.partial = reinterpret_cast<float*>(workspace);
+    } else {
+        a.sched.n_seg = 0;
+        a.sched.n_multi = 0;
+    }
     int G = 1;
     while (G < d / 4 && G < 64) G <<= 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -24,7 +24,7 @@ class _SpmmFn(torch.autograd.Function):
         x = dense.contiguous().float()
         y = torch.empty((adj.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         rp, col, val, heavy = adj.csr(x.device)
-        ops.spmm_csr(rp, col, val, x, y=y, heavy_rows=heavy)
+        ops.spmm_csr(rp, col, val, x, y=y, sched=heavy)
         return y
 
     @staticmethod
@@ -32,7 +32,7 @@ class _SpmmFn(torch.autograd.Function):
         g = grad_out.contiguous().float()
         rp, col, val, heavy = ctx.adj.csr(g.device, transposed=True)
         gx = torch.empty((ctx.adj.shape[1], g.shape[1]), dtype=torch.float32, device=g.device)
-        ops.spmm_csr(rp, col, val, g, y=gx, heavy_rows=heavy)
+        ops.spmm_csr(rp, col, val, g, y=gx, sched=heavy)
         return None, gx
 
 
@@ -60,7 +60,7 @@ class HipSparseAdj(torch.Tensor):
             self._dev[key] = (torch.from_numpy(m.indptr.astype(np.int64)).to(device),
                               torch.from_numpy(m.indices.astype(np.int32)).to(device),
                               torch.from_numpy(m.data.astype(np.float32)).to(device),
-                              ops.heavy_rows_of(m.indptr, device))
+                              ops.SpmmSchedule(m.indptr, device))
         return self._dev[key]
 
     @classmethod

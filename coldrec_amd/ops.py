@@ -2,6 +2,7 @@
 come from PyTorch-ROCm; all arithmetic happens in libcoldrec_hip.so.  No CPU fallback."""
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import numpy as np
@@ -254,22 +255,65 @@ def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps:
     _lib.check(rc, "crh_adam_dense_f32")
 
 
-def heavy_rows_of(rowptr, device) -> Optional[torch.Tensor]:
-    """int32 device list of the rows crh_spmm_csr_f32 should give a whole workgroup (built once per graph)."""
-    rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
-    rows = np.nonzero(np.diff(rp) > _lib.lib().crh_spmm_heavy_degree())[0].astype(np.int32)
-    return torch.from_numpy(rows).to(device) if rows.size else None
+class SpmmSchedule:
+    """Load-balancing schedule of one CSR matrix (see crh_spmm_sched): rows cut into segments of at
+    most crh_spmm_segment_edges() edges, built once per graph on the host with numpy."""
+
+    def __init__(self, rowptr, device):
+        rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
+        rp = rp.astype(np.int64)
+        seg = int(_lib.lib().crh_spmm_segment_edges())
+        deg = np.diff(rp)
+        nseg_row = np.maximum(1, -(-deg // seg))
+        seg_row = np.repeat(np.arange(len(deg), dtype=np.int32), nseg_row)
+        first_seg = np.zeros(len(deg) + 1, np.int64)
+        np.cumsum(nseg_row, out=first_seg[1:])
+        k_in_row = np.arange(int(first_seg[-1]), dtype=np.int64) - first_seg[seg_row]
+        seg_lo = rp[seg_row] + k_in_row * seg
+        seg_hi = np.minimum(seg_lo + seg, rp[seg_row.astype(np.int64) + 1])
+        seg_ptr = np.concatenate([seg_lo, seg_hi[-1:]]) if len(seg_lo) else np.zeros(1, np.int64)
+        multi = nseg_row > 1
+        multi_row = np.nonzero(multi)[0].astype(np.int32)
+        multi_count = nseg_row[multi].astype(np.int32)
+        multi_first = np.zeros(len(multi_row) + 1, np.int64)
+        np.cumsum(multi_count, out=multi_first[1:])
+        seg_slot = np.full(len(seg_row), -1, np.int32)
+        is_multi_seg = multi[seg_row]
+        seg_slot[is_multi_seg] = np.arange(int(is_multi_seg.sum()), dtype=np.int32)
+        # segments of one row are consecutive and seg_ptr[s+1] == seg_ptr of the next segment, except at
+        # row ends where the next row starts exactly where this one stops (CSR) -> one shared array works
+        assert np.array_equal(seg_ptr[1:], seg_hi)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.t = (to(seg_row), to(seg_ptr), to(seg_slot), to(multi_row), to(multi_first[:-1].astype(np.int32)),
+                  to(multi_count))
+        self.c = _lib.SpmmSched(_lib.ptr(self.t[0]), _lib.ptr(self.t[1]), _lib.ptr(self.t[2]), len(seg_row),
+                                _lib.ptr(self.t[3]) if len(multi_row) else None,
+                                _lib.ptr(self.t[4]) if len(multi_row) else None,
+                                _lib.ptr(self.t[5]) if len(multi_row) else None, len(multi_row),
+                                int(multi_first[-1]))
+        self.n_partial = int(multi_first[-1])
+        self.n_seg = len(seg_row)
+        self._ws = {}
+
+    def workspace(self, d: int, device) -> Optional[torch.Tensor]:
+        if self.n_partial == 0:
+            return None
+        if d not in self._ws:
+            self._ws[d] = torch.empty((self.n_partial, d), dtype=torch.float32, device=device)
+        return self._ws[d]
 
 
 def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0,
-             heavy_rows: Optional[torch.Tensor] = None):
+             sched: Optional[SpmmSchedule] = None):
     """P = A @ x; y = P; acc_out = (acc_in*s_in + P)*s_out  (model/LightGCN.py:88-93, fused layer sum)."""
     _need_cuda(rowptr, col, val, x, y, acc_in, acc_out)
     assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
     assert x.dtype == torch.float32 and x.is_contiguous()
     n_rows, d = rowptr.shape[0] - 1, x.shape[1]
+    ws = sched.workspace(d, x.device) if sched is not None else None
     rc = _lib.lib().crh_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                      _lib.ptr(y), _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                     _lib.ptr(heavy_rows), 0 if heavy_rows is None else int(heavy_rows.shape[0]),
+                                     ctypes.byref(sched.c) if sched is not None else None,
+                                     _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0,
                                      _lib.current_stream())
     _lib.check(rc, "crh_spmm_csr_f32")

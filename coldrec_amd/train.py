@@ -73,7 +73,7 @@ class LGCNEngine(_TableState):
         self.col = torch.as_tensor(np.asarray(col, np.int32)).to(dev)
         self.val = torch.as_tensor(np.asarray(val, np.float32)).to(dev)
         assert self.rowptr.shape[0] == self.E.shape[0] + 1
-        self.heavy = ops.heavy_rows_of(np.asarray(rowptr), dev)
+        self.sched = ops.SpmmSchedule(np.asarray(rowptr), dev)
         self.X = [torch.empty_like(self.E) for _ in range(2)]   # layer ping-pong
         self.OUT = torch.empty_like(self.E)                     # mean of the layer outputs
         self.dOUT = torch.zeros_like(self.E)
@@ -85,7 +85,7 @@ class LGCNEngine(_TableState):
             last = k == self.L - 1
             y = None if last else self.X[k & 1]
             ops.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
-                         acc_out=out, s_out=c if last else 1.0, heavy_rows=self.heavy)
+                         acc_out=out, s_out=c if last else 1.0, sched=self.sched)
             x = y
 
     def forward(self):
@@ -103,7 +103,7 @@ class LGCNEngine(_TableState):
         for j in range(self.L):
             dst = self.G if j == self.L - 1 else self.X[j & 1]
             ops.spmm_csr(self.rowptr, self.col, self.val, x, y=None, acc_in=self.dOUT,
-                         s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, heavy_rows=self.heavy)
+                         s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, sched=self.sched)
             x = dst
         self.step_count += 1
         ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False)

@@ -140,15 +140,32 @@ int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0,
  * rowptr (n_rows+1) int64, col int32 ascending per row, val fp32 (util/databuilder.py:220-254,953-962
  * produce exactly this matrix, as COO); x, y, acc_* are (n_rows, d) fp32, d % 4 == 0.
  * acc_out may alias acc_in; outputs must not alias x.
- * heavy_rows (n_heavy int32, may be NULL/0): the rows with more than crh_spmm_heavy_degree() edges,
- * listed once per graph by the caller; each gets a whole workgroup (popular items of a Zipf
- * catalogue have thousands of edges).  Every row with more edges than that MUST be listed when
- * n_heavy > 0; with n_heavy == 0 all rows take the one-lane-group-per-row path.
+ * sched (HOST struct of DEVICE pointers, or NULL): optional load-balancing schedule built once per
+ * graph -- rows cut into segments of at most crh_spmm_segment_edges() edges:
+ *     seg_row[s], seg_ptr[s..s+1] (edge range), seg_slot[s] (-1: the row is in one piece and is
+ *     finished by its segment; >= 0: index of this segment's partial sum), for n_seg segments;
+ *     multi_row[m], multi_first[m], multi_count[m]: the rows with several segments and their
+ *     consecutive partial slots; n_partial = total partial slots.
+ * workspace: crh_spmm_workspace_bytes(sched, d) bytes (0 without schedule).  Without a schedule one
+ * lane group walks each row (bit-identical to the edge-order fma chain).
  */
-int crh_spmm_heavy_degree(void);
+typedef struct {
+    const int32_t* seg_row;
+    const int64_t* seg_ptr;
+    const int32_t* seg_slot;
+    int64_t n_seg;
+    const int32_t* multi_row;
+    const int32_t* multi_first;
+    const int32_t* multi_count;
+    int32_t n_multi;
+    int64_t n_partial;
+} crh_spmm_sched;
+int crh_spmm_segment_edges(void);
+size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d);
 int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                      const float* x, int d, float* y, const float* acc_in, float s_in,
-                     float* acc_out, float s_out, const int32_t* heavy_rows, int n_heavy, void* stream);
+                     float* acc_out, float s_out, const crh_spmm_sched* sched, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /*
  * HOST-side negative sampler reproducing util/utils.py:123-157 (next_batch_pairwise) and NumPy's

@@ -201,8 +201,8 @@ def test_spmm_bit_exact_vs_oracle(d):
     np.testing.assert_allclose(A.cpu().numpy(), (Z * np.float32(0.5) + want) * np.float32(0.25), rtol=1e-6, atol=1e-7)
 
 
-def test_spmm_heavy_rows_and_skew():
-    """Zipf catalogue: a few rows with thousands of edges go through the one-block-per-row kernel."""
+def test_spmm_segment_schedule_on_skewed_graph():
+    """Zipf catalogue: rows with thousands of edges are cut into 64-edge segments and combined."""
     from coldrec_amd import ops
     rng = np.random.default_rng(11)
     n_u, n_i, d = 3000, 500, 64
@@ -211,21 +211,24 @@ def test_spmm_heavy_rows_and_skew():
     key = np.unique(rng.integers(0, n_u, 120_000) * n_i + items)
     rowptr, col, val = orc.norm_adj_csr(key // n_i, key % n_i, n_u, n_i)
     deg = np.diff(rowptr)
-    heavy = ops.heavy_rows_of(rowptr, DEV)
-    assert heavy is not None and deg.max() > 1500 and len(heavy) == (deg > 512).sum()
+    sched = ops.SpmmSchedule(rowptr, DEV)
+    assert deg.max() > 1500 and sched.n_seg == np.maximum(1, -(-deg // 64)).sum()
+    assert sched.n_partial == np.where(deg > 64, -(-deg // 64), 0).sum()
     X = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
-    tX = t(X)
-    Y0, Y1 = torch.empty_like(tX), torch.empty_like(tX)
-    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y0)                       # row kernel only (bit-exact)
-    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y1, heavy_rows=heavy)     # heavy rows by blocks
+    Z = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
+    tX, tZ = t(X), t(Z)
+    Y0, Y1, A1 = torch.empty_like(tX), torch.empty_like(tX), torch.empty_like(tX)
+    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y0)                              # row per lane group
+    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y1, acc_in=tZ, s_in=2.0, acc_out=A1, s_out=0.5, sched=sched)
     want = orc.spmm(rowptr, col, val, X)
     np.testing.assert_array_equal(Y0.cpu().numpy(), want)
-    light = deg <= 512
-    np.testing.assert_array_equal(Y1.cpu().numpy()[light], want[light])
-    np.testing.assert_allclose(Y1.cpu().numpy()[~light], want[~light], rtol=1e-5, atol=1e-6)
+    one = deg <= 64
+    np.testing.assert_array_equal(Y1.cpu().numpy()[one], want[one])                # single segment: same chain
+    np.testing.assert_allclose(Y1.cpu().numpy()[~one], want[~one], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(A1.cpu().numpy(), (Z * 2 + want) * 0.5, rtol=1e-5, atol=1e-6)
     Y2 = torch.empty_like(tX)
-    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y2, heavy_rows=heavy)
-    assert torch.equal(Y1, Y2)                                              # deterministic
+    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y2, sched=sched)
+    assert torch.equal(Y1, Y2)                                                      # deterministic
 
 
 def test_lgcn_forward_golden_g5_and_training():
