@@ -38,10 +38,12 @@ SIGNATURES = {
     "crh_bpr_workspace_bytes": (_sz, [_i64]),
     "crh_bpr_plan_ints": (_i64, [_i64]),
     "crh_bpr_plan_build_host": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "crh_bpr_plan_build": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "crh_bpr_fwd_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _sz, _vp]),
     "crh_adam_dense_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
-                                  _i64, _i32, _vp]),
+                                  _i64, _i32, _vp, _vp]),
+    "crh_adam_step_scalars_host": (None, [_f64, _f64, _f64, _i64, _vp]),
     "crh_spmm_segment_edges": (_i32, []),
     "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),
     "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _sz, _vp]),

@@ -252,6 +252,115 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- plan builder (device)
+// One workgroup per batch sorts the batch's (row << 31 | entry) keys in LDS (bitonic, 64-bit keys) and
+// emits the reverse index in the layout bpr_bwd_rows_kernel reads.  An epoch of S-ML (159 batches of
+// 4096 triples) is one launch of 159 workgroups.
+constexpr int PLAN_THREADS = 256;
+
+__device__ inline void bitonic_sort_lds(unsigned long long* keys, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += PLAN_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool asc = (i & k) == 0;
+                    const unsigned long long x = keys[i], y = keys[ixj];
+                    if ((x > y) == asc) {
+                        keys[i] = y;
+                        keys[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// keys[0..P) sorted, invalid = ~0.  Writes rows[], ptr[], list[] and returns the segment count.
+__device__ inline int plan_emit(const unsigned long long* keys, int P, int32_t* rows, int32_t* ptr, int32_t* list,
+                                int* scan) {
+    const int chunk = (P + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int e0 = threadIdx.x * chunk, e1 = min(e0 + chunk, P);
+    int starts = 0, valid = 0;
+    for (int e = e0; e < e1; ++e) {
+        const unsigned long long kx = keys[e];
+        if (kx == ~0ull) break;
+        ++valid;
+        if (e == 0 || (kx >> 31) != (keys[e - 1] >> 31)) ++starts;
+    }
+    scan[threadIdx.x] = starts;
+    scan[PLAN_THREADS + threadIdx.x] = valid;
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // 256-entry serial scan: negligible next to the sort
+        int acc = 0, tv = 0;
+        for (int i = 0; i < PLAN_THREADS; ++i) {
+            const int c = scan[i];
+            scan[i] = acc;
+            acc += c;
+            tv += scan[PLAN_THREADS + i];
+        }
+        scan[2 * PLAN_THREADS] = acc;
+        scan[2 * PLAN_THREADS + 1] = tv;
+    }
+    __syncthreads();
+    int rank = scan[threadIdx.x];
+    for (int e = e0; e < e1; ++e) {
+        const unsigned long long kx = keys[e];
+        if (kx == ~0ull) break;
+        if (e == 0 || (kx >> 31) != (keys[e - 1] >> 31)) {
+            rows[rank] = (int32_t)(kx >> 31);
+            ptr[rank] = e;
+            ++rank;
+        }
+        list[e] = (int32_t)(kx & 0x7fffffffull);
+    }
+    const int nseg = scan[2 * PLAN_THREADS], nvalid = scan[2 * PLAN_THREADS + 1];
+    if (threadIdx.x == 0) ptr[nseg] = nvalid;
+    __syncthreads();
+    return nseg;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* __restrict__ iu,
+                                                                const int32_t* __restrict__ ip,
+                                                                const int32_t* __restrict__ in_, int64_t n_rec,
+                                                                int L, int P, int32_t* __restrict__ plans,
+                                                                int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    int* scan = reinterpret_cast<int*>(keys + P);
+    const int64_t lo = (int64_t)blockIdx.x * L;
+    const int cnt = (int)((n_rec - lo) < L ? (n_rec - lo) : L);
+    int32_t* pl = plans + (int64_t)blockIdx.x * stride;
+    int32_t* urow = pl + 3;
+    int32_t* uptr = urow + L;
+    int32_t* ulist = uptr + (L + 1);
+    int32_t* irow = ulist + L;
+    int32_t* iptr = irow + 2 * L;
+    int32_t* ilist = iptr + (2 * L + 1);
+
+    for (int e = threadIdx.x; e < P; e += PLAN_THREADS)
+        keys[e] = e < cnt ? (((unsigned long long)(uint32_t)iu[lo + e] << 31) | (unsigned)e) : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    const int nu = plan_emit(keys, P, urow, uptr, ulist, scan);
+
+    for (int e = threadIdx.x; e < P; e += PLAN_THREADS) {
+        unsigned long long kx = ~0ull;
+        if (e < cnt) kx = ((unsigned long long)(uint32_t)ip[lo + e] << 31) | (unsigned)e;
+        else if (e < 2 * cnt) kx = ((unsigned long long)(uint32_t)in_[lo + e - cnt] << 31) | (unsigned)(e - cnt) | (1u << 30);
+        keys[e] = kx;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    const int ni = plan_emit(keys, P, irow, iptr, ilist, scan);
+    if (threadIdx.x == 0) {
+        pl[0] = nu;
+        pl[1] = ni;
+        pl[2] = L;
+    }
+}
+
 // ---------------------------------------------------------------- dense Adam (+ zero the gradient)
 struct AdamSeg {
     float* p;
@@ -263,7 +372,12 @@ struct AdamSeg {
 
 __global__ __launch_bounds__(256) void adam_dense_kernel(AdamSeg s0, AdamSeg s1, float one_minus_b1, float b2,
                                                          float one_minus_b2, float bc2_sqrt, float eps,
-                                                         float neg_step_size, int zero_grad) {
+                                                         float neg_step_size, int zero_grad,
+                                                         const float* __restrict__ step_scalars) {
+    if (step_scalars) {   // step-dependent factors from memory: lets a captured hipGraph be replayed every epoch
+        bc2_sqrt = step_scalars[0];
+        neg_step_size = step_scalars[1];
+    }
     const int64_t total = s0.n4 + s1.n4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -355,6 +469,26 @@ extern "C" int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32
     return CRH_OK;
 }
 
+// Device: plans of every batch of an epoch in one launch (batch_size <= 8192; the sort runs in LDS).
+extern "C" int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                                  int64_t n_records, int64_t batch_size, int32_t* plans_out, void* stream) {
+    CRH_CHECK_ARG(user_idx && pos_idx && neg_idx && plans_out && n_records > 0, "crh_bpr_plan_build: bad arguments");
+    CRH_CHECK_ARG(batch_size >= 1 && batch_size <= 8192, "crh_bpr_plan_build: batch_size=%lld outside 1..8192 "
+                  "(build larger plans with crh_bpr_plan_build_host)", (long long)batch_size);
+    int P = 2;
+    while (P < 2 * batch_size) P <<= 1;
+    const size_t lds = (size_t)P * 8 + (2 * PLAN_THREADS + 2) * sizeof(int);
+    if (lds > 64 * 1024)
+        CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bpr_plan_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t nb = (n_records + batch_size - 1) / batch_size;
+    hipLaunchKernelGGL(bpr_plan_kernel, dim3((unsigned)nb), dim3(PLAN_THREADS), lds,
+                       reinterpret_cast<hipStream_t>(stream), user_idx, pos_idx, neg_idx, n_records, (int)batch_size,
+                       P, plans_out, plan_ints(batch_size));
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
     if (batch <= 0) return 0;
     return (size_t)batch * 4 + (size_t)BPR_MAX_BLOCKS * 16 + 256;
@@ -414,11 +548,13 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
 
 extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0, float* p1, float* g1,
                                   float* m1, float* v1, int64_t n1, double lr, double beta1, double beta2,
-                                  double eps, int64_t step, int zero_grad, void* stream) {
+                                  double eps, int64_t step, int zero_grad, const float* step_scalars,
+                                  void* stream) {
     CRH_CHECK_ARG(p0 && g0 && m0 && v0 && n0 > 0, "crh_adam_dense_f32: NULL / empty first tensor");
     CRH_CHECK_ARG(n1 == 0 || (p1 && g1 && m1 && v1), "crh_adam_dense_f32: NULL second tensor");
     CRH_CHECK_ARG(n0 % 4 == 0 && n1 % 4 == 0, "crh_adam_dense_f32: element counts must be multiples of 4");
-    CRH_CHECK_ARG(step >= 1, "crh_adam_dense_f32: step starts at 1");
+    CRH_CHECK_ARG(step >= 1 || step_scalars, "crh_adam_dense_f32: step starts at 1");
+    if (step < 1) step = 1;
     // scalar factors in double like torch (python floats), then cast
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
@@ -428,7 +564,16 @@ extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, in
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        s0, s1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
-                       (float)(-(lr / bc1)), zero_grad);
+                       (float)(-(lr / bc1)), zero_grad, step_scalars);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
+}
+
+// HOST helper: the two step-dependent Adam factors {sqrt(1-beta2^step), -lr/(1-beta1^step)} exactly as
+// crh_adam_dense_f32 derives them, for callers that keep them in device memory (graph replay).
+extern "C" void crh_adam_step_scalars_host(double lr, double beta1, double beta2, int64_t step, float* out2_host) {
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    out2_host[0] = (float)sqrt(bc2);
+    out2_host[1] = (float)(-(lr / bc1));
 }

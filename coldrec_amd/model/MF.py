@@ -11,8 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
-from ..train import MFEngine
+from ..train import EpochRunner, MFEngine
 from ..util.utils import epoch_triples
 from .BaseRecommender import BaseColdStartTrainer
 
@@ -48,14 +47,12 @@ class MF(BaseColdStartTrainer):
         eng = self.engine = self._make_engine()
         self.timer(start=True)
         epoch = -1
+        runner = EpochRunner(eng, len(self.data.train_u), self.batch_size)
         for epoch in range(self.maxEpoch):
-            u, i, j = (torch.from_numpy(x).to(self.device) for x in epoch_triples(self.data, self.batch_size))
-            plans = ops.build_plans_device(u, i, j, self.batch_size)      # deterministic gradient rows
-            for n, lo in enumerate(range(0, u.shape[0], self.batch_size)):
-                hi = min(lo + self.batch_size, u.shape[0])
-                eng.step(u[lo:hi], i[lo:hi], j[lo:hi], plans[n])
-                if n % 50 == 0:
-                    print('training:', epoch + 1, 'batch', n, 'batch_loss:', eng.last_loss())
+            # one host call samples the epoch, one hipGraph replay trains it; losses come back in bulk
+            losses = runner.run(*epoch_triples(self.data, self.batch_size)).sum(dim=1).cpu().numpy()
+            for n in range(0, len(losses), 50):
+                print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(losses[n]))
             self.user_emb, self.item_emb = eng.forward()
             if epoch % self.eval_every == 0:
                 self.fast_evaluation(epoch, valid_type='all')

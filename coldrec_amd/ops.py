@@ -190,9 +190,22 @@ def build_plans(user_idx, pos_idx, neg_idx, batch_size: int) -> np.ndarray:
 
 def build_plans_device(user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
                        batch_size: int) -> torch.Tensor:
-    """Same plans as ``build_plans`` but assembled on the GPU once per epoch (device-side sort of the
-    epoch's triples batch by batch; pure index plumbing, ~1 ms per epoch at S-ML).  (n_batches, stride)."""
+    """Plans of every batch of an epoch, (n_batches, stride) int32 on the GPU: one launch of
+    crh_bpr_plan_build (LDS sort per batch) for batch_size <= 8192, torch index plumbing above that."""
     _need_cuda(user_idx, pos_idx, neg_idx)
+    if batch_size <= 8192:
+        L = _lib.lib()
+        n_rec = user_idx.numel()
+        nb = (n_rec + batch_size - 1) // batch_size
+        plans = torch.empty((nb, int(L.crh_bpr_plan_ints(batch_size))), dtype=torch.int32, device=user_idx.device)
+        u, p, n = (x.to(torch.int32).contiguous() for x in (user_idx, pos_idx, neg_idx))
+        _lib.check(L.crh_bpr_plan_build(_lib.ptr(u), _lib.ptr(p), _lib.ptr(n), n_rec, int(batch_size),
+                                        _lib.ptr(plans), _lib.current_stream()), "crh_bpr_plan_build")
+        return plans
+    return _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size)
+
+
+def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Tensor:
     dev, L = user_idx.device, int(batch_size)
     n_rec = user_idx.numel()
     nb = (n_rec + L - 1) // L
@@ -238,8 +251,17 @@ def build_plans_device(user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: t
     return plans
 
 
+def adam_step_scalars(first_step: int, n_steps: int, lr: float = 1e-3, betas=(0.9, 0.999)) -> np.ndarray:
+    """(n_steps, 2) float32 host array of the step-dependent Adam factors for steps first_step.."""
+    out = np.empty((n_steps, 2), np.float32)
+    L = _lib.lib()
+    for s in range(n_steps):
+        L.crh_adam_step_scalars_host(float(lr), float(betas[0]), float(betas[1]), first_step + s, out[s].ctypes.data)
+    return out
+
+
 def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-               zero_grad: bool = True, second=None):
+               zero_grad: bool = True, second=None, step_scalars: Optional[torch.Tensor] = None):
     """In-place dense Adam on (p, g, m, v) [and ``second`` = another such 4-tuple] -- model/MF.py:14,27."""
     ts = (p, g, m, v) + (tuple(second) if second else ())
     _need_cuda(*ts)
@@ -251,7 +273,7 @@ def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps:
     rc = _lib.lib().crh_adam_dense_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n0,
                                        _lib.ptr(s[0]), _lib.ptr(s[1]), _lib.ptr(s[2]), _lib.ptr(s[3]), n1,
                                        float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
-                                       1 if zero_grad else 0, _lib.current_stream())
+                                       1 if zero_grad else 0, _lib.ptr(step_scalars), _lib.current_stream())
     _lib.check(rc, "crh_adam_dense_f32")
 
 

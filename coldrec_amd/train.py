@@ -48,14 +48,15 @@ class MFEngine(_TableState):
     """model/MF.py:12-29 with the tables resident on the GPU."""
 
     def step(self, user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
-             plan: Optional[torch.Tensor] = None) -> None:
-        """``plan``: the batch's reverse index (ops.build_plans) -> deterministic gradient rows without
-        atomics; without it gradients are accumulated with fp32 atomics."""
+             plan: Optional[torch.Tensor] = None, loss_out=None, step_scalars=None) -> None:
+        """``plan``: the batch's reverse index (ops.build_plans_device) -> deterministic gradient rows
+        without atomics; without it gradients are accumulated with fp32 atomics."""
         U = self.user_num
         ops.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
-                        self.G[:U], self.G[U:], self.G[U:], self.loss, plan=plan)
+                        self.G[:U], self.G[U:], self.G[U:], self.loss if loss_out is None else loss_out, plan=plan)
         self.step_count += 1
-        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True)
+        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True,
+                       step_scalars=step_scalars)
 
     def forward(self):
         return self.user_emb, self.item_emb
@@ -92,12 +93,14 @@ class LGCNEngine(_TableState):
         self._propagate(self.OUT)
         return self.OUT[: self.user_num], self.OUT[self.user_num:]
 
-    def step(self, user_idx, pos_idx, neg_idx, plan: Optional[torch.Tensor] = None) -> None:
+    def step(self, user_idx, pos_idx, neg_idx, plan: Optional[torch.Tensor] = None, loss_out=None,
+             step_scalars=None) -> None:
         U, c = self.user_num, 1.0 / (self.L + 1)
         self._propagate(self.OUT)
         self.dOUT.zero_()
         ops.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
-                        self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], self.loss, plan=plan)
+                        self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], self.loss if loss_out is None else loss_out,
+                        plan=plan)
         # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
         x = self.dOUT
         for j in range(self.L):
@@ -106,4 +109,61 @@ class LGCNEngine(_TableState):
                          s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, sched=self.sched)
             x = dst
         self.step_count += 1
-        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False)
+        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False,
+                       step_scalars=step_scalars)
+
+
+class EpochRunner:
+    """One epoch of optimiser steps as a replayable hipGraph.
+
+    At MovieLens / CiteULike sizes a step is a handful of 5-30 us kernels, so eager launches (and the
+    Python around them) cost more than the kernels.  The runner owns static device buffers for the
+    epoch's triples, their reverse-index plans, the per-step Adam factors and the per-step losses; the
+    first epoch runs eagerly (warm-up, allocations), the second is captured into a ``torch.cuda.CUDAGraph``
+    (= hipGraph) and every later epoch is one ``replay()`` after the buffers were refreshed.
+    """
+
+    def __init__(self, engine, n_records: int, batch_size: int, use_graph: bool = True):
+        self.eng, self.n, self.B = engine, int(n_records), int(batch_size)
+        dev = engine.device
+        self.steps = [(lo, min(lo + self.B, self.n)) for lo in range(0, self.n, self.B)]
+        self.u, self.i, self.j = (torch.empty(self.n, dtype=torch.int32, device=dev) for _ in range(3))
+        self.plans = None
+        self.scalars = torch.empty((len(self.steps), 2), dtype=torch.float32, device=dev)
+        self.losses = torch.zeros((len(self.steps), 2), dtype=torch.float32, device=dev)
+        self.use_graph, self.graph, self.epochs_done = use_graph, None, 0
+
+    def _all_steps(self):
+        for s, (lo, hi) in enumerate(self.steps):
+            self.eng.step(self.u[lo:hi], self.i[lo:hi], self.j[lo:hi], self.plans[s], self.losses[s], self.scalars[s])
+
+    def run(self, u, i, j) -> torch.Tensor:
+        """Train one epoch on the given triples (host int32 arrays or device tensors); returns the
+        (steps, 2) device tensor of per-step [bpr, l2] losses (valid after the stream is synchronised)."""
+        eng = self.eng
+        for dst, src in ((self.u, u), (self.i, i), (self.j, j)):
+            dst.copy_(torch.as_tensor(src), non_blocking=True)
+        plans = ops.build_plans_device(self.u, self.i, self.j, self.B)
+        if self.plans is None:
+            self.plans = plans
+        else:
+            self.plans.copy_(plans)
+        sc = ops.adam_step_scalars(eng.step_count + 1, len(self.steps), eng.lr)
+        self.scalars.copy_(torch.from_numpy(sc), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+            eng.step_count += len(self.steps)
+        elif self.use_graph and self.epochs_done >= 1:
+            count = eng.step_count
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._all_steps()
+            eng.step_count = count                      # capture launched nothing
+            self.graph = g
+            g.replay()
+            eng.step_count += len(self.steps)
+        else:
+            self._all_steps()
+        self.epochs_done += 1
+        return self.losses

@@ -117,6 +117,10 @@ int64_t crh_bpr_plan_ints(int64_t batch);
 int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx_host,
                             const int32_t* neg_idx_host, int64_t batch, int64_t layout_batch,
                             int32_t* plan_out_host);   /* crh_bpr_plan_ints(layout_batch) ints */
+/* Device version: the plans of all ceil(n_records / batch_size) batches of an epoch in one launch
+ * (LDS bitonic sort per batch; batch_size <= 8192).  plans_out: n_batches * crh_bpr_plan_ints(batch_size). */
+int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                       int64_t n_records, int64_t batch_size, int32_t* plans_out, void* stream);
 int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
                         const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
                         int64_t batch, float reg, float* grad_user, float* grad_pos, float* grad_neg,
@@ -128,11 +132,16 @@ int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const f
  * user table then item table, equal step counters).  Mirrors torch/optim/adam.py
  * _single_tensor_adam op for op; scalar factors are evaluated in double.  step starts at 1.
  * zero_grad != 0 also clears g (the next optimizer.zero_grad()).  n0, n1 multiples of 4; n1 may be 0.
+ * step_scalars (device, 2 floats, or NULL): when given, the step-dependent factors
+ * {sqrt(1-beta2^step), -lr/(1-beta1^step)} are read from memory instead of being derived from
+ * `step`, so that a captured hipGraph of an epoch can be replayed with fresh values
+ * (crh_adam_step_scalars_host computes them on the host).
  */
 int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0,
                        float* p1, float* g1, float* m1, float* v1, int64_t n1,
                        double lr, double beta1, double beta2, double eps, int64_t step, int zero_grad,
-                       void* stream);
+                       const float* step_scalars, void* stream);
+void crh_adam_step_scalars_host(double lr, double beta1, double beta2, int64_t step, float* out2_host);
 
 /*
  * CSR SpMM with the LightGCN layer sum fused (model/LightGCN.py:88-93 and its autograd):

@@ -69,8 +69,10 @@ def test_plan_backward_is_deterministic_and_exact(B, L):
     ni = rng.integers(0, rows + 50, B).astype(np.int32)
     host = ops.build_plans(ui, pi, ni, L)[0]
     devp = ops.build_plans_device(t(ui), t(pi), t(ni), L)
+    devt = ops._build_plans_torch(t(ui), t(pi), t(ni), L)
     for k, v in _plan_views(host).items():
         assert np.array_equal(v, _plan_views(devp[0].cpu().numpy())[k]), k
+        assert np.array_equal(v, _plan_views(devt[0].cpu().numpy())[k]), k
     pv = _plan_views(host)
     assert np.array_equal(pv["urow"], np.unique(ui)) and len(pv["ulist"]) == B and len(pv["ilist"]) == 2 * B
     tU, tV = t(U), t(V)
@@ -87,6 +89,20 @@ def test_plan_backward_is_deterministic_and_exact(B, L):
     np.testing.assert_allclose(outs[0][2].cpu().numpy(), wV, rtol=1e-4, atol=2e-6 * sc)
     untouched = np.setdiff1d(np.arange(rows), ui)
     assert (outs[0][1].cpu().numpy()[untouched] == 0).all()
+
+
+def test_plan_kernel_whole_epoch_with_short_last_batch():
+    from coldrec_amd import ops
+    rng = np.random.default_rng(5)
+    n_rec, L = 10_000, 4096
+    u, p, n = (rng.integers(0, 700, n_rec).astype(np.int32) for _ in range(3))
+    dev = ops.build_plans_device(t(u), t(p), t(n), L).cpu().numpy()
+    host = ops.build_plans(u, p, n, L)
+    assert dev.shape == host.shape == (3, 9 * L + 5)
+    for b in range(3):
+        for k, v in _plan_views(host[b]).items():
+            assert np.array_equal(v, _plan_views(dev[b])[k]), (b, k)
+    assert _plan_views(dev[2])["uptr"][-1] == n_rec - 2 * L
 
 
 @pytest.mark.parametrize("case", ["rand", "reg", "sat"])
@@ -302,3 +318,30 @@ def test_full_size_mf_and_lgcn_steps_vs_oracle():
     ops.spmm_csr(eng.rowptr, eng.col, eng.val, y, y=ay)
     ops.spmm_csr(eng.rowptr, eng.col, eng.val, 2 * x + y, y=axy)
     torch.testing.assert_close(axy, 2 * ax + ay, rtol=1e-4, atol=1e-5)
+
+
+def test_epoch_runner_graph_replay_equals_eager():
+    """Four epochs through EpochRunner (eager, capture, replay, replay) == the same steps issued one by one."""
+    from coldrec_amd.train import EpochRunner, MFEngine, LGCNEngine
+    g = load_golden("g3_mf.npz")
+    rowptr, col, val = _graph()
+    g5 = load_golden("g5_lgcn.npz")
+    rng = np.random.default_rng(0)
+    n, B = 1500, 512
+    for make in (lambda: MFEngine(g["d16_U0"], g["d16_V0"], 1e-3, 1e-4, DEV),
+                 lambda: LGCNEngine(g5["U0"], g5["V0"], rowptr, col, val, 2, 1e-3, 1e-4, DEV)):
+        a, b = make(), make()
+        runner = EpochRunner(a, n, B)
+        for epoch in range(4):
+            u = rng.integers(0, a.user_num, n).astype(np.int32)
+            i = rng.integers(0, a.item_num, n).astype(np.int32)
+            j = rng.integers(0, a.item_num, n).astype(np.int32)
+            losses = runner.run(u, i, j).clone()
+            tu, ti, tj = t(u), t(i), t(j)
+            from coldrec_amd import ops
+            plans = ops.build_plans_device(tu, ti, tj, B)
+            for s, lo in enumerate(range(0, n, B)):
+                b.step(tu[lo:lo + B], ti[lo:lo + B], tj[lo:lo + B], plans[s])
+                assert torch.equal(losses[s], b.loss), (epoch, s)
+        assert runner.graph is not None and a.step_count == b.step_count == 12
+        assert torch.equal(a.E, b.E) and torch.equal(a.M, b.M) and torch.equal(a.V, b.V)
