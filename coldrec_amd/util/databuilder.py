@@ -214,6 +214,23 @@ class ColdStartDataBuilder(object):
         return list(self.training_set_i[i].keys()), list(self.training_set_i[i].values())
 
 
+def bipartite_norm_adj_csr(train_u, train_i, user_num: int, item_num: int):
+    """``norm_adj`` straight from internal-id training pairs (what ``ColdStartDataBuilder`` computes at
+    util/databuilder.py:86-87,220-254), as the (rowptr int64, col int32 ascending, val fp32) arrays
+    crh_spmm_csr_f32 takes.  Same SciPy products as ``normalize_graph_mat`` above."""
+    n = int(user_num) + int(item_num)
+    r = np.asarray(train_u, np.int64)
+    c = np.asarray(train_i, np.int64) + int(user_num)
+    half = sp.csr_matrix((np.ones(r.shape[0], np.float32), (r, c)), shape=(n, n), dtype=np.float32)
+    adj = sp.csr_matrix(half + half.T)
+    rowsum = np.asarray(adj.sum(1)).reshape(-1)
+    d_inv = np.zeros_like(rowsum, dtype=np.float32)
+    np.power(rowsum, -0.5, out=d_inv, where=rowsum != 0)
+    m = sp.csr_matrix(sp.diags(d_inv).dot(adj).dot(sp.diags(d_inv)))
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data.astype(np.float32)
+
+
 class TorchGraphInterface(object):
     """``convert_sparse_mat_to_tensor`` keeps returning what model files pass to
     ``torch.sparse.mm(adj, dense)`` (model/LightGCN.py:76,90) -- a coalesced fp32 COO tensor --
