@@ -41,6 +41,9 @@ SIGNATURES = {
     "crh_bpr_plan_build": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "crh_bpr_fwd_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _sz, _vp]),
+    "crh_bpr_fwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "crh_bpr_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _sz, _vp]),
     "crh_adam_dense_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
                                   _i64, _i32, _vp, _vp]),
     "crh_adam_step_scalars_host": (None, [_f64, _f64, _f64, _i64, _vp]),

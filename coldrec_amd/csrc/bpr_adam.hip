@@ -45,6 +45,10 @@ struct BprArgs {
     float* loss_out;   // [2]: bpr, l2   (may be NULL)
     int nblocks_fwd;
     const int32_t* plan;   // reverse index of the batch (crh_bpr_plan_build_host) or NULL
+    const float* totals;   // [4] batch sums (u^2, p^2, n^2, loss) supplied by the caller -- the data-parallel
+                           // split, where they were all-reduced over the ranks -- or NULL: reduce `partials`
+    float* sums_out;       // [4] forward-only entry point: where bpr_sums_kernel leaves the batch sums
+    int64_t B_global;      // batch size the means / norms refer to (== B unless data-parallel)
 };
 
 template <int G>
@@ -106,19 +110,35 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(BprArgs a) {
     }
 }
 
+// Batch sums for the backward pass: every block reduces the forward partials in the same order ->
+// identical, deterministic totals; in the data-parallel split the caller supplies them (all-reduced).
+__device__ __forceinline__ void batch_totals(const BprArgs& a, float* tot, float* red) {
+    if (a.totals) {
+        if (threadIdx.x < 4) tot[threadIdx.x] = a.totals[threadIdx.x];
+    } else {
+        for (int q = 0; q < 4; ++q) {
+            float s = 0.f;
+            for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) s += a.partials[(size_t)i * 4 + q];
+            s = block_sum(s, red);
+            if (threadIdx.x == 0) tot[q] = s;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BPR_THREADS) void bpr_sums_kernel(BprArgs a) {
+    __shared__ float red[4];
+    __shared__ float tot[4];
+    batch_totals(a, tot, red);
+    if (threadIdx.x < 4) a.sums_out[threadIdx.x] = tot[threadIdx.x];
+}
+
 template <int G>
 __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_kernel(BprArgs a) {
     __shared__ float red[4];
     __shared__ float tot[4];
-    // every block reduces the forward partials in the same order -> identical, deterministic totals
-    for (int q = 0; q < 4; ++q) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) s += a.partials[(size_t)i * 4 + q];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) tot[q] = s;
-    }
-    __syncthreads();
-    const float invB = 1.0f / (float)a.B;
+    batch_totals(a, tot, red);
+    const float invB = 1.0f / (float)a.B_global;
     const float nu = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) {
         a.loss_out[0] = tot[3] * invB;
@@ -178,14 +198,8 @@ template <int G>
 __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a) {
     __shared__ float red[4];
     __shared__ float tot[4];
-    for (int q = 0; q < 4; ++q) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) s += a.partials[(size_t)i * 4 + q];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) tot[q] = s;
-    }
-    __syncthreads();
-    const float invB = 1.0f / (float)a.B;
+    batch_totals(a, tot, red);
+    const float invB = 1.0f / (float)a.B_global;
     const float nu_ = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) {
         a.loss_out[0] = tot[3] * invB;
@@ -494,23 +508,26 @@ extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
     return (size_t)batch * 4 + (size_t)BPR_MAX_BLOCKS * 16 + 256;
 }
 
-extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table,
-                                   int d, const int32_t* user_idx, const int32_t* pos_idx,
-                                   const int32_t* neg_idx, int64_t batch, float reg, float* grad_user,
-                                   float* grad_pos, float* grad_neg, float* loss_out, const int32_t* plan,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-    CRH_CHECK_ARG(user_table && pos_table && neg_table, "crh_bpr_fwd_bwd_f32: NULL table");
-    CRH_CHECK_ARG(batch > 0, "crh_bpr_fwd_bwd_f32: empty batch");
-    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_bpr_fwd_bwd_f32: d=%d must be a positive multiple of 4", d);
+namespace {
+
+// phases: 1 = forward (partials + xbuf), 2 = backward (needs the xbuf of a forward over the same workspace)
+int bpr_launch(int phases, const float* user_table, const float* pos_table, const float* neg_table, int d,
+               const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx, int64_t batch,
+               int64_t global_batch, float reg, float* grad_user, float* grad_pos, float* grad_neg,
+               float* loss_out, const int32_t* plan, const float* totals, float* sums_out, void* workspace,
+               size_t workspace_bytes, void* stream, const char* who) {
+    CRH_CHECK_ARG(user_table && pos_table && neg_table, "%s: NULL table", who);
+    CRH_CHECK_ARG(batch > 0 && global_batch >= batch, "%s: empty batch / global batch smaller than the local one", who);
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "%s: d=%d must be a positive multiple of 4", who, d);
     CRH_CHECK_ARG((grad_user == nullptr) == (grad_pos == nullptr) && (grad_pos == nullptr) == (grad_neg == nullptr),
-                  "crh_bpr_fwd_bwd_f32: give all three gradient tables or none");
+                  "%s: give all three gradient tables or none", who);
     CRH_CHECK_ARG((((uintptr_t)user_table | (uintptr_t)pos_table | (uintptr_t)neg_table | (uintptr_t)grad_user |
                     (uintptr_t)grad_pos | (uintptr_t)grad_neg) & 15) == 0,
-                  "crh_bpr_fwd_bwd_f32: tables must be 16-byte aligned");
+                  "%s: tables must be 16-byte aligned", who);
     CRH_CHECK_ARG(!plan || (grad_user && user_idx && pos_idx && neg_idx && grad_pos == grad_neg && pos_table == neg_table),
-                  "crh_bpr_fwd_bwd_f32: a plan needs index arrays, gradient tables and one shared item table");
+                  "%s: a plan needs index arrays, gradient tables and one shared item table", who);
     if (!workspace || workspace_bytes < crh_bpr_workspace_bytes(batch)) {
-        crh_set_error("crh_bpr_fwd_bwd_f32: workspace %zu < %zu bytes", workspace_bytes, crh_bpr_workspace_bytes(batch));
+        crh_set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, crh_bpr_workspace_bytes(batch));
         return CRH_ERR_WS;
     }
     BprArgs a;
@@ -522,6 +539,9 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
     a.xbuf = a.partials + (size_t)BPR_MAX_BLOCKS * 4;
     a.loss_out = loss_out;
     a.plan = plan;
+    a.totals = totals;
+    a.sums_out = sums_out;
+    a.B_global = global_batch;
     const int G = pick_group(d);
     const int64_t per_block = BPR_THREADS / G;
     int64_t blocks = (batch + per_block - 1) / per_block;
@@ -530,8 +550,17 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dispatch_group(G, [&](auto gc) -> int {
         constexpr int GG = decltype(gc)::value;
-        hipLaunchKernelGGL(bpr_fwd_kernel<GG>, dim3((unsigned)blocks), dim3(BPR_THREADS), 0, st, a);
-        CRH_HIP(hipGetLastError());
+        if (phases & 1) {
+            hipLaunchKernelGGL(bpr_fwd_kernel<GG>, dim3((unsigned)blocks), dim3(BPR_THREADS), 0, st, a);
+            CRH_HIP(hipGetLastError());
+            if (sums_out) {
+                BprArgs r = a;
+                r.totals = nullptr;
+                hipLaunchKernelGGL(bpr_sums_kernel, dim3(1), dim3(BPR_THREADS), 0, st, r);
+                CRH_HIP(hipGetLastError());
+            }
+        }
+        if (!(phases & 2)) return CRH_OK;
         const unsigned bwd_blocks = (grad_user || loss_out) ? (grad_user ? (unsigned)blocks : 1u) : 0u;
         if (plan) {
             int64_t rb = (3 * batch + per_block - 1) / per_block;      // <= 3B touched rows
@@ -544,6 +573,41 @@ extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_tab
         }
         return CRH_OK;
     });
+}
+
+}  // namespace
+
+extern "C" int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table,
+                                   int d, const int32_t* user_idx, const int32_t* pos_idx,
+                                   const int32_t* neg_idx, int64_t batch, float reg, float* grad_user,
+                                   float* grad_pos, float* grad_neg, float* loss_out, const int32_t* plan,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return bpr_launch(3, user_table, pos_table, neg_table, d, user_idx, pos_idx, neg_idx, batch, batch, reg,
+                      grad_user, grad_pos, grad_neg, loss_out, plan, nullptr, nullptr, workspace, workspace_bytes,
+                      stream, "crh_bpr_fwd_bwd_f32");
+}
+
+// Data-parallel split: forward over the rank's slice -> sums_out[4]; the caller all-reduces
+// them; backward over the same slice with the global sums and the global batch size.
+extern "C" int crh_bpr_fwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
+                               const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                               int64_t batch, float* sums_out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    CRH_CHECK_ARG(sums_out, "crh_bpr_fwd_f32: NULL sums_out");
+    return bpr_launch(1, user_table, pos_table, neg_table, d, user_idx, pos_idx, neg_idx, batch, batch, 0.f,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sums_out, workspace, workspace_bytes,
+                      stream, "crh_bpr_fwd_f32");
+}
+
+extern "C" int crh_bpr_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
+                               const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                               int64_t batch, int64_t global_batch, float reg, const float* sums,
+                               float* grad_user, float* grad_pos, float* grad_neg, float* loss_out,
+                               const int32_t* plan, void* workspace, size_t workspace_bytes, void* stream) {
+    CRH_CHECK_ARG(sums, "crh_bpr_bwd_f32: NULL sums");
+    return bpr_launch(2, user_table, pos_table, neg_table, d, user_idx, pos_idx, neg_idx, batch, global_batch, reg,
+                      grad_user, grad_pos, grad_neg, loss_out, plan, sums, nullptr, workspace, workspace_bytes,
+                      stream, "crh_bpr_bwd_f32");
 }
 
 extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0, float* p1, float* g1,

@@ -150,6 +150,17 @@ def main(argv=None):
         out = write_dataset(make_dataset(args.make_synthetic, args.cold_object), args.data_root, args.dataset)
         print('synthetic dataset written to', out)
         return None
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        # (addition) launched by torch.distributed.run, one rank per GPU of the node: training is
+        # data-parallel and evaluation item-row-sharded over RCCL (coldrec_amd/train.py, eval.py);
+        # every rank computes the same metrics, rank 0 alone writes the result file and the tables
+        import torch.distributed as dist
+        args.gpu_id = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(args.gpu_id)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', args.gpu_id))
+        if dist.get_rank() != 0:
+            args.save_emb = False
     config = Config(args, args.data_root)
     top_ns = args.topN.split(',')
     results = {s: {m: [[] for _ in top_ns] for m in METRICS} for _, s in SETTINGS}
@@ -167,6 +178,13 @@ def main(argv=None):
                     results[key][m][i].append(res[i][q])
         done = int(getattr(model, 'epochs_ran', 0) or 0) or (args.epochs if args.epochs > 0 else 1)
         time_results.append((model.train_end_time - model.train_start_time) / done)
+    if world > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return None
     return summarise(results, top_ns, time_results, args)
 
 

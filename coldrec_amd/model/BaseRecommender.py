@@ -25,6 +25,8 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..eval import ShardedTopK, shard_bounds
+from ..train import dp_from_env
 from ..util.evaluator import format_measure, ranking_metrics, truth_csr
 
 _STOCK_PREDICT = re.compile(
@@ -136,8 +138,15 @@ class BaseColdStartTrainer(ABC):
         ue, ie = getattr(self, 'user_emb', None), getattr(self, 'item_emb', None)
         fused = fused and torch.is_tensor(ue) and torch.is_tensor(ie) and ue.is_cuda and ue.dim() == 2
         if fused:
-            s, i = ops.score_topk(ue.detach().float(), c['users_int'], ie.detach().float(), self.max_N,
-                                  c['rated_rowptr'], c['rated_col'], c['bitmap'])
+            dp = dp_from_env()
+            if dp is None:
+                s, i = ops.score_topk(ue.detach().float(), c['users_int'], ie.detach().float(), self.max_N,
+                                      c['rated_rowptr'], c['rated_col'], c['bitmap'])
+            else:                     # item rows sharded over the ranks, all-gather + canonical merge
+                lo, hi = shard_bounds(ie.shape[0], dp.world, dp.rank)
+                eng = ShardedTopK(ie.detach().float()[lo:hi].contiguous(), lo, ie.shape[0], self.max_N,
+                                  dp.world, dp.rank)
+                s, i = eng.topk(ue.detach().float(), c['users_int'], c['rated_rowptr'], c['rated_col'], c['bitmap'])
         else:
             parts_s, parts_i = [], []
             for lo in range(0, len(c['users']), self.batch_size):

@@ -11,7 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..train import EpochRunner, MFEngine
+from ..train import EpochRunner, MFEngine, dp_from_env
 from ..util.utils import epoch_triples
 from .BaseRecommender import BaseColdStartTrainer
 
@@ -47,7 +47,11 @@ class MF(BaseColdStartTrainer):
         eng = self.engine = self._make_engine()
         self.timer(start=True)
         epoch = -1
-        runner = EpochRunner(eng, len(self.data.train_u), self.batch_size)
+        dp = dp_from_env()            # one rank per GPU: shard every batch, all-reduce sums + gradient
+        if dp is not None:
+            eng.enable_data_parallel(dp)
+        # collectives are kept out of graph capture: the data-parallel epoch is launched eagerly
+        runner = EpochRunner(eng, len(self.data.train_u), self.batch_size, use_graph=dp is None)
         for epoch in range(self.maxEpoch):
             # one host call samples the epoch, one hipGraph replay trains it; losses come back in bulk
             losses = runner.run(*epoch_triples(self.data, self.batch_size)).sum(dim=1).cpu().numpy()

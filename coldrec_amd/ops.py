@@ -171,6 +171,54 @@ def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, re
     return loss_out
 
 
+def _bpr_checks(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx):
+    d = user_table.shape[1]
+    batch = user_idx.shape[0] if user_idx is not None else user_table.shape[0]
+    for t in (user_table, pos_table, neg_table):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == d
+    for ix in (user_idx, pos_idx, neg_idx):
+        assert ix is None or (ix.dtype == torch.int32 and ix.is_contiguous() and ix.shape[0] == batch)
+    return d, batch
+
+
+def bpr_fwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, sums_out: torch.Tensor,
+            workspace: torch.Tensor):
+    """Forward of one rank's slice of the batch (data-parallel split): ``sums_out`` (4 floats, device)
+    = [sum u^2, sum p^2, sum n^2, sum -log(1e-5+sigmoid(x))] of the slice.  ``workspace``: uint8 tensor of
+    ``bpr_workspace_bytes(batch)`` that must be handed to ``bpr_bwd`` unchanged."""
+    _need_cuda(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, sums_out, workspace)
+    d, batch = _bpr_checks(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx)
+    assert sums_out.dtype == torch.float32 and sums_out.numel() >= 4
+    rc = _lib.lib().crh_bpr_fwd_f32(_lib.ptr(user_table), _lib.ptr(pos_table), _lib.ptr(neg_table), d,
+                                    _lib.ptr(user_idx), _lib.ptr(pos_idx), _lib.ptr(neg_idx), batch,
+                                    _lib.ptr(sums_out), _lib.ptr(workspace), workspace.numel(),
+                                    _lib.current_stream())
+    _lib.check(rc, "crh_bpr_fwd_f32")
+    return sums_out
+
+
+def bpr_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, global_batch: int, reg: float,
+            sums: torch.Tensor, grad_user, grad_pos, grad_neg, loss_out: Optional[torch.Tensor],
+            workspace: torch.Tensor, plan: Optional[torch.Tensor] = None):
+    """Backward of one rank's slice with the all-reduced ``sums`` and the global batch size."""
+    _need_cuda(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, sums, grad_user, grad_pos, grad_neg,
+               workspace)
+    d, batch = _bpr_checks(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx)
+    rc = _lib.lib().crh_bpr_bwd_f32(_lib.ptr(user_table), _lib.ptr(pos_table), _lib.ptr(neg_table), d,
+                                    _lib.ptr(user_idx), _lib.ptr(pos_idx), _lib.ptr(neg_idx), batch,
+                                    int(global_batch), float(reg), _lib.ptr(sums), _lib.ptr(grad_user),
+                                    _lib.ptr(grad_pos), _lib.ptr(grad_neg), _lib.ptr(loss_out), _lib.ptr(plan),
+                                    _lib.ptr(workspace), workspace.numel(), _lib.current_stream())
+    _lib.check(rc, "crh_bpr_bwd_f32")
+    return loss_out
+
+
+def bpr_workspace(batch: int, device) -> torch.Tensor:
+    """A private scratch buffer for a bpr_fwd / bpr_bwd pair (the shared grow-only workspace may be
+    reused by other ops between the two calls)."""
+    return torch.empty(int(_lib.lib().crh_bpr_workspace_bytes(int(batch))), dtype=torch.uint8, device=device)
+
+
 def build_plans(user_idx, pos_idx, neg_idx, batch_size: int) -> np.ndarray:
     """Host: reverse indices ("plans") for every batch of an epoch of triples (int32 numpy arrays as the
     sampler returns them).  Row b of the result is the plan of batch b (last batch: its own size)."""

@@ -16,8 +16,63 @@ import torch
 from . import ops
 
 
+class DPContext:
+    """Data-parallel training over the GPUs of one node: tables and Adam state are
+    replicated, every rank sees the same global batch (one host sampler stream) and works on the slice
+    [rank*B/G, (rank+1)*B/G).  Two exchanges per optimiser step, both RCCL all-reduce(sum) on the
+    compute stream: the 4 batch sums the backward pass needs (16 bytes) and the dense gradient table.
+    Every replica then applies the identical dense Adam update, so the replicas never diverge and the
+    result equals the single-GPU step up to fp32 addition order."""
+
+    def __init__(self, world: int, rank: int, group=None):
+        assert 0 <= rank < world
+        self.world, self.rank, self.group = int(world), int(rank), group
+
+    def slice(self, n: int):
+        return self.rank * n // self.world, (self.rank + 1) * n // self.world
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def dp_from_env() -> Optional[DPContext]:
+    """The DPContext of this process when it was launched one-rank-per-GPU (torch.distributed initialised,
+    world size > 1), else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return DPContext(dist.get_world_size(), dist.get_rank())
+    return None
+
+
 class _TableState:
-    def __init__(self, user0, item0, lr: float, reg: float, device):
+    dp: Optional[DPContext] = None
+
+    def enable_data_parallel(self, dp: DPContext) -> None:
+        self.dp = dp
+        self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._bpr_ws = None
+
+    def _dp_loss_grad(self, tu, tp, user_idx, pos_idx, neg_idx, gu, gp, loss_out) -> None:
+        """Slice forward -> all-reduce(4 sums) -> slice backward (atomics) into the local gradient."""
+        B = user_idx.shape[0]
+        lo, hi = self.dp.slice(B)
+        if self._bpr_ws is None or self._bpr_cap < hi - lo:
+            self._bpr_cap = max(hi - lo, 1)
+            self._bpr_ws = self.k.bpr_workspace(self._bpr_cap, self.device)
+        u, p, n = user_idx[lo:hi], pos_idx[lo:hi], neg_idx[lo:hi]
+        if hi > lo:
+            self.k.bpr_fwd(tu, tp, tp, u, p, n, self.sums, self._bpr_ws)
+        else:
+            self.sums.zero_()
+        self.dp.all_reduce(self.sums)
+        if hi > lo:
+            self.k.bpr_bwd(tu, tp, tp, u, p, n, B, self.reg, self.sums, gu, gp, gp, loss_out, self._bpr_ws)
+
+    def __init__(self, user0, item0, lr: float, reg: float, device, kernels=None):
+        # ``kernels``: injectable for the CPU (gloo) plumbing tests only; the product path is coldrec_amd.ops
+        self.k = kernels or ops
         u = torch.as_tensor(np.asarray(user0, np.float32) if not torch.is_tensor(user0) else user0.detach().float())
         v = torch.as_tensor(np.asarray(item0, np.float32) if not torch.is_tensor(item0) else item0.detach().float())
         assert u.shape[1] == v.shape[1] and u.shape[1] % 4 == 0, "embedding width must be a multiple of 4"
@@ -52,11 +107,16 @@ class MFEngine(_TableState):
         """``plan``: the batch's reverse index (ops.build_plans_device) -> deterministic gradient rows
         without atomics; without it gradients are accumulated with fp32 atomics."""
         U = self.user_num
-        ops.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
-                        self.G[:U], self.G[U:], self.G[U:], self.loss if loss_out is None else loss_out, plan=plan)
+        loss = self.loss if loss_out is None else loss_out
+        if self.dp is not None:
+            self._dp_loss_grad(self.E[:U], self.E[U:], user_idx, pos_idx, neg_idx, self.G[:U], self.G[U:], loss)
+            self.dp.all_reduce(self.G)
+        else:
+            self.k.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
+                               self.G[:U], self.G[U:], self.G[U:], loss, plan=plan)
         self.step_count += 1
-        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True,
-                       step_scalars=step_scalars)
+        self.k.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True,
+                          step_scalars=step_scalars)
 
     def forward(self):
         return self.user_emb, self.item_emb
@@ -65,8 +125,8 @@ class MFEngine(_TableState):
 class LGCNEngine(_TableState):
     """model/LightGCN.py:14-29,86-96: full-graph L-layer propagation per batch and its backward."""
 
-    def __init__(self, user0, item0, rowptr, col, val, n_layers: int, lr: float, reg: float, device):
-        super().__init__(user0, item0, lr, reg, device)
+    def __init__(self, user0, item0, rowptr, col, val, n_layers: int, lr: float, reg: float, device, kernels=None):
+        super().__init__(user0, item0, lr, reg, device, kernels)
         assert n_layers >= 1
         self.L = int(n_layers)
         dev = self.device
@@ -74,7 +134,7 @@ class LGCNEngine(_TableState):
         self.col = torch.as_tensor(np.asarray(col, np.int32)).to(dev)
         self.val = torch.as_tensor(np.asarray(val, np.float32)).to(dev)
         assert self.rowptr.shape[0] == self.E.shape[0] + 1
-        self.sched = ops.SpmmSchedule(np.asarray(rowptr), dev)
+        self.sched = self.k.SpmmSchedule(np.asarray(rowptr), dev)
         self.X = [torch.empty_like(self.E) for _ in range(2)]   # layer ping-pong
         self.OUT = torch.empty_like(self.E)                     # mean of the layer outputs
         self.dOUT = torch.zeros_like(self.E)
@@ -85,8 +145,8 @@ class LGCNEngine(_TableState):
         for k in range(self.L):
             last = k == self.L - 1
             y = None if last else self.X[k & 1]
-            ops.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
-                         acc_out=out, s_out=c if last else 1.0, sched=self.sched)
+            self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
+                            acc_out=out, s_out=c if last else 1.0, sched=self.sched)
             x = y
 
     def forward(self):
@@ -98,19 +158,26 @@ class LGCNEngine(_TableState):
         U, c = self.user_num, 1.0 / (self.L + 1)
         self._propagate(self.OUT)
         self.dOUT.zero_()
-        ops.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
-                        self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], self.loss if loss_out is None else loss_out,
-                        plan=plan)
+        loss = self.loss if loss_out is None else loss_out
+        if self.dp is not None:
+            # propagation is replicated; only the loss/gradient of the batch is sharded, and the exchange
+            # happens on dOUT so the backward SpMMs run on identical inputs everywhere
+            self._dp_loss_grad(self.OUT[:U], self.OUT[U:], user_idx, pos_idx, neg_idx, self.dOUT[:U], self.dOUT[U:],
+                               loss)
+            self.dp.all_reduce(self.dOUT)
+        else:
+            self.k.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
+                               self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], loss, plan=plan)
         # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
         x = self.dOUT
         for j in range(self.L):
             dst = self.G if j == self.L - 1 else self.X[j & 1]
-            ops.spmm_csr(self.rowptr, self.col, self.val, x, y=None, acc_in=self.dOUT,
-                         s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, sched=self.sched)
+            self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=None, acc_in=self.dOUT,
+                            s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, sched=self.sched)
             x = dst
         self.step_count += 1
-        ops.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False,
-                       step_scalars=step_scalars)
+        self.k.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False,
+                          step_scalars=step_scalars)
 
 
 class EpochRunner:

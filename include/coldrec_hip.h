@@ -128,6 +128,25 @@ int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const f
                         void* stream);
 
 /*
+ * The same step split for data-parallel training (the batch is sharded over the ranks,
+ * tables replicated).  l2_reg_loss (util/utils.py:44-48) uses the Frobenius norm of the WHOLE gathered
+ * batch and bpr_loss (util/utils.py:25-29) its mean, so the backward pass of a slice needs four sums over
+ * all slices.  crh_bpr_fwd_f32 runs the forward over this rank's `batch` triples and leaves
+ * sums_out[4] = {sum u^2, sum p^2, sum n^2, sum -log(1e-5+sigmoid(x))} (device); the caller all-reduces
+ * them (RCCL, 16 bytes); crh_bpr_bwd_f32 then accumulates / stores this slice's gradient rows using the
+ * global sums and `global_batch`, and writes loss_out = the GLOBAL [bpr, l2].  `workspace` must be the
+ * buffer the forward of the same slice used (it carries the per-triple score differences).
+ */
+int crh_bpr_fwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
+                    const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx, int64_t batch,
+                    float* sums_out, void* workspace, size_t workspace_bytes, void* stream);
+int crh_bpr_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
+                    const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx, int64_t batch,
+                    int64_t global_batch, float reg, const float* sums, float* grad_user, float* grad_pos,
+                    float* grad_neg, float* loss_out, const int32_t* plan, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/*
  * torch.optim.Adam(lr) defaults, dense, for up to two tensors in one launch (model/MF.py:14,27:
  * user table then item table, equal step counters).  Mirrors torch/optim/adam.py
  * _single_tensor_adam op for op; scalar factors are evaluated in double.  step starts at 1.

@@ -345,3 +345,62 @@ def test_epoch_runner_graph_replay_equals_eager():
                 assert torch.equal(losses[s], b.loss), (epoch, s)
         assert runner.graph is not None and a.step_count == b.step_count == 12
         assert torch.equal(a.E, b.E) and torch.equal(a.M, b.M) and torch.equal(a.V, b.V)
+
+
+@pytest.mark.parametrize("d,B,cuts", [(128, 4096, (0, 2048, 4096)), (64, 1001, (0, 125, 250, 500, 501, 1001)),
+                                      (16, 7, (0, 3, 7))])
+def test_bpr_split_fwd_bwd_equals_fused(d, B, cuts):
+    """Data-parallel split (crh_bpr_fwd_f32 / crh_bpr_bwd_f32): per-slice forwards, summed batch sums (what the
+    RCCL all-reduce produces), per-slice backwards with the global batch size == the fused single-call step."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(B + d)
+    rows = 500
+    U = (rng.standard_normal((rows, d)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((rows + 9, d)) * 0.3).astype(np.float32)
+    ui, pi, ni = (rng.integers(0, n, B).astype(np.int32) for n in (rows, rows + 9, rows + 9))
+    reg = 0.02
+    tU, tV, tu, tp, tn = t(U), t(V), t(ui), t(pi), t(ni)
+    want_loss, wU, wV = _bpr_gpu(U, V, ui, pi, ni, reg)
+    slices = list(zip(cuts[:-1], cuts[1:]))
+    wss = [ops.bpr_workspace(hi - lo, DEV) for lo, hi in slices]
+    sums = [torch.zeros(4, device=DEV) for _ in slices]
+    for (lo, hi), ws, s in zip(slices, wss, sums):
+        ops.bpr_fwd(tU, tV, tV, tu[lo:hi], tp[lo:hi], tn[lo:hi], s, ws)
+    total = torch.stack(sums).sum(0)
+    gU, gV = torch.zeros_like(tU), torch.zeros_like(tV)
+    loss = torch.zeros(2, device=DEV)
+    for (lo, hi), ws in zip(slices, wss):
+        ops.bpr_bwd(tU, tV, tV, tu[lo:hi], tp[lo:hi], tn[lo:hi], B, reg, total, gU, gV, gV, loss, ws)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss.cpu().numpy(), want_loss, rtol=1e-5)
+    sc = max(np.abs(wU).max(), np.abs(wV).max())
+    np.testing.assert_allclose(gU.cpu().numpy(), wU, rtol=1e-4, atol=2e-6 * sc)
+    np.testing.assert_allclose(gV.cpu().numpy(), wV, rtol=1e-4, atol=2e-6 * sc)
+    bpr, l2, oU, oV, _ = orc.bpr_l2_fwd_bwd(U, V, ui, pi, ni, reg)
+    np.testing.assert_allclose(loss.cpu().numpy(), [bpr, l2], rtol=1e-5)
+    np.testing.assert_allclose(gU.cpu().numpy(), oU, rtol=1e-4, atol=2e-6 * sc)
+
+
+def test_dp_engines_world1_match_plain_engines():
+    """The data-parallel step (slice fwd -> all-reduce -> slice bwd -> all-reduce(grad) -> Adam) at world size 1
+    runs the split HIP entry points; it must match the fused step (1e-5 on losses and table norms)."""
+    from coldrec_amd.train import DPContext, LGCNEngine, MFEngine
+    from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
+    rng = np.random.default_rng(11)
+    n_u, n_i, d, B = 300, 500, 64, 512
+    U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
+    pairs = np.unique(np.stack([rng.integers(0, n_u, 4000), rng.integers(0, n_i - 20, 4000)], 1), axis=0)
+    rowptr, col, val = bipartite_norm_adj_csr(pairs[:, 0], pairs[:, 1], n_u, n_i)
+    tri = [tuple(t(rng.integers(0, n, B).astype(np.int32)) for n in (n_u, n_i, n_i)) for _ in range(5)]
+    for make in (lambda: MFEngine(U0, V0, 1e-2, 1e-3, DEV),
+                 lambda: LGCNEngine(U0, V0, rowptr, col, val, 3, 1e-2, 1e-3, DEV)):
+        a, b = make(), make()
+        b.enable_data_parallel(DPContext(1, 0))
+        for u, i, j in tri:
+            a.step(u, i, j)
+            b.step(u, i, j)
+            np.testing.assert_allclose(b.last_loss(), a.last_loss(), rtol=1e-5)
+        na, nb = float(a.E.norm()), float(b.E.norm())
+        assert abs(na - nb) <= 1e-5 * na
+        assert float((a.E - b.E).norm()) <= 1e-4 * na
