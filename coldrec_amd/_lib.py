@@ -29,6 +29,7 @@ SIGNATURES = {
     "crh_version": (_i32, []),
     "crh_score_topk_supports_dim": (_i32, [_i32]),
     "crh_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "crh_score_topk_min_workspace_bytes": (_sz, [_i64, _i32]),
     "crh_score_topk_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
                                   _vp, _sz, _vp]),
     "crh_score_topk_f32_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,

@@ -38,6 +38,7 @@ struct ScoreArgs {
     const int32_t* users;
     int64_t n_users;
     const float* item_emb;
+    const float* packed;   // item tiles in MFMA-fragment order (pack_items_kernel), or NULL
     int64_t n_items;
     const int64_t* rated_rowptr;
     const int32_t* rated_col;
@@ -71,17 +72,50 @@ __device__ __forceinline__ void chunk_swap(f32x4& cf) {
 
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// Item table -> fragment order.  Tile t = rows [32t, 32t+32) (rows past the end repeat the last row),
+// chunk q = k in [8q, 8q+8):   packed[((t*NCH + q)*64 + h*32 + i)*4 + c] = V[32t + i][8q + 2*j(c) + h],
+// j(x,y,z,w) = 0,2,1,3 -- exactly the f32x4 (chunk_swap's output order) lane (i,h) feeds to the four
+// 32x32x2 MFMAs of chunk q (k = 8q+2j in the low half-wave, 8q+2j+1 in the high one), so the scoring loop issues one fully coalesced 1 KiB load per
+// chunk and no cross-lane swaps (measured: the two v_permlane32_swap per chunk cost ~9 % of the MFMA
+// rate, the 32-B-per-row gather another ~4 %).  One workgroup per tile, staged through LDS.
+template <int D>
+__global__ __launch_bounds__(256) void pack_items_kernel(const float* __restrict__ v, int64_t n_items,
+                                                         float* __restrict__ packed) {
+    constexpr int NCH = D / 8;
+    __shared__ float tile[32][D + 4];
+    const int64_t t = blockIdx.x;
+    for (int e = threadIdx.x; e < 32 * (D / 4); e += 256) {
+        const int r = e / (D / 4), c = e % (D / 4);
+        int64_t row = (t << 5) + r;
+        if (row >= n_items) row = n_items - 1;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(v + row * D + 4 * c);
+        tile[r][4 * c + 0] = x.x; tile[r][4 * c + 1] = x.y; tile[r][4 * c + 2] = x.z; tile[r][4 * c + 3] = x.w;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NCH * 64; e += 256) {
+        const int q = e >> 6, ln = e & 63, i = ln & 31, h = ln >> 5;
+        f32x4 o;
+        o.x = tile[i][8 * q + 0 + h];   // same component order as chunk_swap's output: the MFMAs are
+        o.z = tile[i][8 * q + 2 + h];   // issued .x, .z, .y, .w = k pairs (0,1) (2,3) (4,5) (6,7)
+        o.y = tile[i][8 * q + 4 + h];
+        o.w = tile[i][8 * q + 6 + h];
+        *reinterpret_cast<f32x4*>(packed + ((t * NCH) * 64 + e) * 4) = o;
+    }
+}
+
 template <int UPW>
 struct WaveLds {
     float* ls;       // [UPW][K]
     int* li;         // [UPW][K]
     int* cnt;        // [UPW]
     float* scratch;  // [16][64]
+    int64_t* rlo;    // [UPW] bounds of each user's rated list (rated_rowptr staged once per wave)
+    int64_t* rhi;    // [UPW]
 };
 
 template <int UPW>
 __host__ __device__ constexpr size_t wave_lds_bytes(int K) {
-    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + 16 * 64 * 4;
+    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + 16 * 64 * 4 + (size_t)UPW * 16;
 }
 
 // Slow path for one 32x32 accumulator tile (rare).  acc[r] = score of item row
@@ -117,7 +151,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
             const int gi = (int)(a.item_base + il);
             const int n = __builtin_amdgcn_readfirstlane(w.cnt[ul]);
             if (wave_list_rejects(lsu, liu, n, K, sc, gi)) continue;
-            if (wave_is_masked(gi, slot, a.rated_rowptr, a.rated_col, a.bitmap, lane)) sc = CRH_MASKED_SCORE;
+            if (wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, a.bitmap, lane)) sc = CRH_MASKED_SCORE;
             wave_list_insert(lsu, liu, w.cnt + ul, K, sc, gi, lane);
         }
     }
@@ -129,7 +163,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
 //   1: two register tiles (A double-buffered), ~320 VGPR+AGPR, one wave per SIMD;
 //   2: one register tile reloaded chunk by chunk right behind its last use, <= 256 registers, so a
 //      second wave on the SIMD fills the matrix pipe while this one selects / waits / inserts.
-template <int D, int UW, int OCC>
+template <int D, int UW, int OCC, bool PK>
 __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     constexpr int WPW = 1;
     constexpr int NCH = D / 8;
@@ -153,8 +187,16 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         w.li = reinterpret_cast<int*>(w.ls + UPW * K);
         w.cnt = w.li + UPW * K;
         w.scratch = reinterpret_cast<float*>(w.cnt + UPW);
+        w.rlo = reinterpret_cast<int64_t*>(w.scratch + 16 * 64);
+        w.rhi = w.rlo + UPW;
     }
-    for (int j = lane; j < UPW; j += 64) w.cnt[j] = 0;
+    for (int j = lane; j < UPW; j += 64) {
+        w.cnt[j] = 0;
+        const int64_t slot = ug * UPW + j;
+        const bool has = a.rated_rowptr && slot < a.n_users;
+        w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
+        w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
+    }
 
     // ---- hot user block -> registers (B fragments, already pair-swapped)
     f32x4 b[UW][NCH];
@@ -181,12 +223,25 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     // Two register tiles: while tile t is multiplied out of one, tile t+1 lands in the other
     // (issued a whole tile = NCH*4*UW MFMAs ahead, pinned there by sched_barrier; left to
     // itself hipcc sinks the loads behind the MFMAs and waits vmcnt(0) at the loop head).
+    // address of this lane's first 16 B of tile t: row-major table -> row (t*32 + i), k offset 4h (+8 per
+    // chunk); packed table (pack_items_kernel) -> chunk-major fragments, 1 KiB per wave-load (+256 floats
+    // per chunk).  Rows past the split end are clamped / padded: always a valid address.
+    const int64_t T_all = (a.n_items + 31) >> 5;
+    auto tile_ptr = [&](int64_t t) -> const float* {
+        if (a.ablate & 2) t = 0;   // measurement only: every load hits the same (cached) tile
+        if constexpr (PK) {
+            if (t >= T_all) t = T_all - 1;
+            return a.packed + (t * NCH * 64 + lane) * 4;
+        } else {
+            int64_t row = (t << 5) + i;
+            if (row >= split_end) row = split_end - 1;
+            return a.item_emb + row * D + 4 * h;
+        }
+    };
     auto load_tile = [&](f32x4(&dst)[NCH], int64_t t) {
-        int64_t row = (t << 5) + i;
-        if (row >= split_end) row = split_end - 1;
-        const float* vp = a.item_emb + row * D + 4 * h;
+        const float* vp = tile_ptr(t);
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) dst[q] = load4(vp + 8 * q);
+        for (int q = 0; q < NCH; ++q) dst[q] = load4(vp + (PK ? 256 : 8) * q);
     };
     auto do_tile = [&](f32x4(&src)[NCH], int64_t t, const float* vnext) {
         f32x16 acc[UW];
@@ -197,7 +252,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             f32x4 c = src[q];
-            chunk_swap(c);
+            if constexpr (!PK) chunk_swap(c);   // packed tiles are stored in fragment order already
 #pragma unroll
             for (int u = 0; u < UW; ++u)
                 acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, b[u][q].x, acc[u], 0, 0, 0);
@@ -211,7 +266,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             for (int u = 0; u < UW; ++u)
                 acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b[u][q].w, acc[u], 0, 0, 0);
             if (OCC > 1) {   // ring: the chunk just consumed is refilled with the next tile's rows
-                src[q] = load4(vnext + 8 * q);
+                src[q] = load4(vnext + (PK ? 256 : 8) * q);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -252,11 +307,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         } else {
             f32x4 ta[NCH];
             load_tile(ta, t0);
-            for (int64_t t = t0; t < t1; ++t) {
-                int64_t nrow = ((t + 1) << 5) + i;
-                if (nrow >= split_end) nrow = split_end - 1;
-                do_tile(ta, t, a.item_emb + nrow * D + 4 * h);
-            }
+            for (int64_t t = t0; t < t1; ++t) do_tile(ta, t, tile_ptr(t + 1));
         }
     }
 
@@ -273,12 +324,21 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     }
 }
 
+template <int D, int UW, int OCC, bool PK>
+int launch_score_pk(const ScoreArgs& a, hipStream_t stream);
+
 template <int D, int UW, int OCC>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
+    if (a.packed) return launch_score_pk<D, UW, OCC, true>(a, stream);
+    return launch_score_pk<D, UW, OCC, false>(a, stream);
+}
+
+template <int D, int UW, int OCC, bool PK>
+int launch_score_pk(const ScoreArgs& a, hipStream_t stream) {
     constexpr int UPW = 32 * UW;
     constexpr int WPW = 1;
     const size_t lds = wave_lds_bytes<UPW>(a.k) * WPW;
-    auto kern = score_topk_kernel<D, UW, OCC>;
+    auto kern = score_topk_kernel<D, UW, OCC, PK>;
     if (lds > 64 * 1024)
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -321,11 +381,24 @@ extern "C" int crh_score_topk_supports_dim(int d) {
     return d == 8 || d == 16 || d == 32 || d == 64 || d == 128 || d == 256;
 }
 
+namespace {
+size_t lists_bytes(int64_t n_users, int k) {   // worst case: 64 splits of (score, idx), 256-B aligned
+    return (((size_t)64 * (size_t)n_users * (size_t)k * 8) + 255) & ~(size_t)255;
+}
+size_t packed_bytes(int64_t n_items, int d) { return (size_t)((n_items + 31) / 32) * 32 * (size_t)d * 4; }
+}  // namespace
+
+// Partial lists of the item-range splits + the fragment-ordered copy of the item shard.  A caller that can
+// only afford the first part (crh_score_topk_min_workspace_bytes) still gets the same results from the
+// row-major kernel, at ~0.9x the speed.
 extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
-    (void)n_items;
-    (void)d;
     if (n_users <= 0 || k <= 0) return 0;
-    return (size_t)64 * (size_t)n_users * (size_t)k * 8;   // worst case: 64 splits of (score, idx)
+    return lists_bytes(n_users, k) + (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d) : 0);
+}
+
+extern "C" size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k) {
+    if (n_users <= 0 || k <= 0) return 0;
+    return lists_bytes(n_users, k);
 }
 
 extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n_users,
@@ -382,6 +455,24 @@ extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users
         }
         a.out_score = reinterpret_cast<float*>(workspace);
         a.out_idx = reinterpret_cast<int32_t*>(a.out_score + (size_t)a.n_splits * n_users * k);
+    }
+    // fragment-ordered copy of the shard (one HBM pass, ~0.4 % of a 32 K-user block at 10 M items) when the
+    // workspace has room for it behind the partial lists
+    static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
+    a.packed = nullptr;
+    if (!no_pack && workspace && workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d)) {
+        float* pk = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + lists_bytes(n_users, k));
+        const unsigned tiles = (unsigned)((n_items + 31) / 32);
+        switch (d) {
+            case 8: hipLaunchKernelGGL(pack_items_kernel<8>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
+            case 16: hipLaunchKernelGGL(pack_items_kernel<16>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
+            case 32: hipLaunchKernelGGL(pack_items_kernel<32>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
+            case 64: hipLaunchKernelGGL(pack_items_kernel<64>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
+            case 128: hipLaunchKernelGGL(pack_items_kernel<128>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
+            default: hipLaunchKernelGGL(pack_items_kernel<256>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
+        }
+        CRH_HIP(hipGetLastError());
+        a.packed = pk;
     }
     int rc;
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));

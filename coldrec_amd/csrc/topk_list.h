@@ -62,6 +62,36 @@ __device__ __forceinline__ bool wave_is_masked(int gi, int64_t slot, const int64
     return false;
 }
 
+// Same test with the user's list bounds [lo, hi) already at hand (score_topk keeps them in LDS): the
+// bitmap word and the first probe of the rated list are requested together, so the common case costs ONE
+// memory round trip instead of three dependent ones.  Lists longer than 64 entries are searched 64-ary:
+// lane l probes the head of sub-block l, then the one sub-block that can hold gi is scanned.
+__device__ __forceinline__ bool wave_is_masked_at(int gi, int64_t lo, int64_t hi, const int32_t* rated_col,
+                                                  const uint32_t* bitmap, int lane) {
+    const int64_t n = hi - lo;
+    const int64_t step = (n + 63) >> 6;                 // sub-block length (1 when n <= 64)
+    uint32_t w = 0;
+    if (bitmap) w = bitmap[gi >> 5];
+    int v = CRH_PAD_IDX;
+    const int64_t e = lo + (int64_t)lane * step;
+    if (n > 0 && e < hi) v = rated_col[e];
+    if ((w >> (gi & 31)) & 1u) return true;            // w is wave-uniform (same address in every lane)
+    if (n <= 0) return false;
+    if (__ballot(v == gi) != 0ull) return true;
+    if (step == 1) return false;
+    const int j = __popcll(__ballot(v < gi)) - 1;      // last sub-block whose head is below gi
+    if (j < 0) return false;
+    const int64_t b0 = lo + (int64_t)j * step + 1;     // head already compared
+    const int64_t b1 = (lo + (int64_t)(j + 1) * step) < hi ? (lo + (int64_t)(j + 1) * step) : hi;
+    for (int64_t base = b0; base < b1; base += 64) {
+        const int64_t q = base + lane;
+        const int x = q < b1 ? rated_col[q] : CRH_PAD_IDX;
+        if (__ballot(x == gi) != 0ull) return true;
+        if (__ballot(x > gi) != 0ull) break;
+    }
+    return false;
+}
+
 // fast-path threshold for a list: its k-th score once full, but never above what a masked
 // (-1e9) candidate could beat, so that skipping `raw <= tau` stays exact
 __device__ __forceinline__ float wave_list_tau(const float* lsu, int n, int K) {

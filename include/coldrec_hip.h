@@ -54,9 +54,13 @@ int crh_score_topk_supports_dim(int d);
  *              user's training items, ascending within a row; both NULL = nothing rated
  *   cand_bitmap  bit (gi & 31) of word gi>>5 set => global item gi is masked; NULL = none
  *   k          1..CRH_MAX_K;  out_score/out_idx (n_users, k), idx are GLOBAL item ids
- *   workspace  crh_score_topk_workspace_bytes(...) bytes
+ *   workspace  crh_score_topk_workspace_bytes(...) bytes: partial lists of the item-range splits plus a
+ *              copy of the shard in MFMA-fragment order (n_items*d*4 bytes, written once per call by a
+ *              streaming kernel; removes every cross-lane shuffle from the scoring loop).  With only
+ *              crh_score_topk_min_workspace_bytes(...) the row-major kernel runs: identical results.
  */
 size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k);
+size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k);
 int crh_score_topk_f32(const float* user_emb, const int32_t* users, int64_t n_users,
                        const float* item_emb, int64_t n_items, int d,
                        const int64_t* rated_rowptr, const int32_t* rated_col,

@@ -30,7 +30,10 @@ def _gpu_score_topk(U, users, V, k, rowptr=None, col=None, bitmap_ids=None, item
     ng = n_items_global if n_items_global is not None else item_base + V.shape[0]
     bm = ops.make_bitmap(ng, bitmap_ids, dev)
     s, i = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=item_base, n_splits=n_splits)
+    # every case runs both kernels: fragment-ordered ("packed") item tiles and the row-major fallback
+    s2, i2 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=item_base, n_splits=n_splits, pack=False)
     torch.cuda.synchronize()
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32)), "packed != row-major"
     return s.cpu().numpy(), i.cpu().numpy()
 
 
@@ -215,3 +218,29 @@ def test_full_size_properties_eval_config():
                             orc.make_bitmap(n_items, cold))
     assert np.array_equal(i0n[sample], wi)
     assert np.array_equal(s0n[sample].view(np.uint32), ws.view(np.uint32))
+
+
+def test_long_rated_lists_64ary_search():
+    """Rated lists of 0 ... 9000 entries: the kernel's mask test probes 64 sub-block heads and scans one
+    sub-block (several rounds above 4096 entries).  Quantised tables -> heavy ties, so many candidates reach
+    the mask test; a dense prefix / suffix / stride pattern puts matches at sub-block heads and tails."""
+    rng = np.random.default_rng(77)
+    n_items, d, k = 20000, 8, 20
+    lens = [0, 1, 2, 63, 64, 65, 127, 128, 129, 1000, 4095, 4096, 4097, 9000, 20000]
+    U = rng.integers(-2, 3, (len(lens), d)).astype(np.float32) / 4
+    V = rng.integers(-2, 3, (n_items, d)).astype(np.float32) / 4
+    rated = []
+    for j, n in enumerate(lens):
+        if j % 3 == 0:
+            ids = np.sort(rng.choice(n_items, n, replace=False))
+        elif j % 3 == 1:
+            ids = np.arange(n)                                   # dense prefix: the would-be winners by index
+        else:
+            ids = np.arange(n_items - n, n_items)
+        rated.append(ids.astype(np.int64))
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated)
+    for bm in (None, np.arange(0, n_items, 7)):
+        for splits in (1, 3):
+            _same(_gpu_score_topk(U, None, V, k, rowptr, col, bm, n_splits=splits),
+                  _oracle(U, None, V, k, rowptr, col, bm))
