@@ -73,15 +73,16 @@ def item_shard(n_items, d, lo, hi, device):
 
 
 def rated_lists(n_users, n_items, mean_len, seed):
-    """Per-user training items: Zipf-truncated lengths (mean ~mean_len), uniform ids, ascending."""
+    """Per-user training items (SURVEY.md 8(d) S-EVAL): Zipf-truncated list lengths with mean ~mean_len
+    (zipf(2.5) * 0.54 mean_len, capped at 40*mean_len), uniform item ids, ascending within a user."""
     rng = np.random.default_rng(seed)
-    lens = np.minimum(rng.zipf(1.6, n_users) * (mean_len // 4), 40 * mean_len).astype(np.int64)
+    lens = np.minimum(rng.zipf(2.5, n_users) * max(int(round(mean_len * 0.54)), 1), 40 * mean_len).astype(np.int64)
     rowptr = np.zeros(n_users + 1, np.int64)
     np.cumsum(lens, out=rowptr[1:])
     col = rng.integers(0, n_items, int(rowptr[-1]), dtype=np.int64)
-    row_of = np.repeat(np.arange(n_users), lens)
-    order = np.lexsort((col, row_of))
-    return rowptr, col[order].astype(np.int32)
+    key = np.repeat(np.arange(n_users, dtype=np.int64), lens) << 32 | col
+    key.sort()
+    return rowptr, (key & 0xFFFFFFFF).astype(np.int32)
 
 
 def cpu_baseline(U_cpu, V_cpu, rowptr, col, cold_ids, k, reps):
@@ -220,12 +221,7 @@ def train_xl(dev, steps, warm):
     """HBM-roofline case for the training kernels: tables far beyond every cache."""
     from coldrec_amd.train import MFEngine
     n_u, n_i, d, B = 1_000_000, 10_000_000, 128, 65536
-    eng = MFEngine.__new__(MFEngine)
-    eng.user_num, eng.item_num, eng.d, eng.device = n_u, n_i, d, dev
-    eng.E = xavier_(n_u + n_i, d, 1, dev, n_i)
-    eng.G, eng.M, eng.V = (torch.zeros_like(eng.E) for _ in range(3))
-    eng.lr, eng.reg, eng.step_count = 1e-3, 1e-4, 0
-    eng.loss = torch.zeros(2, dtype=torch.float32, device=dev)
+    eng = MFEngine.from_table(xavier_(n_u + n_i, d, 1, dev, n_i), n_u, 1e-3, 1e-4)
     g = torch.Generator(device=dev).manual_seed(3)
     tri = [(torch.randint(0, n_u, (B,), generator=g, device=dev, dtype=torch.int32),
             torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32),
@@ -245,7 +241,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--users", type=int, default=1_000_000, help="rows of the user table")
-    ap.add_argument("--users-per-step", type=int, default=32768)
+    ap.add_argument("--users-per-step", type=int, default=131072,
+                    help="users scored per step; 2048 wave-groups of 64 users fill the 256 CUs without cutting the "
+                         "item range (every extra cut repeats the top-k warm-up of each user)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--n-splits", type=int, default=0)

@@ -34,6 +34,10 @@ SIGNATURES = {
                                   _vp, _sz, _vp]),
     "crh_score_topk_f32_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
                                      _vp, _sz, _vp, _i32, _vp, _vp]),
+    "crh_score_topk_f16_supports_dim": (_i32, [_i32]),
+    "crh_score_topk_f16_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "crh_score_topk_f16_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
+                                     _vp, _sz, _vp, _i32, _vp, _vp]),
     "crh_mask_topk_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "crh_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crh_bpr_workspace_bytes": (_sz, [_i64]),

@@ -34,11 +34,11 @@
 namespace {
 
 struct ScoreArgs {
-    const float* user_emb;
+    const void* user_emb;   // fp32 or fp16 (the kernel's element type)
     const int32_t* users;
     int64_t n_users;
-    const float* item_emb;
-    const float* packed;   // item tiles in MFMA-fragment order (pack_items_kernel), or NULL
+    const void* item_emb;
+    const void* packed;    // item tiles in MFMA-fragment order (pack_items_kernel), or NULL
     int64_t n_items;
     const int64_t* rated_rowptr;
     const int32_t* rated_col;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void chunk_swap(f32x4& cf) {
     cf = __builtin_bit_cast(f32x4, o);
 }
 
-__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load16(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // Item table -> fragment order.  Tile t = rows [32t, 32t+32) (rows past the end repeat the last row),
 // chunk q = k in [8q, 8q+8):   packed[((t*NCH + q)*64 + h*32 + i)*4 + c] = V[32t + i][8q + 2*j(c) + h],
@@ -102,6 +102,58 @@ __global__ __launch_bounds__(256) void pack_items_kernel(const float* __restrict
         *reinterpret_cast<f32x4*>(packed + ((t * NCH) * 64 + e) * 4) = o;
     }
 }
+
+// fp16 tables (config 5: DropoutNet-style generated embeddings): v_mfma_f32_32x32x16_f16, fp32 accumulate.
+// Lane (i,h) feeds k = 8h..8h+7 of row i, which is one 16-B load of a row-major fp16 row: no swaps at all;
+// packing only makes the loads contiguous: unit (2q+h) of row i -> slot ((t*NCH+q)*64 + h*32 + i).
+template <int D>
+__global__ __launch_bounds__(256) void pack_items_f16_kernel(const _Float16* __restrict__ v, int64_t n_items,
+                                                             _Float16* __restrict__ packed) {
+    constexpr int NCH = D / 16;
+    const int64_t t = blockIdx.x;
+    const u32x4* src = reinterpret_cast<const u32x4*>(v);
+    u32x4* dst = reinterpret_cast<u32x4*>(packed);
+    for (int e = threadIdx.x; e < NCH * 64; e += 256) {
+        // consecutive threads read consecutive 16-B units of a row (coalesced), scatter 16-B units
+        const int r = e / (2 * NCH), c = e % (2 * NCH);
+        int64_t row = (t << 5) + r;
+        if (row >= n_items) row = n_items - 1;
+        const int q = c >> 1, h = c & 1;
+        dst[(t * NCH + q) * 64 + h * 32 + r] = src[row * (2 * NCH) + c];
+    }
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr bool kSwap = true;      // row-major rows need the k-pair swap (chunk_swap)
+    template <int UW>
+    static __device__ __forceinline__ void mma(f32x16 (&acc)[UW], const f32x4& c, const f32x4 (&b)[UW]) {
+        // four k-pairs per 32-byte chunk, users interleaved so dependent MFMAs are one slot apart
+#pragma unroll
+        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, b[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, b[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, b[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b[u].w, acc[u], 0, 0, 0);
+    }
+};
+template <>
+struct Elem<_Float16> {
+    static constexpr bool kSwap = false;
+    template <int UW>
+    static __device__ __forceinline__ void mma(f32x16 (&acc)[UW], const f32x4& c, const f32x4 (&b)[UW]) {
+        const f16x8 ca = __builtin_bit_cast(f16x8, c);
+#pragma unroll
+        for (int u = 0; u < UW; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, __builtin_bit_cast(f16x8, b[u]), acc[u], 0, 0, 0);
+    }
+};
 
 template <int UPW>
 struct WaveLds {
@@ -163,10 +215,12 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
 //   1: two register tiles (A double-buffered), ~320 VGPR+AGPR, one wave per SIMD;
 //   2: one register tile reloaded chunk by chunk right behind its last use, <= 256 registers, so a
 //      second wave on the SIMD fills the matrix pipe while this one selects / waits / inserts.
-template <int D, int UW, int OCC, bool PK>
+template <typename T, int D, int UW, int OCC, bool PK>
 __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     constexpr int WPW = 1;
-    constexpr int NCH = D / 8;
+    constexpr int ROWB = D * (int)sizeof(T);   // bytes per table row
+    constexpr int NCH = ROWB / 32;             // 32-byte chunks per row: lane (i,h) owns 16 B of each
+    constexpr bool SWAP = Elem<T>::kSwap;
     constexpr int UPW = 32 * UW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -199,25 +253,25 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     }
 
     // ---- hot user block -> registers (B fragments, already pair-swapped)
-    f32x4 b[UW][NCH];
+    f32x4 b[NCH][UW];
     float tau[UW];
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
         int64_t slot = ug * UPW + 32 * u + i;
         if (slot >= a.n_users) slot = a.n_users - 1;
         const int64_t row = a.users ? (int64_t)a.users[slot] : slot;
-        const float* up = a.user_emb + row * D + 4 * h;
+        const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            b[u][q] = load4(up + 8 * q);
-            chunk_swap(b[u][q]);
+            b[q][u] = load16(up + 32 * q);
+            if constexpr (SWAP) chunk_swap(b[q][u]);
         }
         tau[u] = CRH_NEG_INF;
     }
 
     // ---- item range of this split, in tiles of 32 rows
-    const int64_t T = (a.n_items + 31) >> 5;
-    const int64_t t0 = T * split / S, t1 = T * (split + 1) / S;
+    const int64_t NT = (a.n_items + 31) >> 5;
+    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
     const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
 
     // Two register tiles: while tile t is multiplied out of one, tile t+1 lands in the other
@@ -227,23 +281,24 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     // chunk); packed table (pack_items_kernel) -> chunk-major fragments, 1 KiB per wave-load (+256 floats
     // per chunk).  Rows past the split end are clamped / padded: always a valid address.
     const int64_t T_all = (a.n_items + 31) >> 5;
-    auto tile_ptr = [&](int64_t t) -> const float* {
+    constexpr int QSTRIDE = PK ? 1024 : 32;    // bytes between this lane's consecutive chunks
+    auto tile_ptr = [&](int64_t t) -> const char* {
         if (a.ablate & 2) t = 0;   // measurement only: every load hits the same (cached) tile
         if constexpr (PK) {
             if (t >= T_all) t = T_all - 1;
-            return a.packed + (t * NCH * 64 + lane) * 4;
+            return reinterpret_cast<const char*>(a.packed) + (t * NCH * 64 + lane) * 16;
         } else {
             int64_t row = (t << 5) + i;
             if (row >= split_end) row = split_end - 1;
-            return a.item_emb + row * D + 4 * h;
+            return reinterpret_cast<const char*>(a.item_emb) + row * ROWB + 16 * h;
         }
     };
     auto load_tile = [&](f32x4(&dst)[NCH], int64_t t) {
-        const float* vp = tile_ptr(t);
+        const char* vp = tile_ptr(t);
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) dst[q] = load4(vp + (PK ? 256 : 8) * q);
+        for (int q = 0; q < NCH; ++q) dst[q] = load16(vp + QSTRIDE * q);
     };
-    auto do_tile = [&](f32x4(&src)[NCH], int64_t t, const float* vnext) {
+    auto do_tile = [&](f32x4(&src)[NCH], int64_t t, const char* vnext) {
         f32x16 acc[UW];
 #pragma unroll
         for (int u = 0; u < UW; ++u)
@@ -252,21 +307,10 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             f32x4 c = src[q];
-            if constexpr (!PK) chunk_swap(c);   // packed tiles are stored in fragment order already
-#pragma unroll
-            for (int u = 0; u < UW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, b[u][q].x, acc[u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < UW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, b[u][q].z, acc[u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < UW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, b[u][q].y, acc[u], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < UW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b[u][q].w, acc[u], 0, 0, 0);
+            if constexpr (SWAP && !PK) chunk_swap(c);   // packed tiles are stored in fragment order already
+            Elem<T>::template mma<UW>(acc, c, b[q]);
             if (OCC > 1) {   // ring: the chunk just consumed is refilled with the next tile's rows
-                src[q] = load4(vnext + (PK ? 256 : 8) * q);
+                src[q] = load16(vnext + QSTRIDE * q);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -324,21 +368,21 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     }
 }
 
-template <int D, int UW, int OCC, bool PK>
+template <typename T, int D, int UW, int OCC, bool PK>
 int launch_score_pk(const ScoreArgs& a, hipStream_t stream);
 
-template <int D, int UW, int OCC>
+template <typename T, int D, int UW, int OCC>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
-    if (a.packed) return launch_score_pk<D, UW, OCC, true>(a, stream);
-    return launch_score_pk<D, UW, OCC, false>(a, stream);
+    if (a.packed) return launch_score_pk<T, D, UW, OCC, true>(a, stream);
+    return launch_score_pk<T, D, UW, OCC, false>(a, stream);
 }
 
-template <int D, int UW, int OCC, bool PK>
+template <typename T, int D, int UW, int OCC, bool PK>
 int launch_score_pk(const ScoreArgs& a, hipStream_t stream) {
     constexpr int UPW = 32 * UW;
     constexpr int WPW = 1;
     const size_t lds = wave_lds_bytes<UPW>(a.k) * WPW;
-    auto kern = score_topk_kernel<D, UW, OCC, PK>;
+    auto kern = score_topk_kernel<T, D, UW, OCC, PK>;
     if (lds > 64 * 1024)
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -349,7 +393,10 @@ int launch_score_pk(const ScoreArgs& a, hipStream_t stream) {
     return CRH_OK;
 }
 
-constexpr int users_per_wave(int d) { return d >= 256 ? 32 : (d >= 128 ? 64 : 128); }
+// users per wave = 32*UW of the instantiation the dispatcher below picks for (element bytes, d)
+constexpr int users_per_wave(int esz, int d) {
+    return esz == 4 ? (d >= 256 ? 32 : (d >= 128 ? 64 : 128)) : (d >= 256 ? 64 : 128);
+}
 
 // Item-range split count.  Workgroups are single waves that all take the same time, and the
 // dispatcher packs them occ-per-SIMD CU by CU (measured: a grid of half the capacity runs on half
@@ -381,46 +428,64 @@ extern "C" int crh_score_topk_supports_dim(int d) {
     return d == 8 || d == 16 || d == 32 || d == 64 || d == 128 || d == 256;
 }
 
+extern "C" int crh_score_topk_f16_supports_dim(int d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
+
 namespace {
 size_t lists_bytes(int64_t n_users, int k) {   // worst case: 64 splits of (score, idx), 256-B aligned
     return (((size_t)64 * (size_t)n_users * (size_t)k * 8) + 255) & ~(size_t)255;
 }
-size_t packed_bytes(int64_t n_items, int d) { return (size_t)((n_items + 31) / 32) * 32 * (size_t)d * 4; }
-}  // namespace
+size_t packed_bytes(int64_t n_items, int d, int esz) { return (size_t)((n_items + 31) / 32) * 32 * (size_t)d * esz; }
 
-// Partial lists of the item-range splits + the fragment-ordered copy of the item shard.  A caller that can
-// only afford the first part (crh_score_topk_min_workspace_bytes) still gets the same results from the
-// row-major kernel, at ~0.9x the speed.
-extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
-    if (n_users <= 0 || k <= 0) return 0;
-    return lists_bytes(n_users, k) + (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d) : 0);
+int pack_items(int esz, const void* item_emb, int64_t n_items, int d, void* pk, hipStream_t st) {
+    const unsigned tiles = (unsigned)((n_items + 31) / 32);
+    const float* vf = reinterpret_cast<const float*>(item_emb);
+    float* pf = reinterpret_cast<float*>(pk);
+    const _Float16* vh = reinterpret_cast<const _Float16*>(item_emb);
+    _Float16* ph = reinterpret_cast<_Float16*>(pk);
+#define CRH_PACK(KERN, V, P) hipLaunchKernelGGL(KERN, dim3(tiles), dim3(256), 0, st, V, n_items, P)
+    if (esz == 4) {
+        switch (d) {
+            case 8: CRH_PACK(pack_items_kernel<8>, vf, pf); break;
+            case 16: CRH_PACK(pack_items_kernel<16>, vf, pf); break;
+            case 32: CRH_PACK(pack_items_kernel<32>, vf, pf); break;
+            case 64: CRH_PACK(pack_items_kernel<64>, vf, pf); break;
+            case 128: CRH_PACK(pack_items_kernel<128>, vf, pf); break;
+            default: CRH_PACK(pack_items_kernel<256>, vf, pf); break;
+        }
+    } else {
+        switch (d) {
+            case 16: CRH_PACK(pack_items_f16_kernel<16>, vh, ph); break;
+            case 32: CRH_PACK(pack_items_f16_kernel<32>, vh, ph); break;
+            case 64: CRH_PACK(pack_items_f16_kernel<64>, vh, ph); break;
+            case 128: CRH_PACK(pack_items_f16_kernel<128>, vh, ph); break;
+            default: CRH_PACK(pack_items_f16_kernel<256>, vh, ph); break;
+        }
+    }
+#undef CRH_PACK
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }
 
-extern "C" size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k) {
-    if (n_users <= 0 || k <= 0) return 0;
-    return lists_bytes(n_users, k);
-}
-
-extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n_users,
-                                     const float* item_emb, int64_t n_items, int d,
-                                     const int64_t* rated_rowptr, const int32_t* rated_col,
-                                     const uint32_t* cand_bitmap, int k, int64_t item_base,
-                                     float* out_score, int32_t* out_idx, void* workspace,
-                                     size_t workspace_bytes, void* stream, int n_splits,
-                                     void* ev_kernel_start, void* ev_kernel_stop) {
-    CRH_CHECK_ARG(user_emb && item_emb && out_score && out_idx, "crh_score_topk_f32: NULL table/output pointer");
-    CRH_CHECK_ARG(n_users > 0 && n_items > 0, "crh_score_topk_f32: empty block (n_users=%lld, n_items=%lld)",
+// esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
+int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
+                   int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
+                   const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
+                   void* workspace, size_t workspace_bytes, void* stream, int n_splits, void* ev_kernel_start,
+                   void* ev_kernel_stop, const char* who) {
+    CRH_CHECK_ARG(user_emb && item_emb && out_score && out_idx, "%s: NULL table/output pointer", who);
+    CRH_CHECK_ARG(n_users > 0 && n_items > 0, "%s: empty block (n_users=%lld, n_items=%lld)", who,
                   (long long)n_users, (long long)n_items);
-    CRH_CHECK_ARG(k >= 1 && k <= CRH_MAX_K, "crh_score_topk_f32: k=%d outside 1..%d", k, CRH_MAX_K);
-    CRH_CHECK_ARG(crh_score_topk_supports_dim(d), "crh_score_topk_f32: d=%d unsupported (pad the tables to 8/16/32/64/128/256)", d);
+    CRH_CHECK_ARG(k >= 1 && k <= CRH_MAX_K, "%s: k=%d outside 1..%d", who, k, CRH_MAX_K);
+    CRH_CHECK_ARG(esz == 4 ? crh_score_topk_supports_dim(d) : crh_score_topk_f16_supports_dim(d),
+                  "%s: d=%d unsupported (pad the tables to %s16/32/64/128/256)", who, d, esz == 4 ? "8/" : "");
     CRH_CHECK_ARG(((uintptr_t)user_emb & 15) == 0 && ((uintptr_t)item_emb & 15) == 0,
-                  "crh_score_topk_f32: tables must be 16-byte aligned");
+                  "%s: tables must be 16-byte aligned", who);
     CRH_CHECK_ARG((rated_rowptr == nullptr) == (rated_col == nullptr) || rated_rowptr != nullptr,
-                  "crh_score_topk_f32: rated_col given without rated_rowptr");
-    CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "crh_score_topk_f32: item ids exceed int32");
-    CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "crh_score_topk_f32: n_splits=%d outside 0..64", n_splits);
+                  "%s: rated_col given without rated_rowptr", who);
+    CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "%s: item ids exceed int32", who);
+    CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "%s: n_splits=%d outside 0..64", who, n_splits);
 
-    const int upw = users_per_wave(d);
+    const int upw = users_per_wave(esz, d);
     ScoreArgs a;
     a.user_emb = user_emb;
     a.users = users;
@@ -435,10 +500,10 @@ extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users
     a.n_ugroups = (n_users + upw - 1) / upw;
     static const int ablate = getenv("CRH_SCORE_ABLATE") ? atoi(getenv("CRH_SCORE_ABLATE")) : 0;
     a.ablate = ablate;
-    // d=128: two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured);
-    // CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD build (tuning hook)
+    // two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured at fp32
+    // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
     static const int variant = getenv("CRH_SCORE_OCC") ? atoi(getenv("CRH_SCORE_OCC")) : 2;
-    const int occ = (variant == 2 && d == 128) ? 2 : 1;
+    const int occ = esz == 2 ? 2 : ((variant == 2 && d == 128) ? 2 : 1);
     a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items, occ);
     const int64_t T = (n_items + 31) / 32;
     if (a.n_splits > T) a.n_splits = (int)T;
@@ -450,45 +515,81 @@ extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users
     } else {
         const size_t need = (size_t)a.n_splits * n_users * k * 8;
         if (!workspace || workspace_bytes < need) {
-            crh_set_error("crh_score_topk_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+            crh_set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, need);
             return CRH_ERR_WS;
         }
         a.out_score = reinterpret_cast<float*>(workspace);
         a.out_idx = reinterpret_cast<int32_t*>(a.out_score + (size_t)a.n_splits * n_users * k);
     }
-    // fragment-ordered copy of the shard (one HBM pass, ~0.4 % of a 32 K-user block at 10 M items) when the
+    // fragment-ordered copy of the shard (one HBM pass, ~0.1 % of a 128 K-user block at 10 M items) when the
     // workspace has room for it behind the partial lists
     static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
     a.packed = nullptr;
-    if (!no_pack && workspace && workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d)) {
-        float* pk = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + lists_bytes(n_users, k));
-        const unsigned tiles = (unsigned)((n_items + 31) / 32);
-        switch (d) {
-            case 8: hipLaunchKernelGGL(pack_items_kernel<8>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
-            case 16: hipLaunchKernelGGL(pack_items_kernel<16>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
-            case 32: hipLaunchKernelGGL(pack_items_kernel<32>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
-            case 64: hipLaunchKernelGGL(pack_items_kernel<64>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
-            case 128: hipLaunchKernelGGL(pack_items_kernel<128>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
-            default: hipLaunchKernelGGL(pack_items_kernel<256>, dim3(tiles), dim3(256), 0, st, item_emb, n_items, pk); break;
-        }
-        CRH_HIP(hipGetLastError());
+    if (!no_pack && workspace && workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz)) {
+        void* pk = reinterpret_cast<char*>(workspace) + lists_bytes(n_users, k);
+        const int prc = pack_items(esz, item_emb, n_items, d, pk, st);
+        if (prc != CRH_OK) return prc;
         a.packed = pk;
     }
     int rc;
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
-    switch (d) {
-        case 8: rc = launch_score<8, 4, 1>(a, st); break;
-        case 16: rc = launch_score<16, 4, 1>(a, st); break;
-        case 32: rc = launch_score<32, 4, 1>(a, st); break;
-        case 64: rc = launch_score<64, 4, 1>(a, st); break;
-        case 128: rc = occ == 2 ? launch_score<128, 2, 2>(a, st) : launch_score<128, 2, 1>(a, st); break;
-        default: rc = launch_score<256, 1, 1>(a, st); break;
+    if (esz == 4) {
+        switch (d) {
+            case 8: rc = launch_score<float, 8, 4, 1>(a, st); break;
+            case 16: rc = launch_score<float, 16, 4, 1>(a, st); break;
+            case 32: rc = launch_score<float, 32, 4, 1>(a, st); break;
+            case 64: rc = launch_score<float, 64, 4, 1>(a, st); break;
+            case 128:
+                rc = occ == 2 ? launch_score<float, 128, 2, 2>(a, st) : launch_score<float, 128, 2, 1>(a, st);
+                break;
+            default: rc = launch_score<float, 256, 1, 1>(a, st); break;
+        }
+    } else {
+        switch (d) {
+            case 16: rc = launch_score<_Float16, 16, 4, 2>(a, st); break;
+            case 32: rc = launch_score<_Float16, 32, 4, 2>(a, st); break;
+            case 64: rc = launch_score<_Float16, 64, 4, 2>(a, st); break;
+            case 128: rc = launch_score<_Float16, 128, 4, 2>(a, st); break;
+            default: rc = launch_score<_Float16, 256, 2, 2>(a, st); break;
+        }
     }
     if (rc != CRH_OK) return rc;
     if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
     if (a.n_splits > 1)
         return crh_merge_topk(a.out_score, a.out_idx, a.n_splits, n_users, k, k, out_score, out_idx, stream);
     return CRH_OK;
+}
+}  // namespace
+
+// Partial lists of the item-range splits + the fragment-ordered copy of the item shard.  A caller that can
+// only afford the first part (crh_score_topk_min_workspace_bytes) still gets the same results from the
+// row-major kernel, at ~0.9x the speed.
+extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
+    if (n_users <= 0 || k <= 0) return 0;
+    return lists_bytes(n_users, k) + (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 4) : 0);
+}
+
+extern "C" size_t crh_score_topk_f16_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
+    if (n_users <= 0 || k <= 0) return 0;
+    return lists_bytes(n_users, k) +
+           (crh_score_topk_f16_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 2) : 0);
+}
+
+extern "C" size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k) {
+    if (n_users <= 0 || k <= 0) return 0;
+    return lists_bytes(n_users, k);
+}
+
+extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n_users,
+                                     const float* item_emb, int64_t n_items, int d,
+                                     const int64_t* rated_rowptr, const int32_t* rated_col,
+                                     const uint32_t* cand_bitmap, int k, int64_t item_base,
+                                     float* out_score, int32_t* out_idx, void* workspace,
+                                     size_t workspace_bytes, void* stream, int n_splits,
+                                     void* ev_kernel_start, void* ev_kernel_stop) {
+    return score_topk_any(4, user_emb, users, n_users, item_emb, n_items, d, rated_rowptr, rated_col, cand_bitmap, k,
+                          item_base, out_score, out_idx, workspace, workspace_bytes, stream, n_splits,
+                          ev_kernel_start, ev_kernel_stop, "crh_score_topk_f32");
 }
 
 extern "C" int crh_score_topk_f32(const float* user_emb, const int32_t* users, int64_t n_users,
@@ -500,4 +601,18 @@ extern "C" int crh_score_topk_f32(const float* user_emb, const int32_t* users, i
     return crh_score_topk_f32_ex(user_emb, users, n_users, item_emb, n_items, d, rated_rowptr, rated_col,
                                  cand_bitmap, k, item_base, out_score, out_idx, workspace, workspace_bytes,
                                  stream, 0, nullptr, nullptr);
+}
+
+// fp16 tables (IEEE half, row-major), fp32 accumulation on v_mfma_f32_32x32x16_f16; everything else --
+// masks, canonical order of the returned lists, splits, workspace protocol -- as crh_score_topk_f32_ex.
+extern "C" int crh_score_topk_f16_ex(const void* user_emb, const int32_t* users, int64_t n_users,
+                                     const void* item_emb, int64_t n_items, int d,
+                                     const int64_t* rated_rowptr, const int32_t* rated_col,
+                                     const uint32_t* cand_bitmap, int k, int64_t item_base,
+                                     float* out_score, int32_t* out_idx, void* workspace,
+                                     size_t workspace_bytes, void* stream, int n_splits,
+                                     void* ev_kernel_start, void* ev_kernel_stop) {
+    return score_topk_any(2, user_emb, users, n_users, item_emb, n_items, d, rated_rowptr, rated_col, cand_bitmap, k,
+                          item_base, out_score, out_idx, workspace, workspace_bytes, stream, n_splits,
+                          ev_kernel_start, ev_kernel_stop, "crh_score_topk_f16");
 }

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 SUPPORTED_DIMS = (8, 16, 32, 64, 128, 256)
+SUPPORTED_DIMS_F16 = (16, 32, 64, 128, 256)
 
 
 def _need_cuda(*ts):
@@ -23,9 +24,10 @@ def pad_dim(table: torch.Tensor) -> torch.Tensor:
     """Zero-pad the embedding width to the next width the MFMA kernel is built for.
     Trailing zeros are exact no-ops of the fp32 fma chain (fma(0,0,s) == s, s never -0)."""
     d = table.shape[1]
-    if d in SUPPORTED_DIMS:
+    dims = SUPPORTED_DIMS_F16 if table.dtype == torch.float16 else SUPPORTED_DIMS
+    if d in dims:
         return table
-    for w in SUPPORTED_DIMS:
+    for w in dims:
         if w > d:
             out = torch.zeros((table.shape[0], w), dtype=table.dtype, device=table.device)
             out[:, :d] = table
@@ -76,13 +78,15 @@ def score_topk(user_emb: torch.Tensor, users: Optional[torch.Tensor], item_emb: 
                out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, kernel_events=None, pack: bool = True):
     """Fused ``user_emb[users] @ item_emb.T`` -> masks -> top-k (model/MF.py:58-63 +
     model/BaseRecommender.py:175-182).  Returns (scores fp32, global item ids int32), each
-    (n_users, k), canonical order.  ``users`` int32 rows of user_emb or None for all rows.
+    (n_users, k), canonical order.  fp32 tables: exact fp32 MFMA, bit-identical to the oracle's fma chain;
+    fp16 tables (both): fp16 MFMA with fp32 accumulation (config 5, generated embeddings).  ``users`` int32 rows of user_emb or None for all rows.
     ``kernel_events``: optional (hipEvent_t, hipEvent_t) raw handles recorded around the scoring
     kernel alone (bench.py's roofline measurement).  ``pack=False`` withholds the workspace for the
     fragment-ordered copy of the item shard (row-major kernel: same results, less memory, ~0.9x speed)."""
     _need_cuda(user_emb, users, item_emb, rated_rowptr, rated_col, cand_bitmap)
-    if user_emb.dtype != torch.float32 or item_emb.dtype != torch.float32:
-        raise RuntimeError("score_topk: fp32 tables expected")
+    if user_emb.dtype != item_emb.dtype or user_emb.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError("score_topk: both tables fp32 (exact, canonical) or both fp16 (fp32 accumulate)")
+    half = user_emb.dtype == torch.float16
     if user_emb.shape[1] != item_emb.shape[1]:
         raise RuntimeError("score_topk: user/item embedding widths differ")
     user_emb, item_emb = pad_dim(user_emb.contiguous()), pad_dim(item_emb.contiguous())
@@ -100,10 +104,10 @@ def score_topk(user_emb: torch.Tensor, users: Optional[torch.Tensor], item_emb: 
         out = (torch.empty((n_users, k), dtype=torch.float32, device=dev),
                torch.empty((n_users, k), dtype=torch.int32, device=dev))
     L = _lib.lib()
-    ws_bytes = (L.crh_score_topk_workspace_bytes(n_users, n_items, d, k) if pack
-                else L.crh_score_topk_min_workspace_bytes(n_users, k))
+    full = L.crh_score_topk_f16_workspace_bytes if half else L.crh_score_topk_workspace_bytes
+    ws_bytes = full(n_users, n_items, d, k) if pack else L.crh_score_topk_min_workspace_bytes(n_users, k)
     ws = _workspace(ws_bytes, dev)
-    rc = L.crh_score_topk_f32_ex(_lib.ptr(user_emb), _lib.ptr(users), n_users, _lib.ptr(item_emb), n_items, d,
+    rc = (L.crh_score_topk_f16_ex if half else L.crh_score_topk_f32_ex)(_lib.ptr(user_emb), _lib.ptr(users), n_users, _lib.ptr(item_emb), n_items, d,
                                  _lib.ptr(rated_rowptr), _lib.ptr(rated_col), _lib.ptr(cand_bitmap), k,
                                  item_base, _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(ws), ws_bytes,
                                  _lib.current_stream(), n_splits,

@@ -70,6 +70,20 @@ class _TableState:
         if hi > lo:
             self.k.bpr_bwd(tu, tp, tp, u, p, n, B, self.reg, self.sums, gu, gp, gp, loss_out, self._bpr_ws)
 
+    @classmethod
+    def from_table(cls, E: torch.Tensor, user_num: int, lr: float, reg: float):
+        """Engine over an existing device-resident (user_num + item_num, d) fp32 table (rows of users first);
+        no host copy is made -- for tables generated on the GPU (bench.py S-TRAIN-XL)."""
+        self = cls.__new__(cls)
+        self.k = ops
+        assert E.is_cuda and E.dtype == torch.float32 and E.is_contiguous() and E.shape[1] % 4 == 0
+        self.user_num, self.item_num, self.d, self.device = int(user_num), E.shape[0] - int(user_num), E.shape[1], E.device
+        self.E = E
+        self.G, self.M, self.V = (torch.zeros_like(E) for _ in range(3))
+        self.lr, self.reg, self.step_count = float(lr), float(reg), 0
+        self.loss = torch.zeros(2, dtype=torch.float32, device=E.device)
+        return self
+
     def __init__(self, user0, item0, lr: float, reg: float, device, kernels=None):
         # ``kernels``: injectable for the CPU (gloo) plumbing tests only; the product path is coldrec_amd.ops
         self.k = kernels or ops

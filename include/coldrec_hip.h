@@ -81,6 +81,24 @@ int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n
                           void* ev_kernel_start, void* ev_kernel_stop);
 
 /*
+ * fp16 variant for generated embeddings (SURVEY.md 8(f)3 / BASELINE.json configs[4]: model/DropoutNet.py:126-135
+ * produces the tables, :67-72 scores them with the same user_emb[users] @ item_emb.T).  Tables are IEEE half,
+ * row-major, d in {16,32,64,128,256}; products are exact in fp32 and accumulated in fp32 by
+ * v_mfma_f32_32x32x16_f16 (the accumulation order inside one 16-wide MFMA step is the hardware's, so
+ * scores are compared with a tolerance, not bit for bit; the ORDER of the returned list is canonical for
+ * the scores the kernel computed).  Masks, splits, workspace protocol, events: as crh_score_topk_f32_ex.
+ */
+int crh_score_topk_f16_supports_dim(int d);
+size_t crh_score_topk_f16_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k);
+int crh_score_topk_f16_ex(const void* user_emb, const int32_t* users, int64_t n_users,
+                          const void* item_emb, int64_t n_items, int d,
+                          const int64_t* rated_rowptr, const int32_t* rated_col,
+                          const uint32_t* cand_bitmap, int k, int64_t item_base,
+                          float* out_score, int32_t* out_idx,
+                          void* workspace, size_t workspace_bytes, void* stream, int n_splits,
+                          void* ev_kernel_start, void* ev_kernel_stop);
+
+/*
  * Mask + top-k over an already materialised dense score block (any batch_predict, e.g.
  * model/VBPR.py:68-75, model/ALDI.py:149-160): model/BaseRecommender.py:175-183.
  * scores (n_users, row_stride) fp32; masked entries are also written back as -1e9 when

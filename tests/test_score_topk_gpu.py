@@ -244,3 +244,70 @@ def test_long_rated_lists_64ary_search():
         for splits in (1, 3):
             _same(_gpu_score_topk(U, None, V, k, rowptr, col, bm, n_splits=splits),
                   _oracle(U, None, V, k, rowptr, col, bm))
+
+
+# ------------------------------------------------------------------ fp16 tables (config 5)
+def _gpu_score_topk_f16(U16, users, V16, k, rowptr=None, col=None, bitmap_ids=None, n_splits=0):
+    from coldrec_amd import ops
+    dev = _dev()
+    tU, tV = torch.from_numpy(U16).to(dev), torch.from_numpy(V16).to(dev)
+    tu = None if users is None else torch.from_numpy(np.asarray(users, np.int32)).to(dev)
+    rp = rc = None
+    if rowptr is not None:
+        srp, src = orc.sort_rated(rowptr, col)
+        rp, rc = torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev)
+    bm = ops.make_bitmap(V16.shape[0], bitmap_ids, dev)
+    s, i = ops.score_topk(tU, tu, tV, k, rp, rc, bm, n_splits=n_splits)
+    s2, i2 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, n_splits=n_splits, pack=False)
+    torch.cuda.synchronize()
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32)), "packed != row-major (f16)"
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("n_users,n_items,k", [(1, 1, 1), (33, 33, 20), (130, 1000, 20), (257, 4097, 64)])
+def test_f16_exact_arithmetic_matches_canonical_oracle(d, n_users, n_items, k):
+    """Tables on a 2^-3 grid in [-1, 1]: exactly representable in fp16 and every partial sum is exact in fp32,
+    so the fp16-MFMA kernel must return bit for bit what the fp32 canonical oracle returns (ties included)."""
+    rng = np.random.default_rng(d + n_users + n_items)
+    U = (rng.integers(-8, 9, (max(n_users, 40), d)) / 8).astype(np.float32)
+    V = (rng.integers(-8, 9, (n_items, d)) / 8).astype(np.float32)
+    users = rng.permutation(U.shape[0])[:n_users].astype(np.int64)
+    rated = [np.unique(rng.integers(0, n_items, rng.poisson(12))) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    bm = np.where(rng.random(n_items) < 0.2)[0]
+    for splits in (0, 3):
+        got = _gpu_score_topk_f16(U.astype(np.float16), users, V.astype(np.float16), k, rowptr, col, bm, n_splits=splits)
+        _same(got, _oracle(U, users, V, k, rowptr, col, bm))
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_f16_continuous_within_tolerance_of_fp64(d):
+    """Continuous fp16 tables: scores within 1e-3 relative (+ rounding floor) of an fp64 re-score of the SAME fp16
+    values; every returned item's true score reaches the true k-th best up to that tolerance; masked items
+    never appear; lists sorted by (score desc, index asc)."""
+    rng = np.random.default_rng(d)
+    n_users, n_items, k = 96, 20000, 20
+    U16 = (rng.standard_normal((n_users, d)) * 0.3).astype(np.float16)
+    V16 = (rng.standard_normal((n_items, d)) * 0.3).astype(np.float16)
+    rated = [np.unique(rng.integers(0, n_items, 30)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    bm = np.where(rng.random(n_items) < 0.2)[0]
+    s, i = _gpu_score_topk_f16(U16, None, V16, k, rowptr, col, bm)
+    S = U16.astype(np.float64) @ V16.astype(np.float64).T
+    absS = np.abs(U16.astype(np.float64)) @ np.abs(V16.astype(np.float64)).T
+    masked = np.zeros((n_users, n_items), bool)
+    masked[:, bm] = True
+    for r in range(n_users):
+        masked[r, rated[r]] = True
+    Sm = np.where(masked, -1e9, S)
+    kth = np.sort(Sm, axis=1)[:, -k]
+    for r in range(n_users):
+        tol = 1e-3 * np.abs(S[r, i[r]]) + 64 * 2.0 ** -24 * absS[r, i[r]]
+        assert not masked[r, i[r]].any()
+        assert np.all(np.abs(s[r] - S[r, i[r]]) <= tol)
+        assert np.all(S[r, i[r]] >= kth[r] - tol)
+        assert np.all((s[r][:-1] > s[r][1:]) | ((s[r][:-1] == s[r][1:]) & (i[r][:-1] < i[r][1:])))
+        assert len(set(i[r].tolist())) == k
