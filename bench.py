@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: BF16/F16 MFMA ~2.5 PF dense (not the 2:1-sparsity headline)
 CHUNK_ROWS = 1_250_000         # item table is generated in chunks so shards agree for N = 1,2,4,8
 
 
@@ -62,14 +63,15 @@ def xavier_(rows, d, seed, device, fan_rows):
     return (torch.rand((rows, d), generator=g, device=device, dtype=torch.float32) * 2 - 1) * a
 
 
-def item_shard(n_items, d, lo, hi, device):
+def item_shard(n_items, d, lo, hi, device, dtype=torch.float32):
     """Rows [lo, hi) of the synthetic item table U(-a, a) (seed 3 + chunk), xavier-like."""
-    parts = []
+    out = torch.empty((hi - lo, d), dtype=dtype, device=device)
     for c in range(lo // CHUNK_ROWS, (hi + CHUNK_ROWS - 1) // CHUNK_ROWS):
         c_lo, c_hi = c * CHUNK_ROWS, min((c + 1) * CHUNK_ROWS, n_items)
         chunk = xavier_(c_hi - c_lo, d, 3000 + c, device, n_items)
-        parts.append(chunk[max(lo, c_lo) - c_lo: min(hi, c_hi) - c_lo])
-    return torch.cat(parts, 0).contiguous()
+        a, b = max(lo, c_lo), min(hi, c_hi)
+        out[a - lo: b - lo] = chunk[a - c_lo: b - c_lo].to(dtype)
+    return out
 
 
 def rated_lists(n_users, n_items, mean_len, seed):
@@ -246,6 +248,9 @@ def main():
                          "item range (every extra cut repeats the top-k warm-up of each user)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
+                    help="f32 = exact fp32 MFMA, bit-exact parity mode (headline); f16 = fp16 tables with fp32 "
+                         "accumulation (BASELINE.json configs[4]: --dtype f16 --items 50000000 --dim 256 --users 100000)")
     ap.add_argument("--n-splits", type=int, default=0)
     ap.add_argument("--masks", choices=["warm", "none"], default="warm",
                     help="'warm' = rated CSR + 20%% cold-item bitmap (default); 'none' = diagnostic run without masks")
@@ -280,10 +285,12 @@ def main():
 
     I, d, k, Bu = args.items, args.dim, args.k, args.users_per_step
     lo, hi = rank * I // world, (rank + 1) * I // world
-    V = item_shard(I, d, lo, hi, dev)
+    tdtype = torch.float16 if args.dtype == "f16" else torch.float32
+    Bu = min(Bu, args.users)
+    V = item_shard(I, d, lo, hi, dev, tdtype)
     n_blocks = args.warmup + args.steps
     n_user_rows = min(args.users, Bu * n_blocks)
-    U = xavier_(n_user_rows, d, 17, dev, args.users)
+    U = xavier_(n_user_rows, d, 17, dev, args.users).to(tdtype)
     rowptr, col = rated_lists(n_user_rows, I, 50, seed=4)
     cold = np.where(np.random.default_rng(5).random(I) < 0.2)[0]       # 'warm' setting: cold items masked
     bitmap = ops.make_bitmap(I, cold, dev)
@@ -326,32 +333,34 @@ def main():
     kern_ms = float(np.mean(events.elapsed_ms()))
     flops_per_launch = 2.0 * d * Bu * (hi - lo)
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+    peak_tf = MFMA_F16_PEAK_TFLOPS if args.dtype == "f16" else MFMA_F32_PEAK_TFLOPS
 
     result = {
         "metric": "ranked items/sec (full-catalogue eval)", "value": value, "unit": "items/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "configs[3] full-catalogue eval: %d-row user table x %d items, d=%d, k=%d, "
+        "config": {"workload": "configs[%d] full-catalogue eval: %d-row user table x %d items, d=%d, k=%d, %s tables, "
                                "user block %d per step, rated CSR (mean ~50) + 20%% cold-item bitmap ('warm' setting), "
-                               "item table row-sharded over %d GPU(s)" % (args.users, I, d, k, Bu, world),
+                               "item table row-sharded over %d GPU(s)"
+                               % (4 if args.dtype == "f16" else 3, args.users, I, d, k, args.dtype, Bu, world),
                    "users_per_step": Bu, "items": I, "dim": d, "k": k,
                    "parallelism": "item-row-shard x%d + all_gather(top-k) + canonical merge" % world if world > 1
                    else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "score_topk_kernel<%d>" % d, "achieved": achieved,
-                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": "score_topk_kernel<%s,%d>" % (args.dtype, d), "achieved": achieved,
+                     "peak": peak_tf, "unit": "TFLOP/s", "frac": achieved / peak_tf,
                      "kernel_ms": kern_ms, "flops_per_launch": flops_per_launch, "traffic": None},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nu, ni = args.cpu_sample_users, min(args.cpu_sample_items, hi - lo)
-        Uc, Vc = U[:nu].cpu(), V[:ni].cpu()
+        Uc, Vc = U[:nu].float().cpu(), V[:ni].float().cpu()   # the reference scores in fp32 (torch.matmul)
         rate = cpu_baseline(Uc, Vc, rowptr[:nu + 1], col, cold, k, reps=2)
         result["cpu_baseline"] = {
             "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
                       "%d threads, 2 reps" % (nu, ni, torch.__version__, os.cpu_count())}
-    if rank == 0 and world == 1 and not args.no_train:
+    if rank == 0 and world == 1 and not args.no_train and args.dtype == "f32":
         del V, U, engine
         torch.cuda.empty_cache()
         result.update(train_legs(dev, not args.no_cpu_baseline))

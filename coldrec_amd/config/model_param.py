@@ -18,4 +18,8 @@ def model_specific_param(model_name, parser, available_models):
     if model_name not in available_models.keys():
         raise ValueError(f"Invalid model name: {model_name}. Available models: {list(available_models.keys())}")
     # MF and LightGCN take no flags beyond the common ones (--layers is common, main.py:94)
+    if model_name == 'DropoutNet':      # config/model_param.py:242-255
+        parser.add_argument('--n_dropout', type=float, default=0.5, help='Dropout rate of the network training')
+        parser.add_argument('--dropoutnet_hidden1', type=int, default=200, help='DeepCF first hidden width')
+        parser.add_argument('--dropoutnet_hidden2', type=int, default=100, help='DeepCF second hidden width')
     return parser

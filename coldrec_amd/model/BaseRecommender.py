@@ -139,14 +139,15 @@ class BaseColdStartTrainer(ABC):
         fused = fused and torch.is_tensor(ue) and torch.is_tensor(ie) and ue.is_cuda and ue.dim() == 2
         if fused:
             dp = dp_from_env()
+            tdt = torch.float16 if getattr(self.args, 'score_dtype', 'fp32') == 'fp16' else torch.float32
+            ue, ie = ue.detach().to(tdt), ie.detach().to(tdt)
             if dp is None:
-                s, i = ops.score_topk(ue.detach().float(), c['users_int'], ie.detach().float(), self.max_N,
-                                      c['rated_rowptr'], c['rated_col'], c['bitmap'])
+                s, i = ops.score_topk(ue, c['users_int'], ie, self.max_N, c['rated_rowptr'], c['rated_col'],
+                                      c['bitmap'])
             else:                     # item rows sharded over the ranks, all-gather + canonical merge
                 lo, hi = shard_bounds(ie.shape[0], dp.world, dp.rank)
-                eng = ShardedTopK(ie.detach().float()[lo:hi].contiguous(), lo, ie.shape[0], self.max_N,
-                                  dp.world, dp.rank)
-                s, i = eng.topk(ue.detach().float(), c['users_int'], c['rated_rowptr'], c['rated_col'], c['bitmap'])
+                eng = ShardedTopK(ie[lo:hi].contiguous(), lo, ie.shape[0], self.max_N, dp.world, dp.rank)
+                s, i = eng.topk(ue, c['users_int'], c['rated_rowptr'], c['rated_col'], c['bitmap'])
         else:
             parts_s, parts_i = [], []
             for lo in range(0, len(c['users']), self.batch_size):

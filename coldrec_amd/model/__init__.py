@@ -6,7 +6,7 @@ subclasses ``BaseColdStartTrainer`` can be registered with ``register(name, cls)
 """
 import importlib
 
-_BUILTIN = {'MF': ('.MF', 'MF'), 'LightGCN': ('.LightGCN', 'LightGCN')}
+_BUILTIN = {'MF': ('.MF', 'MF'), 'LightGCN': ('.LightGCN', 'LightGCN'), 'DropoutNet': ('.DropoutNet', 'DropoutNet')}
 
 
 class _Registry(dict):

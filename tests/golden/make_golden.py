@@ -20,6 +20,7 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g6_eval_*.npz    model/BaseRecommender.py:109-188  _evaluate top-k for all/warm/cold
   g7_metrics.npz   util/evaluator.py:153-187  ranking_evaluation on the g6 lists
   g8_e2e.json      model/BaseRecommender.py:353-370  MF.run() d=64, 3 epochs, test metrics
+  g9_dropoutnet.*  model/DropoutNet.py:12-72  DropoutNet.run() on the g8 tables, 2 epochs: losses, tables, metrics
 """
 import json
 import os
@@ -383,7 +384,45 @@ def g8_e2e(split):
                         V=trainer.item_emb.detach().numpy())
 
 
+def g9_dropoutnet(split):
+    """The reference's DropoutNet on the toy split, backbone tables = the g8 MF tables."""
+    import contextlib
+    import io
+    import tempfile
+    from model.DropoutNet import DropoutNet  # noqa: E402  (reference)
+    data = ref_builder(split)
+    emb = np.load(out("g8_e2e_emb.npz"))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "emb"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(emb["U"])), os.path.join(tmp, "emb", "toy_cold_item_MF_user_emb.pt"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(emb["V"])), os.path.join(tmp, "emb", "toy_cold_item_MF_item_emb.pt"))
+        os.chdir(tmp)
+        try:
+            cfg = ref_config(data, model="DropoutNet", emb_size=64, epochs=3, bs=128, n_dropout=0.5,
+                             dropoutnet_hidden1=200, dropoutnet_hidden2=100)
+            set_seed(2024, False)
+            trainer = DropoutNet(cfg)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                trainer.run()
+        finally:
+            os.chdir(cwd)
+    loss_lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("training:")]
+    payload = dict(args=vars(cfg.args), overall=trainer.overall_test_results, cold=trainer.cold_test_results,
+                   warm=trainer.warm_test_results, best=[trainer.bestPerformance[0], trainer.bestPerformance[1]],
+                   epochs_ran=trainer.epochs_ran, loss_lines=loss_lines,
+                   user_emb_norm=float(trainer.user_emb.norm()), item_emb_norm=float(trainer.item_emb.norm()))
+    with open(out("g9_dropoutnet.json"), "w") as f:
+        json.dump(payload, f, indent=1)
+    np.savez_compressed(out("g9_dropoutnet_emb.npz"), U=trainer.user_emb.detach().numpy(),
+                        V=trainer.item_emb.detach().numpy())
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":          # add the DropoutNet fixture without redoing G1-G8
+        g9_dropoutnet(make_dataset("toy", "item", seed=1))
+        return
     split_i = make_dataset("toy", "item", seed=1)
     split_u = make_dataset("toy", "user", seed=2)
     dump_split(split_i, ref_builder(split_i), "toy_item.npz")
@@ -401,6 +440,7 @@ def main():
     g6_small()
     g7_metrics(lists)
     g8_e2e(split_i)
+    g9_dropoutnet(split_i)
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

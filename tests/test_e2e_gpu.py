@@ -147,3 +147,48 @@ def test_dense_batch_predict_path_equals_fused_path():
             # the dense block comes from rocBLAS (other summation order): same items where the
             # reference fixture guarantees a rank margin
             assert np.array_equal(dense_items[real], want_items[r][real])
+
+
+def _dropoutnet_run(tmp_path, monkeypatch, **kw):
+    from coldrec_amd.model import AVAILABLE_MODELS
+    from coldrec_amd.util.utils import set_seed
+    emb = load_golden("g8_e2e_emb.npz")
+    (tmp_path / "emb").mkdir(exist_ok=True)
+    torch.save(nn.Parameter(torch.from_numpy(emb["U"])), tmp_path / "emb" / "toy_cold_item_MF_user_emb.pt")
+    torch.save(nn.Parameter(torch.from_numpy(emb["V"])), tmp_path / "emb" / "toy_cold_item_MF_item_emb.pt")
+    monkeypatch.chdir(tmp_path)
+    _, data = builder()
+    set_seed(2024, True)
+    tr = AVAILABLE_MODELS["DropoutNet"](_cfg(data, model="DropoutNet", emb_size=64, epochs=3, bs=128, n_dropout=0.5,
+                                             dropoutnet_hidden1=200, dropoutnet_hidden2=100, **kw))
+    tr.run()
+    return tr
+
+
+def test_dropoutnet_matches_reference_end_to_end_g9(tmp_path, monkeypatch, capsys):
+    """the DropoutNet generator (model/DropoutNet.py) trained on the g8 MF tables; the
+    reference's run is in g9_dropoutnet.json.  Same random streams -> same losses and generated tables
+    (GEMM rounding only), ranked by the fused kernel."""
+    want = json.load(open(os.path.join(GOLDEN, "g9_dropoutnet.json")))
+    emb = load_golden("g9_dropoutnet_emb.npz")
+    tr = _dropoutnet_run(tmp_path, monkeypatch)
+    out = capsys.readouterr().out
+    got_losses = [float(l.split("batch_loss:")[1]) for l in out.splitlines() if l.startswith("training:")]
+    ref_losses = [float(l.split("batch_loss:")[1]) for l in want["loss_lines"]]
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=1e-4)
+    assert tr.epochs_ran == want["epochs_ran"] and tr.bestPerformance[0] == want["best"][0]
+    np.testing.assert_allclose(float(tr.user_emb.norm()), want["user_emb_norm"], rtol=1e-4)
+    np.testing.assert_allclose(float(tr.item_emb.norm()), want["item_emb_norm"], rtol=1e-4)
+    assert np.abs(tr.item_emb.cpu().numpy() - emb["V"]).max() < 1e-3 * np.abs(emb["V"]).max()
+    for name, res in (("overall", tr.overall_test_results), ("cold", tr.cold_test_results), ("warm", tr.warm_test_results)):
+        np.testing.assert_allclose(np.array(res), np.array(want[name]), atol=3e-3)
+
+
+def test_dropoutnet_fp16_ranking_close_to_fp32(tmp_path, monkeypatch):
+    """--score_dtype fp16: half tables + fp16 MFMA for the ranking only; metrics stay within a few 1e-3 of the
+    fp32 run (near-ties may swap), training is untouched."""
+    a = _dropoutnet_run(tmp_path, monkeypatch)
+    b = _dropoutnet_run(tmp_path, monkeypatch, score_dtype="fp16")
+    assert torch.equal(a.user_emb, b.user_emb) or float((a.user_emb - b.user_emb).norm()) < 1e-3 * float(a.user_emb.norm())
+    for ra, rb in ((a.overall_test_results, b.overall_test_results), (a.cold_test_results, b.cold_test_results)):
+        np.testing.assert_allclose(np.array(ra), np.array(rb), atol=6e-3)

@@ -117,7 +117,7 @@ def test_trainers_refuse_cpu_and_early_stopping_rules():
     args = argparse.Namespace(dataset="toy", model="MF", epochs=2, layers=2, topN="10,20", bs=512, emb_size=16,
                               lr=1e-3, reg=1e-4, early_stop=2, eval_every=1, cold_object="item", save_emb=False)
     cfg = types.SimpleNamespace(args=args, data=d, device=torch.device("cpu"))
-    assert sorted(AVAILABLE_MODELS.keys()) == ["LightGCN", "MF"]
+    assert sorted(AVAILABLE_MODELS.keys()) == ["DropoutNet", "LightGCN", "MF"]
     with pytest.raises(RuntimeError, match="MI355X only"):
         AVAILABLE_MODELS["MF"](cfg).train()
 
