@@ -109,6 +109,24 @@ def cpu_baseline(U_cpu, V_cpu, rowptr, col, cold_ids, k, reps):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def measured_traffic(kernel_prefix, grid_threads):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc.json, written by tools/profile_round.sh + tools/prof_summary.py in separate --pmc passes;
+    FETCH_SIZE x 1024 x 2 as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950, + WRITE_SIZE x
+    1024).  Only a record of the SAME kernel instantiation and grid counts; otherwise None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            rec = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for name, v in rec.items():
+            if kernel_prefix in name and v.get("_Grid_Size") == grid_threads and "hbm_read_bytes_corrected" in v:
+                best = (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0), os.path.basename(f))
+    return best
+
+
 def _time_steps(fn, n_steps, warm):
     for s in range(warm):
         fn(s)
@@ -351,6 +369,16 @@ def main():
                      "peak": peak_tf, "unit": "TFLOP/s", "frac": achieved / peak_tf,
                      "kernel_ms": kern_ms, "flops_per_launch": flops_per_launch, "traffic": None},
     }
+    if args.dtype == "f32" and d == 128:
+        # grid of the kernel = 64 lanes x (groups of 64 users) x (item-range cuts the library picks: 1 once the
+        # user groups fill the 2048 wave slots)
+        groups = (Bu + 63) // 64
+        tr = measured_traffic("score_topk_kernel<float, 128, 2, 2, true>", float(64 * groups)) if groups >= 2048 else None
+        if tr:
+            result["roofline"]["traffic"] = tr[0]
+            result["roofline"]["traffic_note"] = ("L2-miss (fabric-side) bytes per launch from %s; mostly served by the "
+                                                  "256 MB Infinity Cache, compulsory HBM bytes are %d" % (
+                                                      tr[1], (hi - lo) * d * 4 + Bu * d * 4))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nu, ni = args.cpu_sample_users, min(args.cpu_sample_items, hi - lo)

@@ -16,9 +16,61 @@ import os
 import sys
 
 
+def _db_stats(stats_dir, tag):
+    """rocprofv3's default output here is a rocpd sqlite file: rebuild the --stats kernel table from it."""
+    import sqlite3
+    for f in glob.glob(os.path.join(stats_dir, "**", "*_results.db"), recursive=True):
+        c = sqlite3.connect(f)
+        per = collections.defaultdict(list)
+        for name, dur in c.execute("select name, duration from kernels"):
+            per[name].append(float(dur))
+        total = sum(sum(v) for v in per.values()) or 1.0
+        rows = []
+        for name, v in per.items():
+            mean = sum(v) / len(v)
+            sd = (sum((x - mean) ** 2 for x in v) / len(v)) ** 0.5
+            rows.append([name, len(v), int(sum(v)), "%.6f" % mean, "%.4f" % (100 * sum(v) / total), int(min(v)),
+                         int(max(v)), "%.6f" % sd])
+        ours = lambda n: 0 if ("anonymous namespace)::" in n and "at::native" not in n) else 1
+        rows.sort(key=lambda r: (ours(r[0]), -r[2]))
+        with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as o:
+            w = csv.writer(o)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            w.writerows(rows[:25])
+
+
+def _db_pmc(d, out):
+    import sqlite3
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        c = sqlite3.connect(f)
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        # one row per (dispatch, counter, hardware instance): sum the instances of a dispatch first
+        for name, counter, value in c.execute(
+                "select name, counter_name, sum(counter_value) from pmc_events group by dispatch_id, name, counter_name"):
+            if "at::native" in name or "rocprim" in name:
+                continue
+            agg[name][counter].append(float(value))
+        meta = {}
+        for row in c.execute("select name, duration, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, "
+                             "grid_x, workgroup_x from kernels"):
+            if row[0] in agg:
+                m = meta.setdefault(row[0], collections.defaultdict(list))
+                m["_duration_ns"].append(float(row[1]))
+                for key, v in zip(("_VGPR_Count", "_Accum_VGPR_Count", "_SGPR_Count", "_LDS_Block_Size", "_Grid_Size",
+                                   "_Workgroup_Size"), row[2:]):
+                    m[key] = [float(v)]
+        for name, cs in agg.items():
+            o = out.setdefault(name, {})
+            for cname, v in list(cs.items()) + list(meta.get(name, {}).items()):
+                o[cname] = sum(v) / len(v)
+                if not cname.startswith("_"):
+                    o[cname + "_launches"] = len(v)
+
+
 def main():
     tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     os.makedirs("profiles", exist_ok=True)
+    _db_stats(stats_dir, tag)
     for f in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
         head, body = rows[0], rows[1:]
@@ -30,6 +82,7 @@ def main():
             w.writerows(body[:25])
     out = {}
     for d in pmc_dirs:
+        _db_pmc(d, out)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             agg = collections.defaultdict(lambda: collections.defaultdict(list))
             for r in csv.DictReader(open(f)):
