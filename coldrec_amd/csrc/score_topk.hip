@@ -28,6 +28,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "crh_common.h"
 #include "topk_list.h"
 
@@ -50,6 +53,10 @@ struct ScoreArgs {
     float* out_score;   // [n_splits][n_users][k]
     int32_t* out_idx;
     int ablate;         // measurement only (CRH_SCORE_ABLATE): 1 = skip the selection epilogue
+    unsigned long long* wave_clock;   // measurement only (CRH_SCORE_TIMING): [wave][2] start/end wall clock
+    unsigned* xcd_sync;     // [8 XCD][1 + n_windows] zeroed counters, or NULL: keeps the waves of an XCD within
+    int sync_window;        // two windows of `sync_window` tiles of each other (see xcd_window_sync)
+    int64_t sync_stride;    // counters per XCD
 };
 
 // in : lane (i,0) holds k = 8q+0..3 of row i, lane (i,1) holds k = 8q+4..7
@@ -211,6 +218,30 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
     tau_reg = wave_list_tau(w.ls + my * K, w.cnt[my], K);
 }
 
+// Soft lockstep of the waves of one XCD.  Every wave streams the same item tiles, but left alone the waves
+// drift apart (the older wave of a SIMD pair gets ~80 % of the matrix pipe) until their working set no
+// longer fits the XCD's 4 MiB L2: the L2 hit rate drops to ~50 % and every wave's stream goes out to the
+// fabric (5.5 TB per launch at S-EVAL against a 5 GB table; the fp16 build is bound by exactly this).
+// Protocol: a wave adds itself to done[w] when it finishes window w (= sync_window tiles) and does not start
+// window w+2 before every REGISTERED wave of its XCD finished window w.  Only resident waves register, the
+// wait is bounded, and a wave that times out stops synchronising, so this can slow a launch down but never
+// hang or change its result.  All counters of an XCD are touched by that XCD only (one L2: coherent).
+__device__ __forceinline__ bool xcd_window_sync(unsigned* cnt, int64_t win, int lane) {
+    bool ok = true;
+    if (lane == 0) {
+        if (win >= 1) __hip_atomic_fetch_add(cnt + 1 + (win - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (win >= 2) {
+            int spins = 0;
+            while (__hip_atomic_load(cnt + 1 + (win - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                   __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > 200000) { ok = false; break; }      // ~0.2 s: give up, run free
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+}
+
 // OCC = waves per SIMD the kernel is built for:
 //   1: two register tiles (A double-buffered), ~320 VGPR+AGPR, one wave per SIMD;
 //   2: one register tile reloaded chunk by chunk right behind its last use, <= 256 registers, so a
@@ -233,6 +264,13 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     if (ug >= a.n_ugroups) return;
     const int K = a.k;
     const int i = lane & 31, h = lane >> 5;
+    if (a.wave_clock && lane == 0) a.wave_clock[2 * vb] = wall_clock64();
+    unsigned* sync_cnt = nullptr;
+    if (a.xcd_sync) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
+        sync_cnt = a.xcd_sync + (int64_t)xcc * a.sync_stride;
+        if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     WaveLds<UPW> w;
     {
@@ -351,10 +389,26 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         } else {
             f32x4 ta[NCH];
             load_tile(ta, t0);
-            for (int64_t t = t0; t < t1; ++t) do_tile(ta, t, tile_ptr(t + 1));
+            int64_t next_sync = sync_cnt ? t0 : t1 + 1;
+            for (int64_t t = t0; t < t1; ++t) {
+                if (t == next_sync) {
+                    const int64_t win = (t - t0) / a.sync_window;
+                    if (xcd_window_sync(sync_cnt, win, lane)) {
+                        next_sync += a.sync_window;
+                    } else {   // timed out: run free, and count this wave into every window it will not report
+                        next_sync = t1 + 1;
+                        const int64_t n_win = (t1 - t0 + a.sync_window - 1) / a.sync_window;
+                        if (lane == 0)
+                            for (int64_t wdw = win; wdw < n_win; ++wdw)
+                                __hip_atomic_fetch_add(sync_cnt + 1 + wdw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                do_tile(ta, t, tile_ptr(t + 1));
+            }
         }
     }
 
+    if (a.wave_clock && lane == 0) a.wave_clock[2 * vb + 1] = wall_clock64();
     // ---- write this split's lists: [split][slot][k], padded with (-inf, PAD)
     for (int j = 0; j < UPW; ++j) {
         const int64_t slot = ug * UPW + j;
@@ -435,6 +489,8 @@ size_t lists_bytes(int64_t n_users, int k) {   // worst case: 64 splits of (scor
     return (((size_t)64 * (size_t)n_users * (size_t)k * 8) + 255) & ~(size_t)255;
 }
 size_t packed_bytes(int64_t n_items, int d, int esz) { return (size_t)((n_items + 31) / 32) * 32 * (size_t)d * esz; }
+// window counters of the XCD lockstep: 8 XCDs x (1 + one per 8-tile window, the smallest window allowed)
+size_t sync_bytes(int64_t n_items) { return ((size_t)((n_items + 255) / 256 + 2) * 8 * sizeof(unsigned) + 255) & ~(size_t)255; }
 
 int pack_items(int esz, const void* item_emb, int64_t n_items, int d, void* pk, hipStream_t st) {
     const unsigned tiles = (unsigned)((n_items + 31) / 32);
@@ -532,6 +588,26 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
         a.packed = pk;
     }
     int rc;
+    // XCD soft lockstep (xcd_window_sync): only when every wave is resident at once (one round) and all waves
+    // walk the same tile range (no item-range cuts); counters sit behind the packed copy in the workspace
+    static const int sync_win = getenv("CRH_SCORE_SYNC_WINDOW") ? atoi(getenv("CRH_SCORE_SYNC_WINDOW")) : 128;
+    a.xcd_sync = nullptr;
+    a.sync_window = sync_win;
+    a.sync_stride = 0;
+    if (sync_win > 0 && occ == 2 && a.n_splits == 1 && a.n_ugroups <= 2048 && a.n_ugroups > 256 && a.packed) {
+        const int64_t n_win = (T + sync_win - 1) / sync_win;
+        const size_t need = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);
+        if (workspace_bytes >= need && (size_t)(n_win + 1) * 8 * sizeof(unsigned) <= sync_bytes(n_items)) {
+            a.sync_stride = n_win + 1;
+            a.xcd_sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + lists_bytes(n_users, k) +
+                                                     packed_bytes(n_items, d, esz));
+            CRH_HIP(hipMemsetAsync(a.xcd_sync, 0, (size_t)a.sync_stride * 8 * sizeof(unsigned), st));
+        }
+    }
+    static const int timing = getenv("CRH_SCORE_TIMING") ? atoi(getenv("CRH_SCORE_TIMING")) : 0;
+    a.wave_clock = nullptr;
+    const int64_t n_waves = a.n_ugroups * a.n_splits;
+    if (timing) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // measurement hook only
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
     if (esz == 4) {
         switch (d) {
@@ -555,6 +631,25 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     }
     if (rc != CRH_OK) return rc;
     if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
+    if (timing) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
+        CRH_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)n_waves * 2);
+        CRH_HIP(hipMemcpy(h.data(), a.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));
+        CRH_HIP(hipFree(a.wave_clock));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int64_t wv = 0; wv < n_waves; ++wv) { t0 = std::min(t0, h[2 * wv]); t1 = std::max(t1, h[2 * wv + 1]); }
+        std::vector<double> st_(n_waves), en_(n_waves);
+        for (int64_t wv = 0; wv < n_waves; ++wv) { st_[wv] = (double)(h[2 * wv] - t0); en_[wv] = (double)(h[2 * wv + 1] - t0); }
+        std::sort(st_.begin(), st_.end());
+        std::sort(en_.begin(), en_.end());
+        const double tot = (double)(t1 - t0);
+        fprintf(stderr, "[crh timing] waves=%lld span=%.0f ticks; start quantiles 0/25/50/75/100%%: %.3f %.3f %.3f %.3f %.3f; "
+                        "end quantiles 0/10/25/50/75/90/100%%: %.3f %.3f %.3f %.3f %.3f %.3f %.3f (fraction of span)\n",
+                (long long)n_waves, tot, st_[0] / tot, st_[n_waves / 4] / tot, st_[n_waves / 2] / tot,
+                st_[3 * n_waves / 4] / tot, st_[n_waves - 1] / tot, en_[0] / tot, en_[n_waves / 10] / tot,
+                en_[n_waves / 4] / tot, en_[n_waves / 2] / tot, en_[3 * n_waves / 4] / tot, en_[9 * n_waves / 10] / tot,
+                en_[n_waves - 1] / tot);
+    }
     if (a.n_splits > 1)
         return crh_merge_topk(a.out_score, a.out_idx, a.n_splits, n_users, k, k, out_score, out_idx, stream);
     return CRH_OK;
@@ -566,13 +661,14 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
 // row-major kernel, at ~0.9x the speed.
 extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
     if (n_users <= 0 || k <= 0) return 0;
-    return lists_bytes(n_users, k) + (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 4) : 0);
+    return lists_bytes(n_users, k) +
+           (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 4) + sync_bytes(n_items) : 0);
 }
 
 extern "C" size_t crh_score_topk_f16_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
     if (n_users <= 0 || k <= 0) return 0;
     return lists_bytes(n_users, k) +
-           (crh_score_topk_f16_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 2) : 0);
+           (crh_score_topk_f16_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 2) + sync_bytes(n_items) : 0);
 }
 
 extern "C" size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k) {

@@ -311,3 +311,23 @@ def test_f16_continuous_within_tolerance_of_fp64(d):
         assert np.all(S[r, i[r]] >= kth[r] - tol)
         assert np.all((s[r][:-1] > s[r][1:]) | ((s[r][:-1] == s[r][1:]) & (i[r][:-1] < i[r][1:])))
         assert len(set(i[r].tolist())) == k
+
+
+def test_xcd_lockstep_launch_is_exact():
+    """> 256 wave groups, no item-range cut, packed tiles: the launch runs with the XCD window lockstep
+    (waves of an XCD wait for each other every 128 tiles).  Results must equal the row-major kernel (which never
+    synchronises; checked inside the helper) and the oracle on sampled users."""
+    rng = np.random.default_rng(9)
+    n_users, n_items, d, k = 20000, 40000, 128, 20
+    U = (rng.standard_normal((n_users, d)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((n_items, d)) * 0.3).astype(np.float32)
+    rated = [np.unique(rng.integers(0, n_items, 8)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    bm = np.where(rng.random(n_items) < 0.2)[0]
+    s, i = _gpu_score_topk(U, None, V, k, rowptr, col, bm, n_splits=1)
+    pick = rng.choice(n_users, 96, replace=False)
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
+    assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
