@@ -167,14 +167,22 @@ struct WaveLds {
     float* ls;       // [UPW][K]
     int* li;         // [UPW][K]
     int* cnt;        // [UPW]
-    float* scratch;  // [16][64]
     int64_t* rlo;    // [UPW] bounds of each user's rated list (rated_rowptr staged once per wave)
     int64_t* rhi;    // [UPW]
 };
 
 template <int UPW>
 __host__ __device__ constexpr size_t wave_lds_bytes(int K) {
-    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + 16 * 64 * 4 + (size_t)UPW * 16;
+    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + (size_t)UPW * 16;
+}
+
+__device__ __forceinline__ float pick16(const f32x16& v, int r) {
+    const bool b0 = r & 1, b1 = r & 2, b2 = r & 4, b3 = r & 8;
+    const float p0 = b0 ? v[1] : v[0], p1 = b0 ? v[3] : v[2], p2 = b0 ? v[5] : v[4], p3 = b0 ? v[7] : v[6];
+    const float p4 = b0 ? v[9] : v[8], p5 = b0 ? v[11] : v[10], p6 = b0 ? v[13] : v[12], p7 = b0 ? v[15] : v[14];
+    const float q0 = b1 ? p1 : p0, q1 = b1 ? p3 : p2, q2 = b1 ? p5 : p4, q3 = b1 ? p7 : p6;
+    const float s0 = b2 ? q1 : q0, s1 = b2 ? q3 : q2;
+    return b3 ? s1 : s0;
 }
 
 // Slow path for one 32x32 accumulator tile (rare).  acc[r] = score of item row
@@ -185,10 +193,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
                                                int64_t item0, int64_t split_end, int lane) {
     unsigned cm = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        w.scratch[r * 64 + lane] = acc[r];
-        cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
-    }
+    for (int r = 0; r < 16; ++r) cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
     unsigned long long lanes = __ballot(cm != 0u);
     while (lanes) {
         const int L = __builtin_ctzll(lanes);
@@ -205,8 +210,9 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
             cmL &= cmL - 1;
             const int64_t il = item0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (il >= split_end) continue;   // clamped duplicate rows of the tail tile
-            float sc = __builtin_bit_cast(
-                float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.scratch[r * 64 + L])));
+            // r is wave-uniform: pick the accumulator register with a select tree (static indices only),
+            // then read lane L
+            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
             const int gi = (int)(a.item_base + il);
             const int n = __builtin_amdgcn_readfirstlane(w.cnt[ul]);
             if (wave_list_rejects(lsu, liu, n, K, sc, gi)) continue;
@@ -278,8 +284,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         w.ls = reinterpret_cast<float*>(base);
         w.li = reinterpret_cast<int*>(w.ls + UPW * K);
         w.cnt = w.li + UPW * K;
-        w.scratch = reinterpret_cast<float*>(w.cnt + UPW);
-        w.rlo = reinterpret_cast<int64_t*>(w.scratch + 16 * 64);
+        w.rlo = reinterpret_cast<int64_t*>(w.cnt + UPW);
         w.rhi = w.rlo + UPW;
     }
     for (int j = lane; j < UPW; j += 64) {
@@ -422,6 +427,193 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Workgroup-cooperative variant for fp16 tables.  At 16x the fp32 MFMA rate the per-wave item stream of the
+// kernel above is what bounds it: every wave pulls every tile through its CU's vector cache, and a CU sustains
+// only ~11 B/clk of L2 fills (measured: 17 % of the fp16 peak at d=256).  Here the 8 waves of a workgroup
+// (one CU, two per SIMD) walk the item tiles TOGETHER: each wave fetches 1/8 of a packed tile (global ->
+// registers, two tiles ahead), drops it into a two-slot LDS ring, and all 8 waves read their A fragments from
+// LDS -- 8x less L2 -> CU traffic.  One s_barrier per tile (LDS only: the prefetch loads stay in flight across
+// it).  Users, thresholds, lists and the slow path are per wave exactly as above, so results are identical.
+template <typename T, int D, int UW, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArgs a) {
+    constexpr int ROWB = D * (int)sizeof(T);
+    constexpr int NCH = ROWB / 32;
+    constexpr int UPW = 32 * UW;
+    constexpr int TILE_B = NCH * 1024;                 // one packed tile
+    constexpr int CPW = (NCH + NW - 1) / NW;           // chunks of a tile each wave fetches
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int S = a.n_splits;
+    const int split = (int)(blockIdx.x % S);
+    const int64_t ug_raw = (int64_t)(blockIdx.x / S) * NW + wave;
+    const bool live = ug_raw < a.n_ugroups;            // a dead wave still fetches and synchronises
+    const int64_t ug = live ? ug_raw : a.n_ugroups - 1;
+    const int K = a.k;
+    const int i = lane & 31, h = lane >> 5;
+
+    char* ring = smem;                                  // [2][TILE_B]
+    WaveLds<UPW> w;
+    {
+        char* base = smem + 2 * TILE_B + (size_t)wave * wave_lds_bytes<UPW>(K);
+        w.ls = reinterpret_cast<float*>(base);
+        w.li = reinterpret_cast<int*>(w.ls + UPW * K);
+        w.cnt = w.li + UPW * K;
+        w.rlo = reinterpret_cast<int64_t*>(w.cnt + UPW);
+        w.rhi = w.rlo + UPW;
+    }
+    for (int j = lane; j < UPW; j += 64) {
+        w.cnt[j] = 0;
+        const int64_t slot = ug * UPW + j;
+        const bool has = a.rated_rowptr && slot < a.n_users;
+        w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
+        w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
+    }
+
+    f32x4 b[NCH][UW];
+    float tau[UW];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        int64_t slot = ug * UPW + 32 * u + i;
+        if (slot >= a.n_users) slot = a.n_users - 1;
+        const int64_t row = a.users ? (int64_t)a.users[slot] : slot;
+        const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            b[q][u] = load16(up + 32 * q);
+            if constexpr (Elem<T>::kSwap) chunk_swap(b[q][u]);
+        }
+        tau[u] = CRH_NEG_INF;
+    }
+
+    // the user fragments must have LANDED before the loop: otherwise the compiler's vmcnt bookkeeping for them
+    // (needed in the first iteration only) also drains the tile prefetches of every later iteration
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+        for (int u = 0; u < UW; ++u) asm volatile("" : "+v"(b[q][u]));
+#endif
+    const int64_t NT = (a.n_items + 31) >> 5;
+    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
+    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
+    const char* packed = reinterpret_cast<const char*>(a.packed);
+
+    // this wave's share of tile t: chunks wave, wave+8, ... (1 KiB each, 16 B per lane)
+    auto fetch = [&](f32x4(&st)[CPW], int64_t t) {
+        if (t >= NT) t = NT - 1;
+        if (a.ablate & 2) t = 0;   // measurement only: every fetch hits the same (cached) tile
+        const char* tp = packed + t * TILE_B + lane * 16;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int q = wave + c * NW;
+            if (NCH % NW == 0 || q < NCH) st[c] = load16(tp + q * 1024);   // branch-free when 8 | NCH
+        }
+    };
+    auto commit = [&](const f32x4(&st)[CPW], int64_t t) {
+        char* dst = ring + (t & 1) * TILE_B + lane * 16;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int q = wave + c * NW;
+            if (NCH % NW == 0 || q < NCH) *reinterpret_cast<f32x4*>(dst + q * 1024) = st[c];
+        }
+    };
+    auto lds_barrier = [&]() {   // LDS traffic of this wave done, then meet; global prefetches keep flying
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt/expcnt untouched
+        __builtin_amdgcn_s_barrier();
+    };
+    auto compute = [&](int64_t t) {
+        const char* src = ring + (t & 1) * TILE_B + lane * 16;
+        f32x16 acc[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+        // A fragments come from LDS in groups of GR chunks, one group ahead of the MFMAs that consume them
+        constexpr int GR = NCH >= 8 ? 4 : NCH / 2;
+        f32x4 c[2][GR];
+#pragma unroll
+        for (int j = 0; j < GR; ++j) c[0][j] = *reinterpret_cast<const f32x4*>(src + j * 1024);
+#pragma unroll
+        for (int g = 0; g < NCH / GR; ++g) {
+            if (g + 1 < NCH / GR) {
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+                    c[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(src + ((g + 1) * GR + j) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < GR; ++j) Elem<T>::template mma<UW>(acc, c[g & 1][j], b[g * GR + j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (a.ablate & 1) {
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(acc[u]));
+#endif
+            }
+            return;
+        }
+        if (!live) return;
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+            float m = acc[u][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
+            if (__ballot(m > tau[u]) != 0ull)
+                tile_slow_path<UPW>(acc[u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a, t << 5, split_end, lane);
+        }
+    };
+
+    if (t0 < t1) {
+        f32x4 sa[CPW], sb[CPW];
+        fetch(sa, t0);
+        commit(sa, t0);                 // tile t0 -> slot t0&1
+        fetch(sa, t0 + 1);              // stage A: tile t0+1
+        fetch(sb, t0 + 2);              // stage B: tile t0+2
+        lds_barrier();
+        for (int64_t t = t0; t < t1; t += 2) {
+            commit(sa, t + 1);          // slot of tile t-1: every wave left it before the last barrier
+            fetch(sa, t + 3);
+            compute(t);
+            lds_barrier();
+            if (t + 1 >= t1) break;
+            commit(sb, t + 2);
+            fetch(sb, t + 4);
+            compute(t + 1);
+            lds_barrier();
+        }
+    }
+
+    if (live) {
+        for (int j = 0; j < UPW; ++j) {
+            const int64_t slot = ug * UPW + j;
+            if (slot >= a.n_users) break;
+            const int n = __builtin_amdgcn_readfirstlane(w.cnt[j]);
+            if (lane < K) {
+                const int64_t o = ((int64_t)split * a.n_users + slot) * K + lane;
+                a.out_score[o] = lane < n ? w.ls[j * K + lane] : CRH_NEG_INF;
+                a.out_idx[o] = lane < n ? w.li[j * K + lane] : CRH_PAD_IDX;
+            }
+        }
+    }
+}
+
+template <typename T, int D, int UW, int NW>
+int launch_score_wg(const ScoreArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)2 * (D * sizeof(T) / 32) * 1024 + NW * wave_lds_bytes<32 * UW>(a.k);
+    auto kern = score_topk_wg_kernel<T, D, UW, NW>;
+    CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    const int64_t blocks = ((a.n_ugroups + NW - 1) / NW) * a.n_splits;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), lds, stream, a);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
 template <typename T, int D, int UW, int OCC, bool PK>
 int launch_score_pk(const ScoreArgs& a, hipStream_t stream);
 
@@ -541,7 +733,21 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "%s: item ids exceed int32", who);
     CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "%s: n_splits=%d outside 0..64", who, n_splits);
 
-    const int upw = users_per_wave(esz, d);
+    // fp16: the workgroup-cooperative kernel (64 users per wave, 8 waves share the item tiles through LDS) once
+    // there are enough user groups to fill the CUs and the workspace holds the packed copy
+    static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
+    static const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;
+    const bool can_pack = !no_pack && workspace &&
+                          workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz);
+    // one 8-wave workgroup per CU (tiles shared 8 ways) when its lists fit the 160 KiB of LDS, else two 4-wave
+    // workgroups (large k); measured at k=20: 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two
+    // 4-wave groups 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
+    const size_t ring_b = (size_t)2 * (d * esz / 32) * 1024;
+    const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
+    const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
+    const bool use_wg = esz == 2 && wg_mode && can_pack && (d == 64 || d == 128 || d == 256) &&
+                        (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) && (n_users + 63) / 64 >= 512;
+    const int upw = use_wg ? 64 : users_per_wave(esz, d);
     ScoreArgs a;
     a.user_emb = user_emb;
     a.users = users;
@@ -579,9 +785,8 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     }
     // fragment-ordered copy of the shard (one HBM pass, ~0.1 % of a 128 K-user block at 10 M items) when the
     // workspace has room for it behind the partial lists
-    static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
     a.packed = nullptr;
-    if (!no_pack && workspace && workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz)) {
+    if (can_pack) {
         void* pk = reinterpret_cast<char*>(workspace) + lists_bytes(n_users, k);
         const int prc = pack_items(esz, item_emb, n_items, d, pk, st);
         if (prc != CRH_OK) return prc;
@@ -594,7 +799,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     a.xcd_sync = nullptr;
     a.sync_window = sync_win;
     a.sync_stride = 0;
-    if (sync_win > 0 && occ == 2 && a.n_splits == 1 && a.n_ugroups <= 2048 && a.n_ugroups > 256 && a.packed) {
+    if (sync_win > 0 && !use_wg && occ == 2 && a.n_splits == 1 && a.n_ugroups <= 2048 && a.n_ugroups > 256 && a.packed) {
         const int64_t n_win = (T + sync_win - 1) / sync_win;
         const size_t need = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);
         if (workspace_bytes >= need && (size_t)(n_win + 1) * 8 * sizeof(unsigned) <= sync_bytes(n_items)) {
@@ -619,6 +824,12 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
                 rc = occ == 2 ? launch_score<float, 128, 2, 2>(a, st) : launch_score<float, 128, 2, 1>(a, st);
                 break;
             default: rc = launch_score<float, 256, 1, 1>(a, st); break;
+        }
+    } else if (use_wg) {
+        switch (d) {
+            case 64: rc = wg_waves == 4 ? launch_score_wg<_Float16, 64, 2, 4>(a, st) : launch_score_wg<_Float16, 64, 2, 8>(a, st); break;
+            case 128: rc = wg_waves == 4 ? launch_score_wg<_Float16, 128, 2, 4>(a, st) : launch_score_wg<_Float16, 128, 2, 8>(a, st); break;
+            default: rc = wg_waves == 4 ? launch_score_wg<_Float16, 256, 2, 4>(a, st) : launch_score_wg<_Float16, 256, 2, 8>(a, st); break;
         }
     } else {
         switch (d) {

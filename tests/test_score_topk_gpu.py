@@ -331,3 +331,24 @@ def test_xcd_lockstep_launch_is_exact():
     sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
     ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("d,n_splits", [(256, 1), (128, 0), (64, 3)])
+def test_f16_workgroup_kernel_is_exact(d, n_splits):
+    """>= 512 groups of 64 users: fp16 launches use the workgroup-cooperative kernel (8 waves share the item tiles
+    through an LDS ring).  The helper demands bit-identity with the per-wave row-major kernel; sampled users are
+    checked against the canonical oracle on exact-arithmetic tables (odd sizes: dead waves, clamped tail tile)."""
+    rng = np.random.default_rng(d)
+    n_users, n_items, k = 32768 + 77, 5003, 20
+    U = (rng.integers(-8, 9, (n_users, d)) / 8).astype(np.float32)
+    V = (rng.integers(-8, 9, (n_items, d)) / 8).astype(np.float32)
+    rated = [np.unique(rng.integers(0, n_items, 6)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    bm = np.where(rng.random(n_items) < 0.2)[0]
+    s, i = _gpu_score_topk_f16(U.astype(np.float16), None, V.astype(np.float16), k, rowptr, col, bm, n_splits=n_splits)
+    pick = np.concatenate([rng.choice(n_users, 60, replace=False), [0, n_users - 1, 32767, 32768]])
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
+    assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
