@@ -13,9 +13,17 @@
 // 16-B-per-lane read; products are accumulated in edge (ascending column) order with fmaf, which is
 // the oracle's order (oracle/topk_oracle.c orc_spmm_csr), so results are reproducible bit for bit.
 // Catalogues are Zipf-shaped (a popular item has thousands of edges, a user a few dozen), so the
-// caller may pass a SCHEDULE built once per graph: rows are cut into segments of <= 64 edges, every
-// segment is one work item, and the few rows with several segments are finished by a small combine
-// kernel that adds their partials in segment order (still deterministic, association differs).
+// caller may pass a SCHEDULE built once per graph: rows of <= 64 edges are one work item of a lane
+// group; the few heavier rows get a whole wave each (its lane groups take the row's 64-edge segments
+// round robin and their partial sums are combined by shuffles in a fixed order: deterministic, the
+// association differs from the single chain).  One launch, no partials in memory.
+//
+// XCD-aware column slicing: for graphs whose dense operand does not fit one XCD's 4 MiB L2 but a column
+// slice of it does (CiteULike: 22.5 K rows x 512 B = 11.5 MB; a quarter = 2.9 MB), the feature columns
+// are cut into CS slices and block b works on slice (b % 8) % CS, so every XCD (blocks b % 8) gathers
+// from ONE slice only and its random row reads hit its own L2 instead of going out to the fabric.
+#include <stdlib.h>
+
 #include "crh_common.h"
 
 namespace {
@@ -32,7 +40,9 @@ struct SpmmArgs {
     float* acc_out;
     float s_in, s_out;
     crh_spmm_sched sched;   // n_seg == 0: one lane group per row
-    float* partial;         // [n_partial][d] partial sums of the rows cut into several segments
+    float* partial;         // unused (kept for the ABI's workspace argument)
+    int cs;                 // column slices (1, 2 or 4)
+    int64_t light_blocks;   // blocks per slice working on light work items; heavy rows follow
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -58,7 +68,7 @@ __device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f3
 
 // Accumulate edges [e0, e1) of one row into acc for this lane's 16-B column slice, in edge order.
 // The edge list is read G entries at a time (one per lane) and broadcast by shuffles; neighbour rows
-// are fetched 4 at a time before the dependent fma chain so several loads are in flight per group.
+// are fetched 8 (then 4) at a time before the dependent fma chain so several loads are in flight per group.
 template <int G>
 __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t e1, int c, bool on, int lig,
                                           f32x4& acc) {
@@ -68,6 +78,22 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
         const float my_val = e < e1 ? a.val[e] : 0.f;
         const int cnt = (int)((e1 - base) < G ? (e1 - base) : G);
         int t = 0;
+        for (; t + 8 <= cnt; t += 8) {
+            int cc[8];
+            float vv[8];
+            f32x4 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                cc[q] = __shfl(my_col, t + q, G);
+                vv[q] = __shfl(my_val, t + q, G);
+            }
+            if (on) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = reinterpret_cast<const f32x4*>(a.X + (int64_t)cc[q] * a.d)[c];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fma4(acc, vv[q], x[q]);
+            }
+        }
         for (; t + 4 <= cnt; t += 4) {
             int cc[4];
             float vv[4];
@@ -92,65 +118,81 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
     }
 }
 
-// Work item = one row (no schedule) or one segment of <= crh_spmm_segment_edges() edges of a row.
-// A row in one piece is finished here (bit-identical to the oracle's edge-order chain); a row cut
-// into several segments leaves one partial per segment and is finished by spmm_combine_kernel.
+// Block b -> (slice, work block): slice = (b % 8) % cs keeps every XCD on one column slice; the blocks of a
+// slice are numbered j = (b / 8) * (8 / cs) + (b % 8) / cs.
+// Light path: work item = one row (no schedule) or one single-segment row; a lane group of G lanes owns the
+// row's 16*G-byte column slice and finishes it (bit-identical to the oracle's edge-order chain).
+// Heavy path (rows with several segments): one wave per (row, slice).
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     const int lig = threadIdx.x % G;
-    const int64_t w0 = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
-    const int64_t wstride = (int64_t)gridDim.x * (256 / G);
-    const int nvec = a.d >> 2;
+    const int xcd = blockIdx.x & 7;
+    const int slice = xcd % a.cs;
+    const int64_t j = (int64_t)(blockIdx.x >> 3) * (8 / a.cs) + xcd / a.cs;
+    const int c = slice * G + lig;                   // this lane's float4 column
+    const bool on = c < (a.d >> 2);                  // d/4 not a power of two: the lane group is padded
     const bool seg = a.sched.n_seg > 0;
-    const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
-    for (int64_t w = w0; w < n_work; w += wstride) {
+    if (j < a.light_blocks) {
+        const int64_t w = j * (256 / G) + threadIdx.x / G;
+        const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
+        if (w >= n_work) return;
+        if (seg && a.sched.seg_slot[w] >= 0) return;            // part of a heavy row: done below
         const int64_t row = seg ? a.sched.seg_row[w] : w;
         const int64_t e0 = seg ? a.sched.seg_ptr[w] : a.rowptr[row];
         const int64_t e1 = seg ? a.sched.seg_ptr[w + 1] : a.rowptr[row + 1];
-        const int slot = seg ? a.sched.seg_slot[w] : -1;
-        for (int c0 = 0; c0 < nvec; c0 += G) {                  // one pass when d <= 4*G
-            const int c = c0 + lig;
-            const bool on = c < nvec;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            row_edges<G>(a, e0, e1, c, on, lig, acc);
-            if (on) {
-                if (slot < 0) store_row(a, row * a.d + (int64_t)c * 4, acc);
-                else *reinterpret_cast<f32x4*>(a.partial + (int64_t)slot * a.d + (int64_t)c * 4) = acc;
-            }
-        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        row_edges<G>(a, e0, e1, c, on, lig, acc);
+        if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
+        return;
     }
-}
-
-// Rows cut into several segments: sum the partials in segment order (deterministic), then epilogue.
-__global__ __launch_bounds__(256) void spmm_combine_kernel(SpmmArgs a) {
-    const int nvec = a.d >> 2;
-    const int64_t total = (int64_t)a.sched.n_multi * nvec;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int m = (int)(i / nvec), c = (int)(i - (int64_t)m * nvec);
-        const int first = a.sched.multi_first[m], cnt = a.sched.multi_count[m];
-        f32x4 acc = *reinterpret_cast<const f32x4*>(a.partial + (int64_t)first * a.d + c * 4);
-        for (int q = 1; q < cnt; ++q) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(a.partial + (int64_t)(first + q) * a.d + c * 4);
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-        }
-        store_row(a, (int64_t)a.sched.multi_row[m] * a.d + (int64_t)c * 4, acc);
+    // heavy rows: one block per (row, slice); the NGB lane groups of the block split the row's edge list;
+    // partial sums meet in a fixed order: shuffle tree inside a wave, then the 4 waves through LDS
+    __shared__ f32x4 wsum[4][G];
+    const int64_t m = j - a.light_blocks;
+    if (m >= a.sched.n_multi) return;
+    constexpr int NGB = 256 / G;
+    const int64_t row = a.sched.multi_row[m];
+    const int64_t r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
+    const int gg = threadIdx.x / G;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {   // the row is cut into NGB contiguous chunks (multiples of 8 edges): every lane group gets one
+        int64_t chunk = (r1 - r0 + NGB - 1) / NGB;
+        chunk = (chunk + 7) & ~(int64_t)7;
+        const int64_t e0 = r0 + (int64_t)gg * chunk;
+        const int64_t e1 = e0 + chunk < r1 ? e0 + chunk : r1;
+        if (e0 < r1) row_edges<G>(a, e0, e1, c, on, lig, acc);
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+        acc.x += __shfl_down(acc.x, off);
+        acc.y += __shfl_down(acc.y, off);
+        acc.z += __shfl_down(acc.z, off);
+        acc.w += __shfl_down(acc.w, off);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < G) wsum[wv][lig] = acc;
+    __syncthreads();
+    if (threadIdx.x < G && on) {
+        f32x4 t0 = wsum[0][lig], t1 = wsum[1][lig], t2 = wsum[2][lig], t3 = wsum[3][lig];
+        f32x4 r;
+        r.x = (t0.x + t1.x) + (t2.x + t3.x);
+        r.y = (t0.y + t1.y) + (t2.y + t3.y);
+        r.z = (t0.z + t1.z) + (t2.z + t3.z);
+        r.w = (t0.w + t1.w) + (t2.w + t3.w);
+        store_row(a, row * a.d + (int64_t)c * 4, r);
     }
 }
 
 template <int G>
-int launch_spmm(const SpmmArgs& a, hipStream_t st) {
+int launch_spmm(SpmmArgs a, hipStream_t st) {
     const int64_t per_block = 256 / G;
     const int64_t n_work = a.sched.n_seg > 0 ? a.sched.n_seg : a.n_rows;
-    int64_t blocks = (n_work + per_block - 1) / per_block;
-    if (blocks > 65535 * 4) blocks = 65535 * 4;
-    hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    a.light_blocks = (n_work + per_block - 1) / per_block;
+    const int64_t heavy_blocks = a.sched.n_seg > 0 ? (int64_t)a.sched.n_multi : 0;
+    const int64_t per_slice = a.light_blocks + heavy_blocks;
+    const int64_t groups8 = (per_slice + (8 / a.cs) - 1) / (8 / a.cs);      // grid in units of 8 blocks
+    hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)(groups8 * 8)), dim3(256), 0, st, a);
     CRH_HIP(hipGetLastError());
-    if (a.sched.n_seg > 0 && a.sched.n_multi > 0) {
-        int64_t cb = ((int64_t)a.sched.n_multi * (a.d / 4) + 255) / 256;
-        if (cb > 4096) cb = 4096;
-        hipLaunchKernelGGL(spmm_combine_kernel, dim3((unsigned)cb), dim3(256), 0, st, a);
-        CRH_HIP(hipGetLastError());
-    }
     return CRH_OK;
 }
 
@@ -159,7 +201,9 @@ int launch_spmm(const SpmmArgs& a, hipStream_t st) {
 extern "C" int crh_spmm_segment_edges(void) { return 64; }
 
 extern "C" size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d) {
-    return sched && sched->n_seg > 0 ? (size_t)sched->n_partial * (size_t)d * 4 : 0;
+    (void)sched;
+    (void)d;
+    return 0;   // heavy rows are combined inside their wave: no partial sums in memory any more
 }
 
 extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
@@ -172,24 +216,38 @@ extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const
     CRH_CHECK_ARG(y != x && acc_out != x, "crh_spmm_csr_f32: outputs must not alias x");
     CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out | (uintptr_t)workspace) & 15) == 0,
                   "crh_spmm_csr_f32: dense operands must be 16-byte aligned");
-    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr};
+    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0};
+    (void)workspace;
+    (void)workspace_bytes;
     if (sched && sched->n_seg > 0) {
         CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "crh_spmm_csr_f32: incomplete schedule");
-        CRH_CHECK_ARG(sched->n_multi == 0 || (sched->multi_row && sched->multi_first && sched->multi_count),
-                      "crh_spmm_csr_f32: incomplete schedule (multi-segment rows)");
-        const size_t need = crh_spmm_workspace_bytes(sched, d);
-        if (need && (!workspace || workspace_bytes < need)) {
-            crh_set_error("crh_spmm_csr_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-            return CRH_ERR_WS;
-        }
+        CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "crh_spmm_csr_f32: incomplete schedule (heavy rows)");
         a.sched = *sched;
-        a.partial = reinterpret_cast<float*>(workspace);
     } else {
         a.sched.n_seg = 0;
         a.sched.n_multi = 0;
     }
+    // column slices: as few as make one slice of the dense operand fit an XCD's L2 (leaving room for the
+    // edge stream), at most 4, and only while a slice keeps >= 4 lanes (64 B) per row
+    const int nvec = d / 4;
+    static const int force_cs = getenv("CRH_SPMM_SLICES") ? atoi(getenv("CRH_SPMM_SLICES")) : 0;
+    int cs = 1;
+    const double bytes = (double)n_rows * d * 4;
+    if (sched && sched->n_seg > 0 && bytes > 3.0e6 && bytes <= 4 * 3.2e6) {
+        while (cs < 4 && bytes / cs > 3.2e6) cs <<= 1;
+        // every slice re-reads the edge list (8 B per edge): only worth it while that stays below the operand
+        while (cs > 1 && (double)sched->nnz * 8.0 * cs > bytes) cs >>= 1;
+    }
+    if (force_cs) cs = force_cs;
+    while (cs > 1 && (nvec % cs != 0 || nvec / cs < 4)) cs >>= 1;
+    a.cs = cs;
     int G = 1;
-    while (G < d / 4 && G < 64) G <<= 1;
+    while (G < nvec / cs && G < 64) G <<= 1;
+    CRH_CHECK_ARG(G * cs == nvec || cs == 1, "crh_spmm_csr_f32: internal slice error");
+    if (G * cs != nvec) {   // d/4 not a power of two (or > 64 lanes): fall back to one slice, padded lane group
+        a.cs = 1;
+    }
+    CRH_CHECK_ARG(a.cs > 1 || G >= nvec, "crh_spmm_csr_f32: d=%d above 256 is not supported", d);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (G) {
         case 1: return launch_spmm<1>(a, st);

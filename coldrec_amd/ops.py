@@ -366,17 +366,14 @@ class SpmmSchedule:
                                 _lib.ptr(self.t[3]) if len(multi_row) else None,
                                 _lib.ptr(self.t[4]) if len(multi_row) else None,
                                 _lib.ptr(self.t[5]) if len(multi_row) else None, len(multi_row),
-                                int(multi_first[-1]))
+                                int(multi_first[-1]), int(rp[-1]))
         self.n_partial = int(multi_first[-1])
         self.n_seg = len(seg_row)
         self._ws = {}
 
     def workspace(self, d: int, device) -> Optional[torch.Tensor]:
-        if self.n_partial == 0:
-            return None
-        if d not in self._ws:
-            self._ws[d] = torch.empty((self.n_partial, d), dtype=torch.float32, device=device)
-        return self._ws[d]
+        """Heavy rows are combined on chip: crh_spmm_workspace_bytes() is 0 and no scratch is needed."""
+        return None
 
 
 def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0,

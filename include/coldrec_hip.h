@@ -193,11 +193,16 @@ void crh_adam_step_scalars_host(double lr, double beta1, double beta2, int64_t s
  * sched (HOST struct of DEVICE pointers, or NULL): optional load-balancing schedule built once per
  * graph -- rows cut into segments of at most crh_spmm_segment_edges() edges:
  *     seg_row[s], seg_ptr[s..s+1] (edge range), seg_slot[s] (-1: the row is in one piece and is
- *     finished by its segment; >= 0: index of this segment's partial sum), for n_seg segments;
- *     multi_row[m], multi_first[m], multi_count[m]: the rows with several segments and their
- *     consecutive partial slots; n_partial = total partial slots.
- * workspace: crh_spmm_workspace_bytes(sched, d) bytes (0 without schedule).  Without a schedule one
- * lane group walks each row (bit-identical to the edge-order fma chain).
+ *     finished by a lane group, bit-identical to the edge-order fma chain; >= 0: the row is "heavy"),
+ *     for n_seg segments; multi_row[m]: the n_multi heavy rows -- each is given to a whole workgroup whose
+ *     lane groups split its edge list and combine their partial sums in a fixed order (deterministic; the
+ *     association differs from the single chain); multi_first / multi_count / n_partial describe the
+ *     segments of the heavy rows (informational); nnz = number of stored edges.
+ * With a schedule, and when the dense operand is larger than one XCD's L2 but a half / quarter of its columns
+ * is not (and the edge list is small against it), the feature columns are processed in 2 / 4 slices pinned
+ * to XCDs (block b -> slice (b % 8) % slices) so the random row gathers stay in that XCD's L2.
+ * workspace: unused since the heavy rows are combined on chip (crh_spmm_workspace_bytes returns 0).
+ * Without a schedule one lane group walks each row (bit-identical to the edge-order fma chain).
  */
 typedef struct {
     const int32_t* seg_row;
@@ -209,6 +214,7 @@ typedef struct {
     const int32_t* multi_count;
     int32_t n_multi;
     int64_t n_partial;
+    int64_t nnz;
 } crh_spmm_sched;
 int crh_spmm_segment_edges(void);
 size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d);

@@ -404,3 +404,29 @@ def test_dp_engines_world1_match_plain_engines():
         na, nb = float(a.E.norm()), float(b.E.norm())
         assert abs(na - nb) <= 1e-5 * na
         assert float((a.E - b.E).norm()) <= 1e-4 * na
+
+
+@pytest.mark.parametrize("n_u,n_i,d", [(9000, 3000, 128), (15000, 7000, 128), (15000, 7000, 64), (30000, 2000, 32)])
+def test_spmm_xcd_column_slices(n_u, n_i, d):
+    """Operand sizes where crh_spmm_csr_f32 cuts the feature columns into 2 or 4 XCD-resident slices (and one
+    where it does not): single-segment rows stay bit-identical to the oracle's chain, heavy rows (one wave each,
+    shuffle combine) agree to rounding, with and without the schedule."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(n_u + d)
+    w = 1.0 / np.arange(1, n_i + 1) ** 0.9
+    nnz = 12 * n_u
+    key = np.unique(rng.integers(0, n_u, nnz) * n_i + rng.choice(n_i, nnz, p=w / w.sum()))
+    rowptr, col, val = orc.norm_adj_csr(key // n_i, key % n_i, n_u, n_i)
+    deg = np.diff(rowptr)
+    assert deg.max() > 64
+    X = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
+    tX = t(X)
+    want = orc.spmm(rowptr, col, val, X)
+    Y0, Y1 = torch.empty_like(tX), torch.empty_like(tX)
+    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y0)
+    np.testing.assert_array_equal(Y0.cpu().numpy(), want)
+    sched = ops.SpmmSchedule(rowptr, DEV)
+    ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y1, sched=sched)
+    one = deg <= 64
+    np.testing.assert_array_equal(Y1.cpu().numpy()[one], want[one])
+    np.testing.assert_allclose(Y1.cpu().numpy()[~one], want[~one], rtol=1e-5, atol=1e-6)
