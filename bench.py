@@ -274,6 +274,7 @@ def main():
                     help="'warm' = rated CSR + 20%% cold-item bitmap (default); 'none' = diagnostic run without masks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary train legs (N=1 only)")
+    ap.add_argument("--train-only", action="store_true", help="only the two secondary train legs (profiling aid)")
     ap.add_argument("--train-xl", action="store_true",
                     help="only run the S-TRAIN-XL roofline case of SURVEY.md 8(d) (1M users x 10M items, d=128, "
                          "B=65536 MF steps; 22.5 GB of state) and print its JSON line")
@@ -299,6 +300,9 @@ def main():
 
     if args.train_xl:
         print(json.dumps(train_xl(dev, args.steps, args.warmup)), flush=True)
+        return
+    if args.train_only:
+        print(json.dumps(train_legs(dev, not args.no_cpu_baseline)), flush=True)
         return
 
     I, d, k, Bu = args.items, args.dim, args.k, args.users_per_step

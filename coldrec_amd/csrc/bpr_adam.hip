@@ -26,6 +26,7 @@ namespace {
 
 constexpr int BPR_THREADS = 256;
 constexpr int BPR_MAX_BLOCKS = 1024;
+constexpr int BPR_HEAVY = 32;      // entries of one gradient row above which a whole block sums it
 
 struct BprArgs {
     const float* tu;   // user-side table      (rows x d)
@@ -49,6 +50,8 @@ struct BprArgs {
                            // split, where they were all-reduced over the ranks -- or NULL: reduce `partials`
     float* sums_out;       // [4] forward-only entry point: where bpr_sums_kernel leaves the batch sums
     int64_t B_global;      // batch size the means / norms refer to (== B unless data-parallel)
+    int32_t* heavy;        // [0] = count (zeroed by the forward kernel), [4..] = plan slots of rows with more
+                           // than BPR_HEAVY entries: found by the light backward pass, finished by one block each
 };
 
 template <int G>
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(BprArgs a) {
     const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
     const int nvec = a.d >> 2;
     float su = 0.f, sp = 0.f, sn = 0.f, sl = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.heavy) a.heavy[0] = 0;
     for (int64_t b = gid; b < a.B; b += gstride) {
         const int64_t ru = a.iu ? a.iu[b] : b, rp = a.ip ? a.ip[b] : b, rn = a.in_ ? a.in_[b] : b;
         const f32x4* pu = reinterpret_cast<const f32x4*>(a.tu + ru * a.d);
@@ -194,74 +198,229 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_kernel(BprArgs a) {
 // row of the dense gradient table (which is zero everywhere else): no atomics, bit-reproducible.
 __host__ __device__ inline int64_t plan_ints(int64_t L) { return 3 + (3 * L + 1) + (6 * L + 1); }
 
+struct PlanView {
+    int n_u, n_i;
+    const int32_t *urow, *uptr, *ulist, *irow, *iptr, *ilist;
+};
+
+__device__ __forceinline__ PlanView plan_view(const int32_t* pl) {
+    PlanView v;
+    v.n_u = pl[0];
+    v.n_i = pl[1];
+    const int64_t L = pl[2];
+    v.urow = pl + 3;
+    v.uptr = v.urow + L;
+    v.ulist = v.uptr + (L + 1);
+    v.irow = v.ulist + L;
+    v.iptr = v.irow + 2 * L;
+    v.ilist = v.iptr + (2 * L + 1);
+    return v;
+}
+
+struct BwdCoef {
+    float invB, cu, cp, cn;
+};
+
+// Sum the contributions of plan entries [e0, e1) of ONE gradient row into acc (this lane's 16-B column slice),
+// in list order.  The entries' metadata (triple id -> score difference, the other rows' ids) is fetched G at a
+// time, one entry per lane, and broadcast by shuffles; the rows the entries point at are fetched 4 at a time
+// before the dependent adds, so the chain of a row costs one latency per 4 entries instead of 4 per entry.
+//   user row u:      d/du  = g (p - n) + cu u          (own = u; two gathered rows per entry)
+//   item row, pos:   d/dp  = g u + cp p                (own = p; one gathered row per entry)
+//   item row, neg:   d/dn  = -g u + cn n               (own = n)
+template <int G>
+__device__ __forceinline__ void grad_row_entries(const BprArgs& a, const BwdCoef& k, bool user_side,
+                                                 const int32_t* list, int e0, int e1, int c, bool on, int lig,
+                                                 const f32x4& own, f32x4& acc) {
+    for (int base = e0; base < e1; base += G) {
+        const int e = base + lig;
+        float g = 0.f;
+        int ra = 0, rb = 0, role = 0;
+        if (e < e1) {
+            const int ent = list[e];
+            const int b = ent & 0x3fffffff;
+            role = ent >> 30;
+            const float x = a.xbuf[b];
+            const float sig = 1.0f / (1.0f + expf(-x));
+            g = -k.invB * sig * (1.0f - sig) / (1e-5f + sig);
+            if (user_side) {
+                ra = a.ip[b];
+                rb = a.in_[b];
+            } else {
+                ra = a.iu[b];
+            }
+        }
+        const int cnt = (e1 - base) < G ? (e1 - base) : G;
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) {
+            float gg[4];
+            int aa[4], bb[4], rr[4];
+            f32x4 xa[4], xb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gg[q] = __shfl(g, t + q, G);
+                aa[q] = __shfl(ra, t + q, G);
+                bb[q] = __shfl(rb, t + q, G);
+                rr[q] = __shfl(role, t + q, G);
+            }
+            if (on) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (user_side) {
+                        xa[q] = reinterpret_cast<const f32x4*>(a.tp + (int64_t)aa[q] * a.d)[c];
+                        xb[q] = reinterpret_cast<const f32x4*>(a.tn + (int64_t)bb[q] * a.d)[c];
+                    } else {
+                        xa[q] = reinterpret_cast<const f32x4*>(a.tu + (int64_t)aa[q] * a.d)[c];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (user_side) {
+                        acc.x += gg[q] * (xa[q].x - xb[q].x) + k.cu * own.x;
+                        acc.y += gg[q] * (xa[q].y - xb[q].y) + k.cu * own.y;
+                        acc.z += gg[q] * (xa[q].z - xb[q].z) + k.cu * own.z;
+                        acc.w += gg[q] * (xa[q].w - xb[q].w) + k.cu * own.w;
+                    } else {
+                        const float sg = rr[q] == 0 ? gg[q] : -gg[q];
+                        const float cc = rr[q] == 0 ? k.cp : k.cn;
+                        acc.x += sg * xa[q].x + cc * own.x;
+                        acc.y += sg * xa[q].y + cc * own.y;
+                        acc.z += sg * xa[q].z + cc * own.z;
+                        acc.w += sg * xa[q].w + cc * own.w;
+                    }
+                }
+            }
+        }
+        for (; t < cnt; ++t) {
+            const float gq = __shfl(g, t, G);
+            const int aq = __shfl(ra, t, G), bq = __shfl(rb, t, G), rq = __shfl(role, t, G);
+            if (on) {
+                if (user_side) {
+                    const f32x4 p = reinterpret_cast<const f32x4*>(a.tp + (int64_t)aq * a.d)[c];
+                    const f32x4 n = reinterpret_cast<const f32x4*>(a.tn + (int64_t)bq * a.d)[c];
+                    acc.x += gq * (p.x - n.x) + k.cu * own.x;
+                    acc.y += gq * (p.y - n.y) + k.cu * own.y;
+                    acc.z += gq * (p.z - n.z) + k.cu * own.z;
+                    acc.w += gq * (p.w - n.w) + k.cu * own.w;
+                } else {
+                    const f32x4 u = reinterpret_cast<const f32x4*>(a.tu + (int64_t)aq * a.d)[c];
+                    const float sg = rq == 0 ? gq : -gq;
+                    const float cc = rq == 0 ? k.cp : k.cn;
+                    acc.x += sg * u.x + cc * own.x;
+                    acc.y += sg * u.y + cc * own.y;
+                    acc.z += sg * u.z + cc * own.z;
+                    acc.w += sg * u.w + cc * own.w;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ BwdCoef bwd_coef(const BprArgs& a, const float* tot) {
+    BwdCoef k;
+    k.invB = 1.0f / (float)a.B_global;
+    const float nu_ = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) {
+        a.loss_out[0] = tot[3] * k.invB;
+        a.loss_out[1] = a.reg * (nu_ * k.invB + np_ * k.invB + nn * k.invB);
+    }
+    // d(reg*|X|_F/B)/dX = reg * X / (B*|X|_F)   (0 at X = 0, as autograd returns)
+    k.cu = nu_ > 0.f ? a.reg * k.invB / nu_ : 0.f;
+    k.cp = np_ > 0.f ? a.reg * k.invB / np_ : 0.f;
+    k.cn = nn > 0.f ? a.reg * k.invB / nn : 0.f;
+    return k;
+}
+
+// Light pass: one lane group per touched row with <= BPR_HEAVY entries (the row is summed in list order and
+// STORED); heavier rows are queued for bpr_bwd_heavy_kernel.  d <= 256 (one 16-B slice per lane).
 template <int G>
 __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a) {
     __shared__ float red[4];
     __shared__ float tot[4];
     batch_totals(a, tot, red);
-    const float invB = 1.0f / (float)a.B_global;
-    const float nu_ = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) {
-        a.loss_out[0] = tot[3] * invB;
-        a.loss_out[1] = a.reg * (nu_ * invB + np_ * invB + nn * invB);
-    }
-    const float cu = nu_ > 0.f ? a.reg * invB / nu_ : 0.f;
-    const float cp = np_ > 0.f ? a.reg * invB / np_ : 0.f;
-    const float cn = nn > 0.f ? a.reg * invB / nn : 0.f;
-
-    const int32_t* pl = a.plan;
-    const int n_u = pl[0], n_i = pl[1];
-    const int64_t L = pl[2];
-    const int32_t* urow = pl + 3;
-    const int32_t* uptr = urow + L;
-    const int32_t* ulist = uptr + (L + 1);
-    const int32_t* irow = ulist + L;
-    const int32_t* iptr = irow + 2 * L;
-    const int32_t* ilist = iptr + (2 * L + 1);
-
+    const BwdCoef k = bwd_coef(a, tot);
+    const PlanView pv = plan_view(a.plan);
     const int lig = threadIdx.x % G;
     const int64_t gid = (int64_t)blockIdx.x * (BPR_THREADS / G) + threadIdx.x / G;
     const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
     const int nvec = a.d >> 2;
-    for (int64_t w = gid; w < (int64_t)n_u + n_i; w += gstride) {
-        const bool user_side = w < n_u;
-        const int64_t row = user_side ? urow[w] : irow[w - n_u];
-        const int e0 = user_side ? uptr[w] : iptr[w - n_u];
-        const int e1 = user_side ? uptr[w + 1] : iptr[w - n_u + 1];
-        for (int c = lig; c < nvec; c += G) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int e = e0; e < e1; ++e) {
-                const int ent = user_side ? ulist[e] : ilist[e];
-                const int b = ent & 0x3fffffff;
-                const int role = ent >> 30;
-                const float x = a.xbuf[b];
-                const float sig = 1.0f / (1.0f + expf(-x));
-                const float g = -invB * sig * (1.0f - sig) / (1e-5f + sig);
-                const int64_t ru = a.iu[b], rp = a.ip[b], rn = a.in_[b];
-                const f32x4 u = reinterpret_cast<const f32x4*>(a.tu + ru * a.d)[c];
-                if (user_side) {
-                    const f32x4 p = reinterpret_cast<const f32x4*>(a.tp + rp * a.d)[c];
-                    const f32x4 n = reinterpret_cast<const f32x4*>(a.tn + rn * a.d)[c];
-                    acc.x += g * (p.x - n.x) + cu * u.x;
-                    acc.y += g * (p.y - n.y) + cu * u.y;
-                    acc.z += g * (p.z - n.z) + cu * u.z;
-                    acc.w += g * (p.w - n.w) + cu * u.w;
-                } else if (role == 0) {
-                    const f32x4 p = reinterpret_cast<const f32x4*>(a.tp + rp * a.d)[c];
-                    acc.x += g * u.x + cp * p.x;
-                    acc.y += g * u.y + cp * p.y;
-                    acc.z += g * u.z + cp * p.z;
-                    acc.w += g * u.w + cp * p.w;
-                } else {
-                    const f32x4 n = reinterpret_cast<const f32x4*>(a.tn + rn * a.d)[c];
-                    acc.x += -g * u.x + cn * n.x;
-                    acc.y += -g * u.y + cn * n.y;
-                    acc.z += -g * u.z + cn * n.z;
-                    acc.w += -g * u.w + cn * n.w;
-                }
-            }
-            float* dst = (user_side ? a.gu : a.gp) + row * a.d + c * 4;
-            *reinterpret_cast<f32x4*>(dst) = acc;
+    const bool on = lig < nvec;
+    for (int64_t w = gid; w < (int64_t)pv.n_u + pv.n_i; w += gstride) {
+        const bool user_side = w < pv.n_u;
+        const int64_t row = user_side ? pv.urow[w] : pv.irow[w - pv.n_u];
+        const int e0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
+        const int e1 = user_side ? pv.uptr[w + 1] : pv.iptr[w - pv.n_u + 1];
+        if (e1 - e0 > BPR_HEAVY) {
+            if (lig == 0) a.heavy[4 + atomicAdd(a.heavy, 1)] = (int32_t)w;
+            continue;
+        }
+        f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+        if (on) own = reinterpret_cast<const f32x4*>((user_side ? a.tu : a.tp) + row * a.d)[lig];
+        grad_row_entries<G>(a, k, user_side, user_side ? pv.ulist : pv.ilist, e0, e1, lig, on, lig, own, acc);
+        if (on) *reinterpret_cast<f32x4*>((user_side ? a.gu : a.gp) + row * a.d + lig * 4) = acc;
+    }
+}
+
+// Heavy pass: block i takes queued row i; its lane groups split the row's entry list into contiguous chunks
+// and the partial sums meet in a fixed order (shuffle tree inside a wave, the 4 waves through LDS), so the
+// result does not depend on the order in which rows were queued.
+template <int G>
+__global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_heavy_kernel(BprArgs a) {
+    __shared__ float red[4];
+    __shared__ float tot[4];
+    __shared__ f32x4 wsum[4][G];
+    const int n_heavy = a.heavy[0];
+    if ((int)blockIdx.x >= n_heavy) return;
+    if (a.totals) {
+        if (threadIdx.x < 4) tot[threadIdx.x] = a.totals[threadIdx.x];
+        __syncthreads();
+    } else {
+        batch_totals(a, tot, red);
+    }
+    BwdCoef k;
+    {
+        k.invB = 1.0f / (float)a.B_global;
+        const float nu_ = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
+        k.cu = nu_ > 0.f ? a.reg * k.invB / nu_ : 0.f;
+        k.cp = np_ > 0.f ? a.reg * k.invB / np_ : 0.f;
+        k.cn = nn > 0.f ? a.reg * k.invB / nn : 0.f;
+    }
+    const PlanView pv = plan_view(a.plan);
+    constexpr int NGB = BPR_THREADS / G;
+    const int lig = threadIdx.x % G, gg = threadIdx.x / G;
+    const int nvec = a.d >> 2;
+    const bool on = lig < nvec;
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const int64_t w = a.heavy[4 + h];
+        const bool user_side = w < pv.n_u;
+        const int64_t row = user_side ? pv.urow[w] : pv.irow[w - pv.n_u];
+        const int r0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
+        const int r1 = user_side ? pv.uptr[w + 1] : pv.iptr[w - pv.n_u + 1];
+        int chunk = (r1 - r0 + NGB - 1) / NGB;
+        chunk = (chunk + 3) & ~3;
+        const int e0 = r0 + gg * chunk;
+        const int e1 = e0 + chunk < r1 ? e0 + chunk : r1;
+        f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+        if (on) own = reinterpret_cast<const f32x4*>((user_side ? a.tu : a.tp) + row * a.d)[lig];
+        if (e0 < r1) grad_row_entries<G>(a, k, user_side, user_side ? pv.ulist : pv.ilist, e0, e1, lig, on, lig, own, acc);
+#pragma unroll
+        for (int off = G; off < 64; off <<= 1) {
+            acc.x += __shfl_down(acc.x, off);
+            acc.y += __shfl_down(acc.y, off);
+            acc.z += __shfl_down(acc.z, off);
+            acc.w += __shfl_down(acc.w, off);
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) < G) wsum[threadIdx.x >> 6][lig] = acc;
+        __syncthreads();
+        if (threadIdx.x < G && on) {
+            const f32x4 t0 = wsum[0][lig], t1 = wsum[1][lig], t2 = wsum[2][lig], t3 = wsum[3][lig];
+            f32x4 r;
+            r.x = (t0.x + t1.x) + (t2.x + t3.x);
+            r.y = (t0.y + t1.y) + (t2.y + t3.y);
+            r.z = (t0.z + t1.z) + (t2.z + t3.z);
+            r.w = (t0.w + t1.w) + (t2.w + t3.w);
+            *reinterpret_cast<f32x4*>((user_side ? a.gu : a.gp) + row * a.d + lig * 4) = r;
         }
     }
 }
@@ -505,7 +664,9 @@ extern "C" int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_id
 
 extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
     if (batch <= 0) return 0;
-    return (size_t)batch * 4 + (size_t)BPR_MAX_BLOCKS * 16 + 256;
+    // forward partials, per-triple score differences, queue of heavy gradient rows (<= 3B/33 of them)
+    return (size_t)BPR_MAX_BLOCKS * 16 + (((size_t)batch * 4 + 255) & ~(size_t)255) +
+           (size_t)(3 * batch / BPR_HEAVY + 8) * 4 + 256;
 }
 
 namespace {
@@ -524,6 +685,7 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
     CRH_CHECK_ARG((((uintptr_t)user_table | (uintptr_t)pos_table | (uintptr_t)neg_table | (uintptr_t)grad_user |
                     (uintptr_t)grad_pos | (uintptr_t)grad_neg) & 15) == 0,
                   "%s: tables must be 16-byte aligned", who);
+    CRH_CHECK_ARG(!plan || d <= 256, "%s: the deterministic (plan) backward handles d <= 256, got %d", who, d);
     CRH_CHECK_ARG(!plan || (grad_user && user_idx && pos_idx && neg_idx && grad_pos == grad_neg && pos_table == neg_table),
                   "%s: a plan needs index arrays, gradient tables and one shared item table", who);
     if (!workspace || workspace_bytes < crh_bpr_workspace_bytes(batch)) {
@@ -537,6 +699,7 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
     a.gu = grad_user; a.gp = grad_pos; a.gn = grad_neg;
     a.partials = reinterpret_cast<float*>(workspace);
     a.xbuf = a.partials + (size_t)BPR_MAX_BLOCKS * 4;
+    a.heavy = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.xbuf) + (((size_t)batch * 4 + 255) & ~(size_t)255));
     a.loss_out = loss_out;
     a.plan = plan;
     a.totals = totals;
@@ -565,7 +728,12 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
         if (plan) {
             int64_t rb = (3 * batch + per_block - 1) / per_block;      // <= 3B touched rows
             if (rb > BPR_MAX_BLOCKS) rb = BPR_MAX_BLOCKS;
+            if (!(phases & 1)) CRH_HIP(hipMemsetAsync(a.heavy, 0, 4, st));   // the forward normally zeroes it
             hipLaunchKernelGGL(bpr_bwd_rows_kernel<GG>, dim3((unsigned)rb), dim3(BPR_THREADS), 0, st, a);
+            CRH_HIP(hipGetLastError());
+            int64_t hb = 3 * batch / BPR_HEAVY + 1;                     // worst case; surplus blocks exit at once
+            if (hb > 512) hb = 512;
+            hipLaunchKernelGGL(bpr_bwd_heavy_kernel<GG>, dim3((unsigned)hb), dim3(BPR_THREADS), 0, st, a);
             CRH_HIP(hipGetLastError());
         } else if (bwd_blocks) {
             hipLaunchKernelGGL(bpr_bwd_kernel<GG>, dim3(bwd_blocks), dim3(BPR_THREADS), 0, st, a);
