@@ -543,6 +543,27 @@ struct AdamSeg {
     int64_t n4;   // elements / 4
 };
 
+// One Adam step of one element, op for op what torch/optim/adam.py _single_tensor_adam does.  Shared by the
+// dense kernel and by the touched-rows replay below so that both produce the same bits.
+struct AdamK {
+    float one_minus_b1, b2, one_minus_b2, eps;
+};
+__device__ __forceinline__ void adam_elem4(f32x4& p, f32x4& m, f32x4& v, const f32x4& g, const AdamK& k,
+                                           float bc2_sqrt, float neg_step_size) {
+    // every product and sum rounded on its own, as the separate ATen ops of the reference do -- and so that
+    // the compiler cannot fuse differently in the two kernels that share this function
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float mc = m[c] + k.one_minus_b1 * (g[c] - m[c]);        // exp_avg.lerp_(grad, 1-b1)
+        const float vc = v[c] * k.b2 + (k.one_minus_b2 * g[c]) * g[c];  // mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(vc) / bc2_sqrt + k.eps;               // sqrt()/bc2_sqrt + eps
+        p[c] = p[c] + neg_step_size * (mc / denom);                     // addcdiv_(m, denom, -step_size)
+        m[c] = mc;
+        v[c] = vc;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_dense_kernel(AdamSeg s0, AdamSeg s1, float one_minus_b1, float b2,
                                                          float one_minus_b2, float bc2_sqrt, float eps,
                                                          float neg_step_size, int zero_grad,
@@ -562,15 +583,77 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(AdamSeg s0, AdamSeg s1,
         f32x4* M = reinterpret_cast<f32x4*>(s.m) + j;
         f32x4* V = reinterpret_cast<f32x4*>(s.v) + j;
         f32x4 p = *P, g = *G, m = *M, v = *V;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            m[c] = m[c] + one_minus_b1 * (g[c] - m[c]);                 // exp_avg.lerp_(grad, 1-b1)
-            v[c] = v[c] * b2 + (one_minus_b2 * g[c]) * g[c];             // mul_(b2).addcmul_(g, g, 1-b2)
-            const float denom = sqrtf(v[c]) / bc2_sqrt + eps;            // sqrt()/bc2_sqrt + eps
-            p[c] = p[c] + neg_step_size * (m[c] / denom);                // addcdiv_(m, denom, -step_size)
-        }
+        const AdamK k{one_minus_b1, b2, one_minus_b2, eps};
+        adam_elem4(p, m, v, g, k, bc2_sqrt, neg_step_size);
         *P = p; *M = m; *V = v;
         if (zero_grad) *G = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ---------------------------------------------------------------- touched-rows replay of dense Adam
+// torch.optim.Adam moves EVERY row every step: a row whose gradient is zero still decays its
+// moments and drifts by its stale momentum.  At catalogue scale (S-TRAIN-XL: 11 M rows, 196 K touched per
+// step) the dense pass is 99.5 % of the step's HBM traffic.  But rows are independent and the update is
+// elementwise, so a row that is not touched between steps s and t can be brought up to date LATER by
+// replaying its zero-gradient steps s+1..t-1 in registers -- the same fp32 operations in the same order,
+// hence the same bits as the dense kernel -- provided the step-dependent factors of every step are at hand
+// (`table`: [step][2] = {sqrt(1-beta2^step), -lr/(1-beta1^step)}, step 1 at index 1).  `last[row]` is the
+// step the row's (p, m, v) are valid for.
+//   mode 0  catch-up  rows of the plan -> valid for step `step` - 1      (before the forward pass of `step`)
+//   mode 1  step      rows of the plan: apply step `step` with g = G[row], clear G[row]
+//   mode 2  flush     ALL rows -> valid for step `step`                   (before the tables are read)
+struct AdamRowsArgs {
+    float *p, *g, *m, *v;
+    int32_t* last;
+    int64_t n_rows;        // rows of the table (mode 2)
+    int d;
+    const int32_t* plan;   // modes 0/1: touched rows (users, then items offset by user_rows)
+    int64_t user_rows;
+    int64_t step;
+    const float* table;
+    AdamK k;
+    int mode;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void adam_rows_kernel(AdamRowsArgs a) {
+    const int lig = threadIdx.x % G;
+    const int64_t gid = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int64_t gstride = (int64_t)gridDim.x * (256 / G);
+    const int nvec = a.d >> 2;
+    int64_t n_work = a.n_rows;
+    PlanView pv{};
+    if (a.mode != 2) {
+        pv = plan_view(a.plan);
+        n_work = (int64_t)pv.n_u + pv.n_i;
+    }
+    for (int64_t w = gid; w < n_work; w += gstride) {
+        int64_t row = w;
+        if (a.mode != 2) row = w < pv.n_u ? (int64_t)pv.urow[w] : a.user_rows + pv.irow[w - pv.n_u];
+        const int64_t from = (int64_t)a.last[row] + 1;
+        const int64_t upto = a.mode == 0 ? a.step - 1 : (a.mode == 1 ? a.step - 1 : a.step);   // zero-gradient part
+        if (a.mode != 1 && from > upto) continue;
+        for (int c = lig; c < nvec; c += G) {
+            const int64_t o = row * a.d + (int64_t)c * 4;
+            f32x4 p = *reinterpret_cast<f32x4*>(a.p + o);
+            f32x4 m = *reinterpret_cast<f32x4*>(a.m + o);
+            f32x4 v = *reinterpret_cast<f32x4*>(a.v + o);
+            for (int64_t s = from; s <= upto; ++s) {
+                const float bc2_sqrt = a.table[2 * s], nss = a.table[2 * s + 1];
+                adam_elem4(p, m, v, f32x4{0.f, 0.f, 0.f, 0.f}, a.k, bc2_sqrt, nss);
+            }
+            if (a.mode == 1) {
+                const f32x4 g = *reinterpret_cast<f32x4*>(a.g + o);
+                const float bc2_sqrt = a.table[2 * a.step], nss = a.table[2 * a.step + 1];
+                adam_elem4(p, m, v, g, a.k, bc2_sqrt, nss);
+                *reinterpret_cast<f32x4*>(a.g + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            *reinterpret_cast<f32x4*>(a.p + o) = p;
+            *reinterpret_cast<f32x4*>(a.m + o) = m;
+            *reinterpret_cast<f32x4*>(a.v + o) = v;
+        }
+        // all lanes of the group have read last[row] before anyone overwrites it (same wave, in order)
+        if (lig == 0) a.last[row] = (int32_t)(a.mode == 0 ? a.step - 1 : a.step);
     }
 }
 
@@ -799,6 +882,38 @@ extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, in
                        (float)(-(lr / bc1)), zero_grad, step_scalars);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
+}
+
+
+// Touched-rows replay of dense Adam (see adam_rows_kernel).  p, g, m, v: (n_rows, d) fp32 tables, users first;
+// last_step (n_rows) int32, all zero at the start (every row valid for "step 0"); plan: a batch's reverse index
+// (crh_bpr_plan_build*), its item rows are offset by user_rows; scalar_table: device floats [2*(max_step+1)],
+// entry s = {sqrt(1-beta2^s), -lr/(1-beta1^s)} (crh_adam_step_scalars_host); mode 0/1/2 = catch-up / step /
+// flush.  Interleaving  catch-up(t) -> forward/backward(t) -> step(t)  for t = 1, 2, ... and a flush(T)
+// before the tables are read reproduces crh_adam_dense_f32 applied T times bit for bit.
+extern "C" int crh_adam_rows_f32(float* p, float* g, float* m, float* v, int32_t* last_step, int64_t n_rows, int d,
+                                 const int32_t* plan, int64_t batch, int64_t user_rows, int64_t step,
+                                 const float* scalar_table, double beta1, double beta2, double eps, int mode,
+                                 void* stream) {
+    CRH_CHECK_ARG(p && m && v && last_step && scalar_table && n_rows > 0, "crh_adam_rows_f32: NULL / empty table");
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_adam_rows_f32: d=%d must be a positive multiple of 4", d);
+    CRH_CHECK_ARG(mode >= 0 && mode <= 2, "crh_adam_rows_f32: mode %d outside 0..2", mode);
+    CRH_CHECK_ARG(mode == 2 || (plan && batch > 0), "crh_adam_rows_f32: modes 0/1 need the batch's plan");
+    CRH_CHECK_ARG(mode != 1 || g, "crh_adam_rows_f32: mode 1 needs the gradient table");
+    CRH_CHECK_ARG(step >= (mode == 2 ? 0 : 1), "crh_adam_rows_f32: step starts at 1");
+    AdamRowsArgs a{p, g, m, v, last_step, n_rows, d, plan, user_rows, step, scalar_table,
+                   AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps}, mode};
+    const int G = pick_group(d);
+    const int64_t work = mode == 2 ? n_rows : 3 * batch;
+    int64_t blocks = (work + (256 / G) - 1) / (256 / G);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dispatch_group(G, [&](auto gc) -> int {
+        constexpr int GG = decltype(gc)::value;
+        hipLaunchKernelGGL(adam_rows_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    });
 }
 
 // HOST helper: the two step-dependent Adam factors {sqrt(1-beta2^step), -lr/(1-beta1^step)} exactly as

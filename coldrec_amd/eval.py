@@ -8,6 +8,7 @@ no collective at all.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -32,6 +33,8 @@ class ShardedTopK:
         # injectable for the CPU (gloo) plumbing tests; the product path is the HIP ops
         self._local_topk = local_topk or ops.score_topk
         self._merge = merge or ops.merge_topk
+        # test hook: run the all-gather + merge even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.force_collective = bool(int(os.environ.get("CRH_FORCE_COLLECTIVE", "0")))
 
     def topk(self, user_emb, users, rated_rowptr=None, rated_col=None, cand_bitmap=None, n_splits: int = 0,
              kernel_events=None):
@@ -42,7 +45,7 @@ class ShardedTopK:
             kw["n_splits"] = n_splits
         s, i = self._local_topk(user_emb, users, self.items, self.k, rated_rowptr, rated_col, cand_bitmap,
                                 item_base=self.item_base, **kw)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return s, i
         import torch.distributed as dist
         packed = torch.cat([s.view(torch.int32), i], dim=1).contiguous()          # (Bu, 2k) int32

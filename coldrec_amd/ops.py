@@ -331,6 +331,19 @@ def adam_dense(p, g, m, v, step: int, lr: float = 1e-3, betas=(0.9, 0.999), eps:
     _lib.check(rc, "crh_adam_dense_f32")
 
 
+def adam_rows(p, g, m, v, last_step, plan, batch: int, user_rows: int, step: int, scalar_table, mode: int,
+              betas=(0.9, 0.999), eps: float = 1e-8):
+    """Touched-rows replay of dense Adam (crh_adam_rows_f32): mode 0 catch-up / 1 step / 2 flush."""
+    _need_cuda(p, g, m, v, last_step, plan, scalar_table)
+    assert last_step.dtype == torch.int32 and scalar_table.dtype == torch.float32
+    assert scalar_table.numel() >= 2 * (step + 1), "scalar table too short for this step"
+    rc = _lib.lib().crh_adam_rows_f32(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), _lib.ptr(last_step),
+                                      p.shape[0], p.shape[1], _lib.ptr(plan), int(batch), int(user_rows), int(step),
+                                      _lib.ptr(scalar_table), float(betas[0]), float(betas[1]), float(eps), int(mode),
+                                      _lib.current_stream())
+    _lib.check(rc, "crh_adam_rows_f32")
+
+
 class SpmmSchedule:
     """Load-balancing schedule of one CSR matrix (see crh_spmm_sched): rows cut into segments of at
     most crh_spmm_segment_edges() edges, built once per graph on the host with numpy."""

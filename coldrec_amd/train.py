@@ -114,7 +114,48 @@ class _TableState:
 
 
 class MFEngine(_TableState):
-    """model/MF.py:12-29 with the tables resident on the GPU."""
+    """model/MF.py:12-29 with the tables resident on the GPU.
+
+    ``enable_lazy_adam()`` switches the optimiser to the touched-rows replay of dense Adam
+    (crh_adam_rows_f32): per step only the rows of the batch are read and written, every other row is
+    brought up to date -- bit for bit what the dense pass would have produced -- when it is next touched or
+    when the tables are read (``forward()`` / ``sync_tables()``).  For catalogue-scale tables."""
+
+    lazy = False
+
+    def enable_lazy_adam(self) -> None:
+        assert self.dp is None, "the touched-rows optimiser is single-GPU"
+        self.lazy = True
+        self.last_step = torch.zeros(self.E.shape[0], dtype=torch.int32, device=self.device)
+        self._table = None
+        self._table_steps = 0
+        self._dirty = False
+
+    def _scalar_table(self, upto: int) -> torch.Tensor:
+        if self._table is None or upto > self._table_steps:
+            n = max(1024, 2 * upto)
+            sc = np.zeros((n + 1, 2), np.float32)
+            sc[1:] = ops.adam_step_scalars(1, n, self.lr)
+            self._table, self._table_steps = torch.from_numpy(sc).to(self.device), n
+        return self._table
+
+    def sync_tables(self) -> None:
+        """Bring every row up to the current step (no-op for the dense optimiser)."""
+        if self.lazy and self._dirty:
+            ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, None, 0, self.user_num, self.step_count,
+                          self._scalar_table(self.step_count), mode=2)
+            self._dirty = False
+
+    def _lazy_step(self, user_idx, pos_idx, neg_idx, plan, loss) -> None:
+        U, B, t = self.user_num, user_idx.shape[0], self.step_count + 1
+        if plan is None:
+            plan = ops.build_plans_device(user_idx, pos_idx, neg_idx, B)[0]
+        tab = self._scalar_table(t)
+        ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=0)
+        self.k.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
+                           self.G[:U], self.G[U:], self.G[U:], loss, plan=plan)
+        ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=1)
+        self.step_count, self._dirty = t, True
 
     def step(self, user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
              plan: Optional[torch.Tensor] = None, loss_out=None, step_scalars=None) -> None:
@@ -122,6 +163,8 @@ class MFEngine(_TableState):
         without atomics; without it gradients are accumulated with fp32 atomics."""
         U = self.user_num
         loss = self.loss if loss_out is None else loss_out
+        if self.lazy:
+            return self._lazy_step(user_idx, pos_idx, neg_idx, plan, loss)
         if self.dp is not None:
             self._dp_loss_grad(self.E[:U], self.E[U:], user_idx, pos_idx, neg_idx, self.G[:U], self.G[U:], loss)
             self.dp.all_reduce(self.G)
@@ -133,6 +176,7 @@ class MFEngine(_TableState):
                           step_scalars=step_scalars)
 
     def forward(self):
+        self.sync_tables()
         return self.user_emb, self.item_emb
 
 
@@ -212,7 +256,7 @@ class EpochRunner:
         self.plans = None
         self.scalars = torch.empty((len(self.steps), 2), dtype=torch.float32, device=dev)
         self.losses = torch.zeros((len(self.steps), 2), dtype=torch.float32, device=dev)
-        self.use_graph, self.graph, self.epochs_done = use_graph, None, 0
+        self.use_graph, self.graph, self.epochs_done = use_graph and not getattr(engine, "lazy", False), None, 0
 
     def _all_steps(self):
         for s, (lo, hi) in enumerate(self.steps):

@@ -185,6 +185,24 @@ int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0,
 void crh_adam_step_scalars_host(double lr, double beta1, double beta2, int64_t step, float* out2_host);
 
 /*
+ * Touched-rows replay of the same dense Adam, for tables whose gradient is zero in almost every row (BPR-MF at
+ * catalogue scale: SURVEY.md 8(d) S-TRAIN-XL touches 196 K of 11 M rows per step, and the dense pass is 99.5 % of
+ * the step's HBM traffic).  Rows are independent and the update is elementwise, so a row that was not touched
+ * between steps s and t is brought up to date later by replaying its zero-gradient steps s+1..t-1 in registers:
+ * the same fp32 operations in the same order as crh_adam_dense_f32, hence the same bits.
+ *   p, g, m, v   (n_rows, d) fp32 tables (users first); last_step (n_rows) int32, zero-initialised
+ *   plan         the batch's reverse index (crh_bpr_plan_build*); its item rows are offset by user_rows
+ *   scalar_table device floats [2 * (max_step + 1)]: entry s = crh_adam_step_scalars_host(lr, b1, b2, s)
+ *   mode 0  catch-up: rows of the plan become valid for step-1   (before the forward pass of `step`)
+ *   mode 1  step:     rows of the plan take step `step` with g = their gradient rows, which are cleared
+ *   mode 2  flush:    ALL rows become valid for `step`            (before the tables are read or saved)
+ * catch-up(t) -> crh_bpr_fwd_bwd_f32(plan) -> step(t) for t = 1, 2, ..., then flush(T), equals T dense steps.
+ */
+int crh_adam_rows_f32(float* p, float* g, float* m, float* v, int32_t* last_step, int64_t n_rows, int d,
+                      const int32_t* plan, int64_t batch, int64_t user_rows, int64_t step,
+                      const float* scalar_table, double beta1, double beta2, double eps, int mode, void* stream);
+
+/*
  * CSR SpMM with the LightGCN layer sum fused (model/LightGCN.py:88-93 and its autograd):
  *     P = A * x ;  y = P (if y) ;  acc_out = (acc_in * s_in + P) * s_out (if acc_out; acc_in NULL = 0)
  * rowptr (n_rows+1) int64, col int32 ascending per row, val fp32 (util/databuilder.py:220-254,953-962

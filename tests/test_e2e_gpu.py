@@ -192,3 +192,52 @@ def test_dropoutnet_fp16_ranking_close_to_fp32(tmp_path, monkeypatch):
     assert torch.equal(a.user_emb, b.user_emb) or float((a.user_emb - b.user_emb).norm()) < 1e-3 * float(a.user_emb.norm())
     for ra, rb in ((a.overall_test_results, b.overall_test_results), (a.cold_test_results, b.cold_test_results)):
         np.testing.assert_allclose(np.array(ra), np.array(rb), atol=6e-3)
+
+
+def test_rccl_allgather_merge_path_single_rank(tmp_path):
+    """One-rank RCCL process group on the 1-GPU box: bench.py's multi-GPU step (shard -> all_gather_into_tensor of
+    the packed top-k -> canonical merge) and the data-parallel trainer's two all-reduces run for real on RCCL,
+    and must reproduce the collective-free results."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, os.environ["CR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+from coldrec_amd import ops
+from coldrec_amd.eval import ShardedTopK
+from coldrec_amd.train import DPContext, MFEngine
+g = torch.Generator(device=dev).manual_seed(1)
+U = torch.randn(500, 64, generator=g, device=dev) * 0.2
+V = torch.randn(9000, 64, generator=g, device=dev) * 0.2
+want = ops.score_topk(U, None, V, 20)
+os.environ["CRH_FORCE_COLLECTIVE"] = "1"
+eng = ShardedTopK(V, 0, V.shape[0], 20, world=1, rank=0)
+got = eng.topk(U, None)
+torch.cuda.synchronize()
+assert torch.equal(got[1], want[1]) and torch.equal(got[0].view(torch.int32), want[0].view(torch.int32))
+rng = np.random.default_rng(0)
+U0 = (rng.standard_normal((300, 32)) * 0.1).astype(np.float32); V0 = (rng.standard_normal((400, 32)) * 0.1).astype(np.float32)
+a, b = MFEngine(U0, V0, 1e-2, 1e-3, dev), MFEngine(U0, V0, 1e-2, 1e-3, dev)
+b.enable_data_parallel(DPContext(1, 0))
+b.dp.world = 2; b.dp.slice = lambda n: (0, n)       # keep the whole batch but take the RCCL all-reduce branch
+import types
+def _ar(self, t):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+b.dp.all_reduce = types.MethodType(_ar, b.dp)
+for s in range(4):
+    tri = [torch.from_numpy(rng.integers(0, n, 256).astype(np.int32)).to(dev) for n in (300, 400, 400)]
+    a.step(*tri); b.step(*tri)
+assert abs(a.last_loss() - b.last_loss()) <= 1e-5 * abs(a.last_loss())
+assert float((a.E - b.E).norm()) <= 1e-4 * float(a.E.norm())
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+''')
+    env = dict(os.environ, CR_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

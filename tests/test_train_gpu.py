@@ -430,3 +430,41 @@ def test_spmm_xcd_column_slices(n_u, n_i, d):
     one = deg <= 64
     np.testing.assert_array_equal(Y1.cpu().numpy()[one], want[one])
     np.testing.assert_allclose(Y1.cpu().numpy()[~one], want[~one], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("d,B", [(64, 300), (128, 2048)])
+def test_lazy_adam_replay_is_bitwise_dense_adam(d, B):
+    """Touched-rows replay of dense Adam (crh_adam_rows_f32) vs the dense kernel on the same deterministic
+    gradients: after every step the ROWS OF THE NEXT BATCH, and after the flush the WHOLE tables (p, m, v), must be
+    bit-identical -- including rows never touched (pure zero-gradient decay) and rows touched on consecutive steps."""
+    from coldrec_amd import ops
+    from coldrec_amd.train import MFEngine
+    rng = np.random.default_rng(d)
+    n_u, n_i, steps = 3000, 5000, 25
+    U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
+    dense, lazy = MFEngine(U0, V0, 1e-2, 1e-3, DEV), MFEngine(U0, V0, 1e-2, 1e-3, DEV)
+    lazy.enable_lazy_adam()
+    hot = rng.integers(0, n_i, 40)                                 # a few items recur in most batches
+    for s in range(steps):
+        u = rng.integers(0, n_u, B).astype(np.int32)
+        i = np.where(rng.random(B) < 0.3, hot[rng.integers(0, 40, B)], rng.integers(0, n_i, B)).astype(np.int32)
+        j = rng.integers(0, n_i, B).astype(np.int32)
+        tu, ti, tj = t(u), t(i), t(j)
+        plan = ops.build_plans_device(tu, ti, tj, B)[0]
+        dense.step(tu, ti, tj, plan=plan)
+        lazy.step(tu, ti, tj, plan=plan)
+        assert torch.equal(dense.loss, lazy.loss), s               # same forward inputs -> same bits
+    torch.cuda.synchronize()
+    assert not torch.equal(dense.E, lazy.E)                        # untouched rows are still behind ...
+    ue, ie = lazy.forward()                                        # ... until the flush
+    assert torch.equal(dense.E.view(torch.int32), lazy.E.view(torch.int32))
+    assert torch.equal(dense.M.view(torch.int32), lazy.M.view(torch.int32))
+    assert torch.equal(dense.V.view(torch.int32), lazy.V.view(torch.int32))
+    assert int(lazy.last_step.min()) == steps and float(lazy.G.abs().max()) == 0.0
+    # training goes on after a flush
+    tu, ti, tj = t(rng.integers(0, n_u, B).astype(np.int32)), t(rng.integers(0, n_i, B).astype(np.int32)), t(rng.integers(0, n_i, B).astype(np.int32))
+    dense.step(tu, ti, tj, plan=ops.build_plans_device(tu, ti, tj, B)[0])
+    lazy.step(tu, ti, tj)
+    lazy.sync_tables()
+    assert torch.equal(dense.E.view(torch.int32), lazy.E.view(torch.int32))
