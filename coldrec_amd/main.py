@@ -79,6 +79,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--result_file', type=str, default='')
     p.add_argument('--result_overwrite', action='store_true')
     p.add_argument('--data_root', type=str, default='./data', help='(addition) where <dataset>/ lives')
+    p.add_argument('--lazy_adam', choices=['auto', 'on', 'off'], default='auto',
+                   help='(addition) BPR-MF only: replay dense Adam on the rows a batch touches (bit-identical to the '
+                        'dense pass, which it replaces when the tables are much larger than a batch)')
     p.add_argument('--score_dtype', choices=['fp32', 'fp16'], default='fp32',
                    help='(addition) table precision of the fused full-catalogue ranking: fp32 = exact, the '
                         'reference\'s arithmetic; fp16 = half tables, fp32 accumulation (16x the MFMA rate)')

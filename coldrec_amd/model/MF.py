@@ -50,6 +50,14 @@ class MF(BaseColdStartTrainer):
         dp = dp_from_env()            # one rank per GPU: shard every batch, all-reduce sums + gradient
         if dp is not None:
             eng.enable_data_parallel(dp)
+        else:
+            # catalogue-scale tables: replay dense Adam on the touched rows only (bit-identical, see
+            # crh_adam_rows_f32); 'auto' = when a batch touches under ~5 % of the rows
+            mode = getattr(self.args, 'lazy_adam', 'auto')
+            rows = self.data.user_num + self.data.item_num
+            if hasattr(eng, 'enable_lazy_adam') and type(eng).__name__ == 'MFEngine' and \
+                    (mode == 'on' or (mode == 'auto' and rows > 64 * self.batch_size)):
+                eng.enable_lazy_adam()
         # collectives are kept out of graph capture: the data-parallel epoch is launched eagerly
         runner = EpochRunner(eng, len(self.data.train_u), self.batch_size, use_graph=dp is None)
         for epoch in range(self.maxEpoch):

@@ -241,3 +241,20 @@ print("RCCL_OK")
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_mf_trainer_with_lazy_adam_matches_dense_trainer():
+    """--lazy_adam on: the MF trainer (eager epochs, touched-rows optimiser, flush before every validation) must
+    end with exactly the tables and metrics of the dense trainer."""
+    from coldrec_amd.model import AVAILABLE_MODELS
+    from coldrec_amd.util.utils import set_seed
+    outs = []
+    for mode in ("off", "on"):
+        _, data = builder()
+        set_seed(2024, True)
+        tr = AVAILABLE_MODELS["MF"](_cfg(data, lazy_adam=mode, epochs=3))
+        tr.run()
+        outs.append((tr.user_emb.clone(), tr.item_emb.clone(), tr.overall_test_results, tr.engine.lazy))
+    assert outs[0][3] is False and outs[1][3] is True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
