@@ -394,7 +394,9 @@ def main():
                    "users_per_step": Bu, "items": I, "dim": d, "k": k,
                    "parallelism": "item-row-shard x%d + all_gather(top-k) + canonical merge" % world if world > 1
                    else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "score_topk_kernel<%s,%d>" % (args.dtype, d), "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "score_topk%s_kernel<%s,%d>" % (
+                         "_wg" if (Bu + 63) // 64 >= 512 and (args.dtype == "f16" or d == 128) else "", args.dtype, d),
+                     "achieved": achieved,
                      "peak": peak_tf, "unit": "TFLOP/s", "frac": achieved / peak_tf,
                      "kernel_ms": kern_ms, "flops_per_launch": flops_per_launch, "traffic": None},
     }
@@ -402,7 +404,9 @@ def main():
         # grid of the kernel = 64 lanes x (groups of 64 users) x (item-range cuts the library picks: 1 once the
         # user groups fill the 2048 wave slots)
         groups = (Bu + 63) // 64
-        tr = measured_traffic("score_topk_kernel<float, 128, 2, 2, true>", float(64 * groups)) if groups >= 2048 else None
+        tr = None
+        if groups >= 2048:       # the library's choice for this shape: the workgroup-cooperative kernel
+            tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8>", float(64 * ((groups + 7) // 8) * 8))
         if tr:
             result["roofline"]["traffic"] = tr[0]
             result["roofline"]["traffic_note"] = ("L2-miss (fabric-side) bytes per launch from %s; mostly served by the "

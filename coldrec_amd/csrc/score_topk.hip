@@ -733,20 +733,22 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "%s: item ids exceed int32", who);
     CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "%s: n_splits=%d outside 0..64", who, n_splits);
 
-    // fp16: the workgroup-cooperative kernel (64 users per wave, 8 waves share the item tiles through LDS) once
-    // there are enough user groups to fill the CUs and the workspace holds the packed copy
+    // The workgroup-cooperative kernel (8 waves share the packed item tiles through LDS) once there are enough
+    // user groups to fill the CUs and the workspace holds the packed copy.  fp16: d = 64/128/256, 64 users per
+    // wave.  fp32: d = 128 (64 users per wave; +1.5 % over the per-wave kernel and 1/8 of its L2 -> CU traffic).
     static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
     static const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;
     const bool can_pack = !no_pack && workspace &&
                           workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz);
-    // one 8-wave workgroup per CU (tiles shared 8 ways) when its lists fit the 160 KiB of LDS, else two 4-wave
-    // workgroups (large k); measured at k=20: 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two
-    // 4-wave groups 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
+    // one 8-wave workgroup per CU when its lists fit the 160 KiB of LDS, else two 4-wave workgroups (large k);
+    // measured at k=20 (fp16): 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two 4-wave groups
+    // 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
     const size_t ring_b = (size_t)2 * (d * esz / 32) * 1024;
     const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
     const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
-    const bool use_wg = esz == 2 && wg_mode && can_pack && (d == 64 || d == 128 || d == 256) &&
-                        (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) && (n_users + 63) / 64 >= 512;
+    const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
+    const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
+                        (n_users + 63) / 64 >= 512;
     const int upw = use_wg ? 64 : users_per_wave(esz, d);
     ScoreArgs a;
     a.user_emb = user_emb;
@@ -812,9 +814,11 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     static const int timing = getenv("CRH_SCORE_TIMING") ? atoi(getenv("CRH_SCORE_TIMING")) : 0;
     a.wave_clock = nullptr;
     const int64_t n_waves = a.n_ugroups * a.n_splits;
-    if (timing) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // measurement hook only
+    if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // measurement hook only
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
-    if (esz == 4) {
+    if (esz == 4 && use_wg) {
+        rc = launch_score_wg<float, 128, 2, 8>(a, st);
+    } else if (esz == 4) {
         switch (d) {
             case 8: rc = launch_score<float, 8, 4, 1>(a, st); break;
             case 16: rc = launch_score<float, 16, 4, 1>(a, st); break;
@@ -842,7 +846,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     }
     if (rc != CRH_OK) return rc;
     if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
-    if (timing) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
+    if (timing && !use_wg) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
         CRH_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)n_waves * 2);
         CRH_HIP(hipMemcpy(h.data(), a.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));

@@ -352,3 +352,24 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
     sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
     ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("n_splits", [1, 0])
+def test_f32_workgroup_kernel_is_bit_exact(n_splits):
+    """fp32 d=128 launches with >= 512 user groups also run the workgroup-cooperative kernel (packed tiles through
+    LDS); its k-ordered MFMA chain must still be the oracle's fma chain bit for bit.  The helper checks bit-identity
+    with the per-wave row-major kernel; sampled users go against the C oracle."""
+    rng = np.random.default_rng(128 + n_splits)
+    n_users, n_items, d, k = 32768 + 77, 5003, 128, 20
+    U = (rng.standard_normal((n_users, d)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((n_items, d)) * 0.3).astype(np.float32)
+    rated = [np.unique(rng.integers(0, n_items, 6)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    bm = np.where(rng.random(n_items) < 0.2)[0]
+    s, i = _gpu_score_topk(U, None, V, k, rowptr, col, bm, n_splits=n_splits)
+    pick = np.concatenate([rng.choice(n_users, 60, replace=False), [0, n_users - 1, 32767, 32768]])
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
+    assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
