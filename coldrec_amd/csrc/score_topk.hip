@@ -176,6 +176,16 @@ __host__ __device__ constexpr size_t wave_lds_bytes(int K) {
     return (size_t)UPW * K * 8 + (size_t)UPW * 4 + (size_t)UPW * 16;
 }
 
+// maximum of the 16 accumulator registers as a depth-3 tree of 3-input maxima (v_max3_f32): the wave waits
+// for this chain between two tiles, and a sequential chain of 15 is ~4x longer
+__device__ __forceinline__ float max16(const f32x16& v) {
+    const float a0 = fmaxf(fmaxf(v[0], v[1]), v[2]), a1 = fmaxf(fmaxf(v[3], v[4]), v[5]);
+    const float a2 = fmaxf(fmaxf(v[6], v[7]), v[8]), a3 = fmaxf(fmaxf(v[9], v[10]), v[11]);
+    const float a4 = fmaxf(fmaxf(v[12], v[13]), v[14]);
+    const float b0 = fmaxf(fmaxf(a0, a1), a2), b1 = fmaxf(fmaxf(a3, a4), v[15]);
+    return fmaxf(b0, b1);
+}
+
 __device__ __forceinline__ float pick16(const f32x16& v, int r) {
     const bool b0 = r & 1, b1 = r & 2, b2 = r & 4, b3 = r & 8;
     const float p0 = b0 ? v[1] : v[0], p1 = b0 ? v[3] : v[2], p2 = b0 ? v[5] : v[4], p3 = b0 ? v[7] : v[6];
@@ -369,9 +379,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         // selection: one compare per lane and accumulator in the common case
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
-            float m = acc[u][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
+            const float m = max16(acc[u]);
             if (__ballot(m > tau[u]) != 0ull)
                 tile_slow_path<UPW>(acc[u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a, t << 5, split_end,
                                     lane);
@@ -560,9 +568,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
         if (!live) return;
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
-            float m = acc[u][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[u][r]);
+            const float m = max16(acc[u]);
             if (__ballot(m > tau[u]) != 0ull)
                 tile_slow_path<UPW>(acc[u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a, t << 5, split_end, lane);
         }
