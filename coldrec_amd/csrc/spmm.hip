@@ -43,6 +43,7 @@ struct SpmmArgs {
     float* partial;         // unused (kept for the ABI's workspace argument)
     int cs;                 // column slices (1, 2 or 4)
     int64_t light_blocks;   // blocks per slice working on light work items; heavy rows follow
+    int skip;               // measurement only (CRH_SPMM_SKIP): 1 = no heavy rows, 2 = no light rows
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     const bool on = c < (a.d >> 2);                  // d/4 not a power of two: the lane group is padded
     const bool seg = a.sched.n_seg > 0;
     if (j < a.light_blocks) {
+        if (a.skip & 2) return;
         const int64_t w = j * (256 / G) + threadIdx.x / G;
         const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
         if (w >= n_work) return;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     // partial sums meet in a fixed order: shuffle tree inside a wave, then the 4 waves through LDS
     __shared__ f32x4 wsum[4][G];
     const int64_t m = j - a.light_blocks;
-    if (m >= a.sched.n_multi) return;
+    if (m >= a.sched.n_multi || (a.skip & 1)) return;
     constexpr int NGB = 256 / G;
     const int64_t row = a.sched.multi_row[m];
     const int64_t r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
@@ -216,7 +218,8 @@ extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const
     CRH_CHECK_ARG(y != x && acc_out != x, "crh_spmm_csr_f32: outputs must not alias x");
     CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out | (uintptr_t)workspace) & 15) == 0,
                   "crh_spmm_csr_f32: dense operands must be 16-byte aligned");
-    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0};
+    static const int skip = getenv("CRH_SPMM_SKIP") ? atoi(getenv("CRH_SPMM_SKIP")) : 0;
+    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0, skip};
     (void)workspace;
     (void)workspace_bytes;
     if (sched && sched->n_seg > 0) {
