@@ -237,6 +237,52 @@ def train_legs(dev, with_cpu):
     return out
 
 
+def train_dp_leg(dev, world, rank):
+    """N > 1 only: the data-parallel BPR-MF step of SURVEY.md 8(e) on the MovieLens-shaped config (tables and
+    Adam state replicated, batch sharded, RCCL all-reduce of the 4 batch sums and of the dense gradient), eager
+    launches.  At this size the 5 MB gradient all-reduce is latency-bound: reported as measured."""
+    import torch.distributed as dist
+    from coldrec_amd.data.synth import make_dataset
+    from coldrec_amd.sampler import PairwiseSampler
+    from coldrec_amd.train import DPContext, MFEngine
+    B, d = 4096, 128
+    split = make_dataset("movielens", "item", seed=1, with_content=False)
+    tr = split.warm_train
+    _, ru = np.unique(tr[:, 0], return_inverse=True)
+    _, ri = np.unique(tr[:, 1], return_inverse=True)
+    n_u, n_i, n = split.user_num, split.item_num, tr.shape[0]
+    smp = PairwiseSampler(ru, ri, n_u, n_i)
+    smp.seed(2024)                                   # same stream on every rank: replicated sampler
+    u, i, j = (torch.from_numpy(x).to(dev) for x in smp.epoch(B))
+    g = torch.Generator().manual_seed(2024)
+    U0 = torch.nn.init.xavier_uniform_(torch.empty(n_u, d), generator=g)
+    V0 = torch.nn.init.xavier_uniform_(torch.empty(n_i, d), generator=g)
+    eng = MFEngine(U0, V0, 1e-3, 1e-4, dev)
+    eng.enable_data_parallel(DPContext(world, rank))
+    steps = [(lo, min(lo + B, n)) for lo in range(0, n, B)]
+    for lo, hi in steps[:8]:
+        eng.step(u[lo:hi], i[lo:hi], j[lo:hi])
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for lo, hi in steps:
+        eng.step(u[lo:hi], i[lo:hi], j[lo:hi])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    sec = float(dt.item()) / len(steps)
+    chk = eng.E.double().sum().reshape(1)
+    lo_, hi_ = chk.clone(), chk.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    return {"metric": "BPR triples/sec (train)", "value": n / (sec * len(steps)), "unit": "triples/s",
+            "ms_per_step": sec * 1e3, "replicas_identical": bool(lo_.item() == hi_.item()),
+            "config": {"workload": "configs[1] BPR-MF, movielens-shaped synthetic, d=%d, global B=%d sharded over %d GPUs, "
+                                   "dense Adam, all-reduce(4 sums) + all-reduce(gradient %d bytes) per step"
+                                   % (d, B, world, (n_u + n_i) * d * 4), "parallelism": "dp%d" % world}}
+
+
 def train_xl(dev, steps, warm, lazy=False):
     """HBM-roofline case for the training kernels: tables far beyond every cache.  ``lazy``: the touched-rows
     replay of dense Adam (same bits, crh_adam_rows_f32) instead of the dense pass; the per-batch reverse index
@@ -421,6 +467,16 @@ def main():
             "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
                       "%d threads, 2 reps" % (nu, ni, torch.__version__, os.cpu_count())}
+    if world > 1 and not args.no_train and args.dtype == "f32":
+        try:                                   # every rank takes part; rank 0 reports
+            del V, U, engine
+            torch.cuda.empty_cache()
+            leg = train_dp_leg(dev, world, rank)
+            if rank == 0:
+                result["train_mf_dp"] = leg
+        except Exception as e:                 # the headline line must survive a failure of the secondary leg
+            if rank == 0:
+                result["train_mf_dp"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_train and args.dtype == "f32":
         del V, U, engine
         torch.cuda.empty_cache()
