@@ -319,7 +319,7 @@ def train_xl(dev, steps, warm, lazy=False):
                                  "would move %d bytes per step" % (24 * d * B + 32 * (n_u + n_i) * d)}})
     else:
         bytes_step = 24 * d * B + 32 * (n_u + n_i) * d
-        tr = measured_traffic("adam_dense_kernel", float(2048 * 256))      # dominant kernel of the step
+        tr = measured_traffic("adam_dense_kernel", float(16384 * 256))      # dominant kernel of the step
         out["roofline"] = {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                            "traffic": tr[0] if tr else None,
