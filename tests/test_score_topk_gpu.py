@@ -354,13 +354,13 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
 
 
-@pytest.mark.parametrize("n_splits", [1, 0])
-def test_f32_workgroup_kernel_is_bit_exact(n_splits):
+@pytest.mark.parametrize("n_splits,n_items", [(1, 5003), (0, 5003), (1, 200_003)])
+def test_f32_workgroup_kernel_is_bit_exact(n_splits, n_items):
     """fp32 d=128 launches with >= 512 user groups also run the workgroup-cooperative kernel (packed tiles through
     LDS); its k-ordered MFMA chain must still be the oracle's fma chain bit for bit.  The helper checks bit-identity
     with the per-wave row-major kernel; sampled users go against the C oracle."""
-    rng = np.random.default_rng(128 + n_splits)
-    n_users, n_items, d, k = 32768 + 77, 5003, 128, 20
+    rng = np.random.default_rng(128 + n_splits + n_items)
+    n_users, d, k = 32768 + 77, 128, 20
     U = (rng.standard_normal((n_users, d)) * 0.3).astype(np.float32)
     V = (rng.standard_normal((n_items, d)) * 0.3).astype(np.float32)
     rated = [np.unique(rng.integers(0, n_items, 6)) for _ in range(n_users)]
