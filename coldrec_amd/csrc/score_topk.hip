@@ -443,6 +443,8 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 // registers, two tiles ahead), drops it into a two-slot LDS ring, and all 8 waves read their A fragments from
 // LDS -- 8x less L2 -> CU traffic.  One s_barrier per tile (LDS only: the prefetch loads stay in flight across
 // it).  Users, thresholds, lists and the slow path are per wave exactly as above, so results are identical.
+constexpr int WG_RING = 3;   // item-tile slots in LDS
+
 template <typename T, int D, int UW, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArgs a) {
     constexpr int ROWB = D * (int)sizeof(T);
@@ -462,10 +464,10 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     const int K = a.k;
     const int i = lane & 31, h = lane >> 5;
 
-    char* ring = smem;                                  // [2][TILE_B]
+    char* ring = smem;                                  // [RING][TILE_B]
     WaveLds<UPW> w;
     {
-        char* base = smem + 2 * TILE_B + (size_t)wave * wave_lds_bytes<UPW>(K);
+        char* base = smem + WG_RING * TILE_B + (size_t)wave * wave_lds_bytes<UPW>(K);
         w.ls = reinterpret_cast<float*>(base);
         w.li = reinterpret_cast<int*>(w.ls + UPW * K);
         w.cnt = w.li + UPW * K;
@@ -520,8 +522,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
             if (NCH % NW == 0 || q < NCH) st[c] = load16(tp + q * 1024);   // branch-free when 8 | NCH
         }
     };
-    auto commit = [&](const f32x4(&st)[CPW], int64_t t) {
-        char* dst = ring + (t & 1) * TILE_B + lane * 16;
+    // ring of WG_RING = 3 tile slots: tile t lives in slot t % 3.  Tile t+2 is committed during iteration t
+    // (into the slot tile t-1 left before the last barrier), so tile t+1 is already visible while tile t is
+    // multiplied and its first LDS group can be pulled into registers BEFORE the barrier: the next iteration
+    // starts its MFMAs without waiting for LDS.
+    auto commit = [&](const f32x4(&st)[CPW], int slot) {
+        char* dst = ring + slot * TILE_B + lane * 16;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
             const int q = wave + c * NW;
@@ -532,24 +538,32 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt/expcnt untouched
         __builtin_amdgcn_s_barrier();
     };
-    auto compute = [&](int64_t t) {
-        const char* src = ring + (t & 1) * TILE_B + lane * 16;
+    // A fragments come from LDS in groups of GR chunks, one group ahead of the MFMAs that consume them
+    constexpr int GR = NCH >= 16 ? 2 : (NCH >= 8 ? 4 : NCH / 2);
+    f32x4 cfirst[GR];            // first group of the tile about to be multiplied
+    auto load_first = [&](int slot) {
+        const char* src = ring + slot * TILE_B + lane * 16;
+#pragma unroll
+        for (int j = 0; j < GR; ++j) cfirst[j] = *reinterpret_cast<const f32x4*>(src + j * 1024);
+    };
+    auto compute = [&](int64_t t, int slot, int slot_next, bool has_next) {
+        const char* src = ring + slot * TILE_B + lane * 16;
         f32x16 acc[UW];
 #pragma unroll
         for (int u = 0; u < UW; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
-        // A fragments come from LDS in groups of GR chunks, one group ahead of the MFMAs that consume them
-        constexpr int GR = NCH >= 8 ? 4 : NCH / 2;
         f32x4 c[2][GR];
 #pragma unroll
-        for (int j = 0; j < GR; ++j) c[0][j] = *reinterpret_cast<const f32x4*>(src + j * 1024);
+        for (int j = 0; j < GR; ++j) c[0][j] = cfirst[j];
 #pragma unroll
         for (int g = 0; g < NCH / GR; ++g) {
             if (g + 1 < NCH / GR) {
 #pragma unroll
                 for (int j = 0; j < GR; ++j)
                     c[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(src + ((g + 1) * GR + j) * 1024);
+            } else if (has_next) {
+                load_first(slot_next);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -577,20 +591,26 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     if (t0 < t1) {
         f32x4 sa[CPW], sb[CPW];
         fetch(sa, t0);
-        commit(sa, t0);                 // tile t0 -> slot t0&1
-        fetch(sa, t0 + 1);              // stage A: tile t0+1
-        fetch(sb, t0 + 2);              // stage B: tile t0+2
+        fetch(sb, t0 + 1);
+        commit(sa, 0);                  // tile t0   -> slot 0
+        commit(sb, 1);                  // tile t0+1 -> slot 1
+        fetch(sa, t0 + 2);              // stage A: tile t0+2
+        fetch(sb, t0 + 3);              // stage B: tile t0+3
         lds_barrier();
+        load_first(0);
+        int s0 = 0;                     // slot of tile t
         for (int64_t t = t0; t < t1; t += 2) {
-            commit(sa, t + 1);          // slot of tile t-1: every wave left it before the last barrier
-            fetch(sa, t + 3);
-            compute(t);
+            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            commit(sa, s2);             // tile t+2 -> the slot tile t-1 left before the last barrier
+            fetch(sa, t + 4);
+            compute(t, s0, s1, t + 1 < t1);
             lds_barrier();
             if (t + 1 >= t1) break;
-            commit(sb, t + 2);
-            fetch(sb, t + 4);
-            compute(t + 1);
+            commit(sb, s0);             // tile t+3 -> slot of tile t
+            fetch(sb, t + 5);
+            compute(t + 1, s1, s2, t + 2 < t1);
             lds_barrier();
+            s0 = s2;
         }
     }
 
@@ -610,7 +630,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
 
 template <typename T, int D, int UW, int NW>
 int launch_score_wg(const ScoreArgs& a, hipStream_t stream) {
-    const size_t lds = (size_t)2 * (D * sizeof(T) / 32) * 1024 + NW * wave_lds_bytes<32 * UW>(a.k);
+    const size_t lds = (size_t)WG_RING * (D * sizeof(T) / 32) * 1024 + NW * wave_lds_bytes<32 * UW>(a.k);
     auto kern = score_topk_wg_kernel<T, D, UW, NW>;
     CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
@@ -749,7 +769,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     // one 8-wave workgroup per CU when its lists fit the 160 KiB of LDS, else two 4-wave workgroups (large k);
     // measured at k=20 (fp16): 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two 4-wave groups
     // 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
-    const size_t ring_b = (size_t)2 * (d * esz / 32) * 1024;
+    const size_t ring_b = (size_t)WG_RING * (d * esz / 32) * 1024;
     const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
     const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
