@@ -63,36 +63,21 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------ dense mask + top-k
-__global__ __launch_bounds__(256) void mask_writeback_kernel(float* __restrict__ S, int64_t n_users,
-                                                             int64_t n_items, int64_t stride,
-                                                             const int64_t* __restrict__ rated_rowptr,
-                                                             const int32_t* __restrict__ rated_col,
-                                                             const uint32_t* __restrict__ bitmap,
-                                                             int64_t item_base) {
-    // one block per row: rated scatter, then the column bitmap
-    const int64_t row = blockIdx.x;
-    float* srow = S + row * stride;
-    if (rated_rowptr) {
-        for (int64_t e = rated_rowptr[row] + threadIdx.x; e < rated_rowptr[row + 1]; e += blockDim.x) {
-            const int64_t il = (int64_t)rated_col[e] - item_base;
-            if (il >= 0 && il < n_items) srow[il] = CRH_MASKED_SCORE;
-        }
-    }
-    if (bitmap) {
-        for (int64_t il = threadIdx.x; il < n_items; il += blockDim.x) {
-            const int64_t gi = item_base + il;
-            if ((bitmap[gi >> 5] >> (gi & 31)) & 1u) srow[il] = CRH_MASKED_SCORE;
-        }
-    }
-}
-
-// One wave per row, 4 rows per block.  LDS per wave: one k-entry list.
-__global__ __launch_bounds__(256) void mask_topk_kernel(const float* __restrict__ S, int64_t n_users,
+// LDS per wave: one k-entry list.  ONE streaming pass: the candidate bitmap is applied in registers while the
+// row streams by (a masked score is -1e9 before the threshold test, so it rarely reaches the slow path), and
+// with write_back the modified 16-byte vectors go straight back (the reference mutates the block,
+// model/BaseRecommender.py:175-180); the user's rated items are tested on the slow path only and written back
+// after the row.  Four 16-byte loads per lane are in flight per iteration (HBM-bound: 4 B per pair).
+// WPR = waves per row: 1 -> four rows per block; 4 -> the four waves of a block split ONE row (few-row
+// blocks would otherwise leave most of the chip idle) and merge their lists in LDS.
+template <int WPR>
+__global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ S, int64_t n_users,
                                                         int64_t n_items, int64_t stride,
                                                         const int64_t* __restrict__ rated_rowptr,
                                                         const int32_t* __restrict__ rated_col,
                                                         const uint32_t* __restrict__ bitmap, int K,
-                                                        int64_t item_base, float* __restrict__ out_score,
+                                                        int64_t item_base, int write_back,
+                                                        float* __restrict__ out_score,
                                                         int32_t* __restrict__ out_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -100,46 +85,114 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(const float* __restrict_
     float* ls = reinterpret_cast<float*>(smem) + (size_t)wave * (2 * K + 4);
     int* li = reinterpret_cast<int*>(ls + K);
     int* cnt = li + K;
+    const int64_t row_step = WPR == 1 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
 
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_users; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = WPR == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x; row < n_users; row += row_step) {
         if (lane == 0) *cnt = 0;
-        const float* srow = S + row * stride;
+        float* srow = S + row * stride;
         const bool vec_ok = ((reinterpret_cast<uintptr_t>(srow) & 15) == 0);
         float tau = CRH_NEG_INF;
-        for (int64_t base = 0; base < n_items; base += 256) {
-            const int64_t e0 = base + lane * 4;
-            float v[4];
-            if (vec_ok && e0 + 3 < n_items) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(srow + e0);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
+        // this wave's item range, a multiple of the 1024-item iteration
+        int64_t i0 = 0, i1 = n_items;
+        if (WPR > 1) {
+            const int64_t q = (((n_items + WPR - 1) / WPR) + 1023) & ~(int64_t)1023;
+            i0 = q * wave < n_items ? q * wave : n_items;
+            i1 = i0 + q < n_items ? i0 + q : n_items;
+        }
+        for (int64_t base = i0; base < i1; base += 1024) {
+            f32x4 vq[4];
+            unsigned bq[4];
+            bool fullq[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = e0 + c < n_items ? srow[e0 + c] : CRH_NEG_INF;
-            }
-            const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            if (__ballot(m > tau) == 0ull) continue;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t e0 = base + u * 256 + lane * 4;
+                fullq[u] = vec_ok && e0 + 3 < i1;
+                if (fullq[u]) {
+                    vq[u] = *reinterpret_cast<const f32x4*>(srow + e0);
+                } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                unsigned long long cand = __ballot(v[c] > tau && e0 + c < n_items);
-                while (cand) {
-                    const int L = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    float sc = __builtin_bit_cast(
-                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c]), L));
-                    const int gi = (int)(item_base + base + L * 4 + c);
-                    const int n = __builtin_amdgcn_readfirstlane(*cnt);
-                    if (wave_list_rejects(ls, li, n, K, sc, gi)) continue;
-                    if (wave_is_masked(gi, row, rated_rowptr, rated_col, bitmap, lane)) sc = CRH_MASKED_SCORE;
-                    wave_list_insert(ls, li, cnt, K, sc, gi, lane);
+                    for (int c = 0; c < 4; ++c) vq[u][c] = e0 + c < i1 ? srow[e0 + c] : CRH_NEG_INF;
+                }
+                bq[u] = 0;
+                if (bitmap && e0 < i1) {
+                    const int64_t g0 = item_base + e0;
+                    // 4 consecutive items: bits g0&31 .. of one word, spilling into the next one at most
+                    const int sh = (int)(g0 & 31);
+                    const bool spill = sh > 28 && e0 + (32 - sh) < n_items;      // only then the next word exists
+                    const uint64_t two = (uint64_t)bitmap[g0 >> 5] | ((uint64_t)(spill ? bitmap[(g0 >> 5) + 1] : 0u) << 32);
+                    bq[u] = (unsigned)(two >> sh) & 0xfu;
                 }
             }
-            tau = wave_list_tau(ls, *cnt, K);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t e0 = base + u * 256 + lane * 4;
+                float v[4] = {vq[u][0], vq[u][1], vq[u][2], vq[u][3]};
+                const unsigned bits = bq[u];
+                if (bits) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (((bits >> c) & 1u) && e0 + c < i1) v[c] = CRH_MASKED_SCORE;
+                    if (write_back) {
+                        if (fullq[u]) {
+                            *reinterpret_cast<f32x4*>(srow + e0) = f32x4{v[0], v[1], v[2], v[3]};
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (((bits >> c) & 1u) && e0 + c < i1) srow[e0 + c] = CRH_MASKED_SCORE;
+                        }
+                    }
+                }
+                const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                if (__ballot(m > tau) == 0ull) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned long long cand = __ballot(v[c] > tau && e0 + c < i1);
+                    while (cand) {
+                        const int L = __builtin_ctzll(cand);
+                        cand &= cand - 1;
+                        float sc = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c]), L));
+                        const int gi = (int)(item_base + base + u * 256 + L * 4 + c);
+                        const int n = __builtin_amdgcn_readfirstlane(*cnt);
+                        if (wave_list_rejects(ls, li, n, K, sc, gi)) continue;
+                        if (wave_is_masked(gi, row, rated_rowptr, rated_col, bitmap, lane)) sc = CRH_MASKED_SCORE;
+                        wave_list_insert(ls, li, cnt, K, sc, gi, lane);
+                    }
+                }
+                tau = wave_list_tau(ls, *cnt, K);
+            }
         }
-        const int n = __builtin_amdgcn_readfirstlane(*cnt);
-        if (lane < K) {
-            out_score[row * K + lane] = lane < n ? ls[lane] : CRH_NEG_INF;
-            out_idx[row * K + lane] = lane < n ? li[lane] : CRH_PAD_IDX;
+        if (WPR > 1) {                           // waves 1..3 hand their lists to wave 0 (final scores: no mask test)
+            __syncthreads();
+            if (wave == 0) {
+                for (int ow = 1; ow < WPR; ++ow) {
+                    const float* os = reinterpret_cast<float*>(smem) + (size_t)ow * (2 * K + 4);
+                    const int* oi = reinterpret_cast<const int*>(os + K);
+                    const int on = __builtin_amdgcn_readfirstlane(oi[K]);
+                    for (int e = 0; e < on; ++e) {
+                        const float sc = os[e];
+                        const int gi = oi[e];
+                        const int n = __builtin_amdgcn_readfirstlane(*cnt);
+                        if (wave_list_rejects(ls, li, n, K, sc, gi) && sc >= CRH_MASKED_SCORE) continue;
+                        wave_list_insert(ls, li, cnt, K, sc, gi, lane);
+                    }
+                }
+            }
         }
+        if (WPR == 1 || wave == 0) {
+            const int n = __builtin_amdgcn_readfirstlane(*cnt);
+            if (lane < K) {
+                out_score[row * K + lane] = lane < n ? ls[lane] : CRH_NEG_INF;
+                out_idx[row * K + lane] = lane < n ? li[lane] : CRH_PAD_IDX;
+            }
+            if (write_back && rated_rowptr) {       // the row has been read: now it may be scribbled on
+                for (int64_t e = rated_rowptr[row] + lane; e < rated_rowptr[row + 1]; e += 64) {
+                    const int64_t il = (int64_t)rated_col[e] - item_base;
+                    if (il >= 0 && il < n_items) srow[il] = CRH_MASKED_SCORE;
+                }
+            }
+        }
+        if (WPR > 1) __syncthreads();            // lists are reused by the next row of this block
     }
 }
 
@@ -174,16 +227,17 @@ extern "C" int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items
     CRH_CHECK_ARG(k >= 1 && k <= CRH_MAX_K, "crh_mask_topk_f32: k=%d outside 1..%d", k, CRH_MAX_K);
     CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "crh_mask_topk_f32: item ids exceed int32");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (write_back && (rated_rowptr || cand_bitmap)) {
-        hipLaunchKernelGGL(mask_writeback_kernel, dim3((unsigned)n_users), dim3(256), 0, st, scores, n_users,
-                           n_items, row_stride, rated_rowptr, rated_col, cand_bitmap, item_base);
-        CRH_HIP(hipGetLastError());
-    }
-    int64_t blocks = (n_users + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
     const size_t lds = (size_t)4 * (2 * k + 4) * 4;
-    hipLaunchKernelGGL(mask_topk_kernel, dim3((unsigned)blocks), dim3(256), lds, st, scores, n_users, n_items,
-                       row_stride, rated_rowptr, rated_col, cand_bitmap, k, item_base, out_score, out_idx);
+    if (n_users < 4096 && n_items >= 8192) {        // few rows: four waves per row
+        int64_t blocks = n_users > 16384 ? 16384 : n_users;
+        hipLaunchKernelGGL(mask_topk_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, st, scores, n_users, n_items,
+                           row_stride, rated_rowptr, rated_col, cand_bitmap, k, item_base, write_back, out_score, out_idx);
+    } else {
+        int64_t blocks = (n_users + 3) / 4;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(mask_topk_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, scores, n_users, n_items,
+                           row_stride, rated_rowptr, rated_col, cand_bitmap, k, item_base, write_back, out_score, out_idx);
+    }
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

@@ -185,6 +185,33 @@ def test_merge_and_mask_topk_match_oracle():
     np.testing.assert_array_equal(tS2.cpu().numpy(), S)
 
 
+@pytest.mark.parametrize("n_users,n_items,base", [(37, 20011, 0), (5, 70000, 12345), (4100, 9001, 0)])
+def test_mask_topk_dense_block_variants(n_users, n_items, base):
+    """crh_mask_topk_f32 on dense blocks: four-waves-per-row launches (few rows), odd row strides (unaligned rows),
+    a shard in the middle of the catalogue (bitmap words straddled by a 4-item vector), heavy ties; top-k AND the
+    mutated block must equal the oracle's, with and without write-back."""
+    from coldrec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(n_users + n_items)
+    S = (rng.integers(-6, 7, (n_users, n_items)) / 4).astype(np.float32)        # quantised: many exact ties
+    S[:, : n_items // 3] += rng.standard_normal((n_users, n_items // 3)).astype(np.float32)
+    n_glob = base + n_items + 77
+    rated = [np.unique(rng.integers(base, base + n_items, rng.integers(0, 90))) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64) if rowptr[-1] else np.zeros(0, np.int64)
+    bm = np.where(rng.random(n_glob) < 0.2)[0]
+    srp, src = orc.sort_rated(rowptr, col)
+    for wb in (True, False):
+        S_ref = S.copy()
+        ws, wi = orc.mask_topk(S_ref, 20, rowptr, col, orc.make_bitmap(n_glob, bm), item_base=base, write_back=wb)
+        tS = torch.from_numpy(S.copy()).to(dev)
+        ds, di = ops.mask_topk(tS, 20, torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev),
+                               ops.make_bitmap(n_glob, bm, dev), item_base=base, write_back=wb)
+        torch.cuda.synchronize()
+        _same((ds.cpu().numpy(), di.cpu().numpy()), (ws, wi))
+        np.testing.assert_array_equal(tS.cpu().numpy(), S_ref if wb else S)
+
+
 def test_full_size_properties_eval_config():
     """BASELINE config 4 shape on one GPU, scaled to what a test may take: 4096 users x 1M items,
     d=128.  Size-independent properties: (1) independent of the item-range split count,
