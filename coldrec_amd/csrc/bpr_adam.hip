@@ -933,6 +933,17 @@ extern "C" int crh_adam_rows_f32(float* p, float* g, float* m, float* v, int32_t
 
 // HOST helper: the two step-dependent Adam factors {sqrt(1-beta2^step), -lr/(1-beta1^step)} exactly as
 // crh_adam_dense_f32 derives them, for callers that keep them in device memory (graph replay).
+// HOST helper: the same two factors for steps first_step .. first_step + n - 1 (out: n pairs).
+extern "C" void crh_adam_step_scalars_range_host(double lr, double beta1, double beta2, int64_t first_step, int64_t n,
+                                                 float* out_host) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double bc1 = 1.0 - pow(beta1, (double)(first_step + i));
+        const double bc2 = 1.0 - pow(beta2, (double)(first_step + i));
+        out_host[2 * i] = (float)sqrt(bc2);
+        out_host[2 * i + 1] = (float)(-(lr / bc1));
+    }
+}
+
 extern "C" void crh_adam_step_scalars_host(double lr, double beta1, double beta2, int64_t step, float* out2_host) {
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);

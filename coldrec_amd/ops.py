@@ -308,9 +308,8 @@ def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Ten
 def adam_step_scalars(first_step: int, n_steps: int, lr: float = 1e-3, betas=(0.9, 0.999)) -> np.ndarray:
     """(n_steps, 2) float32 host array of the step-dependent Adam factors for steps first_step.."""
     out = np.empty((n_steps, 2), np.float32)
-    L = _lib.lib()
-    for s in range(n_steps):
-        L.crh_adam_step_scalars_host(float(lr), float(betas[0]), float(betas[1]), first_step + s, out[s].ctypes.data)
+    _lib.lib().crh_adam_step_scalars_range_host(float(lr), float(betas[0]), float(betas[1]), int(first_step),
+                                                int(n_steps), out.ctypes.data)
     return out
 
 

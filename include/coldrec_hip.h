@@ -183,6 +183,8 @@ int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0,
                        double lr, double beta1, double beta2, double eps, int64_t step, int zero_grad,
                        const float* step_scalars, void* stream);
 void crh_adam_step_scalars_host(double lr, double beta1, double beta2, int64_t step, float* out2_host);
+void crh_adam_step_scalars_range_host(double lr, double beta1, double beta2, int64_t first_step, int64_t n,
+                                      float* out_host);   /* n pairs, steps first_step .. first_step+n-1 */
 
 /*
  * Touched-rows replay of the same dense Adam, for tables whose gradient is zero in almost every row (BPR-MF at
