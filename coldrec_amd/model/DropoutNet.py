@@ -22,7 +22,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..util.utils import next_batch_pairwise
+from ..util.utils import epoch_triples
 from .BaseRecommender import BaseColdStartTrainer
 
 
@@ -152,7 +152,11 @@ class DropoutNet(BaseColdStartTrainer):
         epoch = -1
         for epoch in range(self.maxEpoch):
             model.train()
-            for n, (user_idx, pos_idx, neg_idx) in enumerate(next_batch_pairwise(self.data, self.batch_size)):
+            # the epoch's triples come from the same sampler stream as next_batch_pairwise, in one host call and
+            # one upload (the reference converts three Python lists per batch)
+            eu, ei, ej = (torch.from_numpy(x).to(self.device, torch.long) for x in epoch_triples(self.data, self.batch_size))
+            for n, lo in enumerate(range(0, eu.shape[0], self.batch_size)):
+                user_idx, pos_idx, neg_idx = (x[lo:lo + self.batch_size] for x in (eu, ei, ej))
                 target = torch.cat((model.pair_score(user_idx, pos_idx), model.pair_score(user_idx, neg_idx)))
                 pred = torch.cat((model.deepcf_forward(user_idx, pos_idx, is_drop=True),
                                   model.deepcf_forward(user_idx, neg_idx, is_drop=True)))
