@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzzing of the training kernels against the oracle (tests-style tool: it imports oracle/).
+
+Per case: random table sizes / widths / batch sizes / duplicate patterns, then
+  * crh_bpr_fwd_bwd_f32 with the atomics backward and with the reverse-index ("plan") backward vs the fp64
+    closed form (1e-5 on the losses, 5e-4 / scaled absolute on gradients); the plan backward twice -> identical bits;
+  * crh_spmm_csr_f32 with and without the schedule on a random Zipf graph vs the C oracle: rows in one piece
+    bit-exact, heavy rows to rounding;
+  * a few optimiser steps with the dense Adam and with the touched-rows replay -> identical bits after the flush.
+
+    python tools/fuzz_train_ops.py --minutes 5 [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from coldrec_amd import ops  # noqa: E402
+from coldrec_amd.train import MFEngine  # noqa: E402
+from oracle import oracle_np as orc  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return (x if dtype is None else x.to(dtype)).to(DEV)
+
+
+def fail(what, **kw):
+    print("MISMATCH", what, kw, flush=True)
+    sys.exit(1)
+
+
+def case_bpr(rng):
+    d = int(rng.choice([4, 8, 16, 64, 128, 200, 256]))
+    n_u, n_i = int(rng.integers(1, 3000)), int(rng.integers(2, 4000))
+    B = int(rng.choice([1, 7, 64, 513, 4096]))
+    U = (rng.standard_normal((n_u, d)) * 0.3).astype(np.float32)
+    V = (rng.standard_normal((n_i, d)) * 0.3).astype(np.float32)
+    ui = rng.integers(0, n_u, B).astype(np.int32)
+    hot = rng.integers(0, n_i, 3)
+    pi = np.where(rng.random(B) < rng.choice([0.0, 0.3, 0.9]), hot[rng.integers(0, 3, B)], rng.integers(0, n_i, B)).astype(np.int32)
+    ni = rng.integers(0, n_i, B).astype(np.int32)
+    ni = np.where(ni == pi, (ni + 1) % n_i, ni).astype(np.int32)   # the sampler never returns neg == pos (the g*u terms
+    reg = float(rng.choice([0.0, 1e-4, 0.05]))                      # of such a triple cancel catastrophically in fp32)
+    bpr, l2, wU, wV, _ = orc.bpr_l2_fwd_bwd(U, V, ui, pi, ni, reg)
+    sc = max(np.abs(wU).max(), np.abs(wV).max(), 1e-30)
+    # fp32 evaluates (1 - sigmoid(x)) with ~6e-8 absolute error (the reference's fp32 autograd does the same):
+    # the relative error of a saturated triple's gradient is 6e-8 / (1 - sigmoid)
+    x64 = (U.astype(np.float64)[ui] * (V.astype(np.float64)[pi] - V.astype(np.float64)[ni])).sum(1)
+    sat = 1.0e-6 / max(1e-12, float((1.0 - 1.0 / (1.0 + np.exp(-x64))).min()))
+    tU, tV = t(U), t(V)
+    outs = []
+    plan = ops.build_plans_device(t(ui), t(pi), t(ni), B)[0] if B <= 8192 else None
+    for mode in ("atomic", "plan", "plan"):
+        gU, gV = torch.zeros_like(tU), torch.zeros_like(tV)
+        loss = ops.bpr_fwd_bwd(tU, tV, tV, t(ui), t(pi), t(ni), reg, gU, gV, gV, plan=None if mode == "atomic" else plan)
+        torch.cuda.synchronize()
+        ln = loss.cpu().numpy()
+        # -log(1e-5 + sigmoid) of a saturated triple is ~6e-8 absolute in fp32: 1e-5 relative for a real batch mean,
+        # a little more for the single-triple batches drawn here
+        if not (np.allclose(ln[0], bpr, rtol=1e-5 if B >= 64 else 1e-4, atol=1e-7) and
+                np.allclose(ln[1], l2, rtol=1e-5, atol=1e-12)):
+            fail("bpr loss", d=d, B=B, mode=mode, got=ln.tolist(), want=[float(bpr), float(l2)])
+        for g, w in ((gU, wU), (gV, wV)):
+            # fp32 sigmoid / (1 - sigmoid) loses relative precision when saturated (as the reference's own fp32
+            # autograd does): 5e-4 relative, plus a floor scaled by the largest gradient entry
+            if not np.allclose(g.cpu().numpy(), w, rtol=5e-4, atol=(1e-4 + sat) * sc):
+                fail("bpr grad", d=d, B=B, mode=mode, err=float(np.abs(g.cpu().numpy() - w).max()), scale=float(sc),
+                     sat=sat, reg=reg, x=x64[:4].tolist())
+        outs.append((gU, gV))
+    if not (torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])):
+        fail("plan backward not deterministic", d=d, B=B)
+
+
+def case_spmm(rng):
+    d = int(rng.choice([4, 32, 64, 128, 256]))
+    n_u, n_i = int(rng.integers(50, 30000)), int(rng.integers(20, 9000))
+    w = 1.0 / np.arange(1, n_i + 1) ** float(rng.choice([0.0, 0.8, 1.1]))
+    nnz = int(rng.integers(n_u, 12 * n_u))
+    key = np.unique(rng.integers(0, n_u, nnz) * n_i + rng.choice(n_i, nnz, p=w / w.sum()))
+    rowptr, col, val = orc.norm_adj_csr(key // n_i, key % n_i, n_u, n_i)
+    deg = np.diff(rowptr)
+    X = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
+    Z = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
+    want = orc.spmm(rowptr, col, val, X)
+    tX, tZ = t(X), t(Z)
+    rp, cl, vl = t(rowptr), t(col), t(val)
+    Y0 = torch.empty_like(tX)
+    ops.spmm_csr(rp, cl, vl, tX, y=Y0)
+    if not np.array_equal(Y0.cpu().numpy(), want):
+        fail("spmm rows", d=d, n=n_u + n_i)
+    sched = ops.SpmmSchedule(rowptr, DEV)
+    Y1, A1 = torch.empty_like(tX), torch.empty_like(tX)
+    ops.spmm_csr(rp, cl, vl, tX, y=Y1, acc_in=tZ, s_in=0.5, acc_out=A1, s_out=2.0, sched=sched)
+    y1 = Y1.cpu().numpy()
+    one = deg <= 64
+    if not np.array_equal(y1[one], want[one]):
+        fail("spmm sched light rows", d=d, n=n_u + n_i)
+    # heavy rows are summed in a different (fixed) association: bound the difference by the row's condition,
+    # 4 ulp-ish of sum |a_ij x_j| (fp64 reference via scipy)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(n_u + n_i, n_u + n_i))
+    p64 = A @ X.astype(np.float64)
+    bound = (abs(A) @ np.abs(X).astype(np.float64)) * 4e-7 + 1e-9
+    if not np.all(np.abs(y1[~one] - p64[~one]) <= bound[~one] + 1e-6 * np.abs(p64[~one])):
+        fail("spmm sched heavy rows", d=d, n=n_u + n_i)
+    a_want = (Z.astype(np.float64) * 0.5 + p64) * 2.0
+    if not np.all(np.abs(A1.cpu().numpy() - a_want) <= 2 * bound + 1e-6 * (np.abs(a_want) + np.abs(Z))):
+        fail("spmm epilogue", d=d)
+
+
+def case_adam(rng):
+    d = int(rng.choice([8, 64, 128]))
+    n_u, n_i = int(rng.integers(10, 4000)), int(rng.integers(10, 6000))
+    B = int(rng.choice([5, 300, 2048]))
+    U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
+    lr = float(rng.choice([1e-3, 1e-2]))
+    dense, lazy = MFEngine(U0, V0, lr, 1e-3, DEV), MFEngine(U0, V0, lr, 1e-3, DEV)
+    lazy.enable_lazy_adam()
+    for s in range(int(rng.integers(1, 12))):
+        tri = [t(rng.integers(0, n, B).astype(np.int32)) for n in (n_u, n_i, n_i)]
+        plan = ops.build_plans_device(*tri, B)[0]
+        dense.step(*tri, plan=plan)
+        lazy.step(*tri, plan=plan)
+        if rng.random() < 0.2:
+            lazy.sync_tables()
+    lazy.sync_tables()
+    torch.cuda.synchronize()
+    for name in ("E", "M", "V"):
+        if not torch.equal(getattr(dense, name).view(torch.int32), getattr(lazy, name).view(torch.int32)):
+            fail("lazy adam", what=name, d=d, B=B)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.minutes * 60
+    counts = {"bpr": 0, "spmm": 0, "adam": 0}
+    while time.time() < t_end:
+        which = str(rng.choice(["bpr", "spmm", "adam"]))
+        {"bpr": case_bpr, "spmm": case_spmm, "adam": case_adam}[which](rng)
+        counts[which] += 1
+    print(f"fuzz ok: {counts} random cases within parity, seed {args.seed}")
+
+
+if __name__ == "__main__":
+    main()
