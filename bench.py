@@ -363,11 +363,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: coldrec_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hook (CRH_BENCH_BACKEND=gloo): several ranks on ONE GPU over gloo, to exercise the N > 1 control flow on a
+    # 1-GPU box; the driver's runs use RCCL ("nccl") with one GPU per rank
+    backend = os.environ.get("CRH_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from coldrec_amd import ops
     from coldrec_amd.eval import ShardedTopK
