@@ -283,6 +283,41 @@ def train_dp_leg(dev, world, rank):
                                    % (d, B, world, (n_u + n_i) * d * 4), "parallelism": "dp%d" % world}}
 
 
+def dropoutnet_generator(dev, n_items, d, content_dim=300, chunk=1_000_000):
+    """BASELINE.json configs[4], generator half (model/DropoutNet.py:126-135): every item goes through the item tower
+    of DeepCF -- [warm embedding ; content] (d + content_dim) -> 200 -> 100 -> d, Linear + eval-mode BatchNorm + tanh --
+    as stock PyTorch-ROCm modules (rocBLAS / hipBLASLt GEMMs), chunk by chunk, and lands as the fp16 item table the
+    scoring kernel ranks.  Inputs are generated per chunk on the device (a 50 M x 300 content matrix is 60 GB)."""
+    from coldrec_amd.model.DropoutNet import get_model
+    torch.manual_seed(0)
+    net = get_model(d, 0, content_dim, [200, 100], d).to(dev).eval()
+    out = torch.empty((n_items, d), dtype=torch.float16, device=dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    warm = torch.randn((chunk, d), generator=g, device=dev) * 0.1
+    content = torch.randn((chunk, content_dim), generator=g, device=dev)
+    users_dummy = torch.zeros((1, d), device=dev)
+    flops_item = 2.0 * ((d + content_dim) * 200 + 200 * 100 + 100 * d)
+
+    def run():
+        with torch.no_grad():
+            for lo in range(0, n_items, chunk):
+                hi = min(lo + chunk, n_items)
+                _, v = net.encode(users_dummy, warm[: hi - lo], None, content[: hi - lo])
+                out[lo:hi] = v.to(torch.float16)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    return out, {"metric": "items generated/sec (DropoutNet item tower)", "value": n_items / sec, "unit": "items/s",
+                 "seconds": sec, "tflops": flops_item * n_items / sec / 1e12,
+                 "config": {"workload": "DeepCF item tower %d -> 200 -> 100 -> %d (fp32 GEMMs via PyTorch-ROCm, eval-mode "
+                                        "BatchNorm, tanh), %d items in chunks of %d, output cast to fp16"
+                                        % (d + content_dim, d, n_items, chunk)}}
+
+
 def train_xl(dev, steps, warm, lazy=False):
     """HBM-roofline case for the training kernels: tables far beyond every cache.  ``lazy``: the touched-rows
     replay of dense Adam (same bits, crh_adam_rows_f32) instead of the dense pass; the per-batch reverse index
@@ -342,6 +377,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32",
                     help="f32 = exact fp32 MFMA, bit-exact parity mode (headline); f16 = fp16 tables with fp32 "
                          "accumulation (BASELINE.json configs[4]: --dtype f16 --items 50000000 --dim 256 --users 100000)")
+    ap.add_argument("--generator", action="store_true",
+                    help="configs[4]: build the (fp16) item table with the DropoutNet item tower first and report its rate")
     ap.add_argument("--n-splits", type=int, default=0)
     ap.add_argument("--masks", choices=["warm", "none"], default="warm",
                     help="'warm' = rated CSR + 20%% cold-item bitmap (default); 'none' = diagnostic run without masks")
@@ -390,7 +427,12 @@ def main():
     lo, hi = rank * I // world, (rank + 1) * I // world
     tdtype = torch.float16 if args.dtype == "f16" else torch.float32
     Bu = min(Bu, args.users)
-    V = item_shard(I, d, lo, hi, dev, tdtype)
+    gen_leg = None
+    if args.generator:           # configs[4]: the item table is GENERATED by the DropoutNet tower, then ranked in fp16
+        assert args.dtype == "f16", "--generator produces the fp16 table of configs[4]: use --dtype f16"
+        V, gen_leg = dropoutnet_generator(dev, hi - lo, d)
+    else:
+        V = item_shard(I, d, lo, hi, dev, tdtype)
     n_blocks = args.warmup + args.steps
     n_user_rows = min(args.users, Bu * n_blocks)
     U = xavier_(n_user_rows, d, 17, dev, args.users).to(tdtype)
@@ -469,6 +511,8 @@ def main():
                                                   "256 MB Infinity Cache, compulsory HBM bytes are %d" % (
                                                       tr[1], (hi - lo) * d * 4 + Bu * d * 4))
 
+    if gen_leg is not None and rank == 0:
+        result["dropoutnet_generator"] = gen_leg
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nu, ni = args.cpu_sample_users, min(args.cpu_sample_items, hi - lo)
         Uc, Vc = U[:nu].float().cpu(), V[:ni].float().cpu()   # the reference scores in fp32 (torch.matmul)
