@@ -4,26 +4,31 @@
 // (the -10e8 masks) and :182 (torch.topk) of the reference without ever writing the
 // (users x items) score block to memory.
 //
-// Design (one wave64 is the unit of work; waves never synchronise with each other):
+// What every variant shares:
 //   * a wave owns 32*UW users.  Their embeddings are loaded once and stay in VGPRs as the
-//     B operand of v_mfma_f32_32x32x2_f32 for the whole kernel (the "hot user block").
-//   * the wave streams its item range in tiles of 32 items.  Lane (i, h) = (lane&31, lane>>5)
-//     loads 16 B of row i per 8-wide k chunk (h selects the half), then two
-//     v_permlane32_swap per chunk put k = 2t in the low half-wave and k = 2t+1 in the high
-//     half-wave, which is exactly the A fragment of the 32x32x2 MFMA.  Issued in k order into
-//     ONE accumulator per (item tile, user tile), the MFMA result is bit-identical to the
-//     canonical fp32 fma chain of the oracle (oracle/topk_oracle.c).
-//   * accumulator layout (A = items -> rows, B = users -> columns): a lane holds 16 item
-//     scores of ONE user, so the running k-th best score tau of that user is one VGPR and the
-//     common case is: max of 16 registers, one compare, one ballot per 32x32 tile.
-//   * only tiles that contain a score above tau take the slow path: scores are staged to LDS,
-//     each candidate is checked against the masks (bitmap bit, rated list) and inserted into
-//     the user's sorted list in LDS by the whole wave (topk_list.h).  Expected slow-path
-//     events per user are ~ k*ln(range/k), against range/32 tiles.
-//   * the grid is (user groups) x (item-range splits); block b works on split b % S so that
-//     the blocks of one XCD (b % 8) stream the same item rows through that XCD's L2.
-//     Partial lists are merged by merge_topk with the same canonical key, so the result does
-//     not depend on S, on the tiling or (after the all-gather) on the GPU count.
+//     B operand of the MFMA for the whole kernel (the "hot user block").
+//   * items are walked in tiles of 32 rows.  With A = items -> rows and B = users -> columns a lane
+//     holds 16 item scores of ONE user, so the running k-th best score tau of that user is one VGPR and
+//     the common case is: max of 16 registers, one compare, one ballot per 32x32 tile.
+//   * fp32: v_mfma_f32_32x32x2_f32 issued in k order into ONE accumulator per (item tile, user tile) --
+//     bit-identical to the canonical fp32 fma chain of the oracle (oracle/topk_oracle.c).  fp16 tables:
+//     v_mfma_f32_32x32x16_f16 with fp32 accumulation.
+//   * only tiles that contain a score above tau take the slow path: each candidate is checked against the
+//     masks (bitmap bit + rated list in one memory round trip) and inserted into the user's sorted list in
+//     LDS by the whole wave (topk_list.h).  Expected slow-path events per user are ~ k*ln(range/k),
+//     against range/32 tiles.
+//   * the grid is (user groups) x (item-range splits); partial lists are merged by merge_topk with the same
+//     canonical key, so the result does not depend on the split count, on the tiling or (after the
+//     all-gather) on the GPU count.
+//   * pack_items_kernel writes a copy of the item shard in MFMA-fragment order (one pass per call) so the
+//     scoring loops issue fully coalesced 1 KiB loads and no cross-lane shuffles.
+// Two kernels:
+//   * score_topk_kernel      one wave = one workgroup, waves never synchronise; two waves per SIMD hide each
+//                            other's stalls; optional soft lockstep of the waves of an XCD (L2 locality).
+//                            Small launches, every width, the row-major fallback.
+//   * score_topk_wg_kernel   the 8 waves of a workgroup walk the tiles together through a three-slot LDS ring
+//                            (1/8 of the L2 -> CU traffic): fp16 (where the per-wave stream is the bound) and
+//                            fp32 d=128 launches of >= 512 user groups.
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
