@@ -379,6 +379,9 @@ def main():
                          "accumulation (BASELINE.json configs[4]: --dtype f16 --items 50000000 --dim 256 --users 100000)")
     ap.add_argument("--generator", action="store_true",
                     help="configs[4]: build the (fp16) item table with the DropoutNet item tower first and report its rate")
+    ap.add_argument("--shard", choices=["items", "users"], default="items",
+                    help="N > 1: 'items' = item table row-sharded + all-gather(top-k) + merge (north_star); 'users' = item "
+                         "table replicated, user block cut across the ranks (zero-exchange validation mode)")
     ap.add_argument("--n-splits", type=int, default=0)
     ap.add_argument("--masks", choices=["warm", "none"], default="warm",
                     help="'warm' = rated CSR + 20%% cold-item bitmap (default); 'none' = diagnostic run without masks")
@@ -425,6 +428,8 @@ def main():
 
     I, d, k, Bu = args.items, args.dim, args.k, args.users_per_step
     lo, hi = rank * I // world, (rank + 1) * I // world
+    if args.shard == "users":
+        lo, hi = 0, I
     tdtype = torch.float16 if args.dtype == "f16" else torch.float32
     Bu = min(Bu, args.users)
     gen_leg = None
@@ -446,14 +451,19 @@ def main():
         rc = torch.from_numpy(col[rowptr[u0]:rowptr[u0 + Bu]]).to(dev)
         blocks.append((torch.arange(u0, u0 + Bu, dtype=torch.int32, device=dev), rp, rc))
 
-    engine = ShardedTopK(V, item_base=lo, n_items_global=I, k=k, world=world, rank=rank)
+    if args.shard == "users":
+        from coldrec_amd.eval import UserShardedTopK
+        engine = UserShardedTopK(V, k, world, rank)
+    else:
+        engine = ShardedTopK(V, item_base=lo, n_items_global=I, k=k, world=world, rank=rank)
     events = HipEvents(args.steps)
 
     def step(b, ev=None):
         users, rp, rc = blocks[b]
-        if args.masks == "none":
-            return engine.topk(U, users, None, None, None, n_splits=args.n_splits, kernel_events=ev)
-        return engine.topk(U, users, rp, rc, bitmap, n_splits=args.n_splits, kernel_events=ev)
+        m = (None, None, None) if args.masks == "none" else (rp, rc, bitmap)
+        if args.shard == "users":
+            return engine.topk(U, users, *m)
+        return engine.topk(U, users, *m, n_splits=args.n_splits, kernel_events=ev)
 
     def barrier():
         if world > 1:
@@ -475,8 +485,12 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = Bu * I / (ms_per_step * 1e-3)
-    kern_ms = float(np.mean(events.elapsed_ms()))
-    flops_per_launch = 2.0 * d * Bu * (hi - lo)
+    if args.shard == "users":                      # no kernel events in this mode: the step time stands in
+        kern_ms = ms_per_step
+        flops_per_launch = 2.0 * d * ((rank + 1) * Bu // world - rank * Bu // world) * I
+    else:
+        kern_ms = float(np.mean(events.elapsed_ms()))
+        flops_per_launch = 2.0 * d * Bu * (hi - lo)
     achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
     peak_tf = MFMA_F16_PEAK_TFLOPS if args.dtype == "f16" else MFMA_F32_PEAK_TFLOPS
 
@@ -487,11 +501,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[%d] full-catalogue eval: %d-row user table x %d items, d=%d, k=%d, %s tables, "
                                "user block %d per step, rated CSR (mean ~50) + 20%% cold-item bitmap ('warm' setting), "
-                               "item table row-sharded over %d GPU(s)"
-                               % (4 if args.dtype == "f16" else 3, args.users, I, d, k, args.dtype, Bu, world),
+                               "%s over %d GPU(s)"
+                               % (4 if args.dtype == "f16" else 3, args.users, I, d, k, args.dtype, Bu,
+                                  "item table row-sharded" if args.shard == "items" else "user block sharded, items replicated",
+                                  world),
                    "users_per_step": Bu, "items": I, "dim": d, "k": k,
-                   "parallelism": "item-row-shard x%d + all_gather(top-k) + canonical merge" % world if world > 1
-                   else "single GPU"},
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "item-row-shard x%d + all_gather(top-k) + canonical merge" % world if args.shard == "items"
+                                   else "user-block-shard x%d (items replicated) + all_gather" % world)},
         "roofline": {"bound": "mfma", "kernel": "score_topk%s_kernel<%s,%d>" % (
                          "_wg" if (Bu + 63) // 64 >= 512 and (args.dtype == "f16" or d == 128) else "", args.dtype, d),
                      "achieved": achieved,

@@ -181,6 +181,12 @@ eng = ShardedTopK(V[lo:hi], lo, n_items, k, world, rank, local_topk=local_topk, 
 s, i = eng.topk(U, None, rp, rc, bm)
 ws, wi = local_topk(U, None, V, k, rp, rc, bm)
 assert torch.equal(i, wi) and torch.equal(s.view(torch.int32), ws.view(torch.int32)), rank
+# user-sharded alternative: replicated items, users cut across the ranks (uneven: 37 users on 2 ranks)
+from coldrec_amd.eval import UserShardedTopK
+ueng = UserShardedTopK(V, k, world, rank, local_topk=local_topk)
+users_all = torch.arange(37, dtype=torch.int32)
+s2, i2 = ueng.topk(U, users_all, rp, rc, bm)
+assert torch.equal(i2, wi) and torch.equal(s2.view(torch.int32), ws.view(torch.int32)), ("user-sharded", rank)
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK", world)
