@@ -533,11 +533,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nu, ni = args.cpu_sample_users, min(args.cpu_sample_items, hi - lo)
         Uc, Vc = U[:nu].float().cpu(), V[:ni].float().cpu()   # the reference scores in fp32 (torch.matmul)
-        rate = cpu_baseline(Uc, Vc, rowptr[:nu + 1], col, cold, k, reps=2)
+        rate = cpu_baseline(Uc, Vc, rowptr[:nu + 1], col, cold, k, reps=4)
         result["cpu_baseline"] = {
             "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
-                      "%d threads, 2 reps" % (nu, ni, torch.__version__, os.cpu_count())}
+                      "%d threads, 4 reps (~12 s of CPU work)" % (nu, ni, torch.__version__, os.cpu_count())}
     if world > 1 and not args.no_train and args.dtype == "f32":
         try:                                   # every rank takes part; rank 0 reports
             del V, U, engine
