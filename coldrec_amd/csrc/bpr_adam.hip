@@ -51,8 +51,6 @@ struct BprArgs {
                            // split, where they were all-reduced over the ranks -- or NULL: reduce `partials`
     float* sums_out;       // [4] forward-only entry point: where bpr_sums_kernel leaves the batch sums
     int64_t B_global;      // batch size the means / norms refer to (== B unless data-parallel)
-    int32_t* heavy;        // [0] = count (zeroed by the forward kernel), [4..] = plan slots of rows with more
-                           // than BPR_HEAVY entries: found by the light backward pass, finished by one block each
 };
 
 template <int G>
@@ -81,7 +79,6 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(BprArgs a) {
     const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
     const int nvec = a.d >> 2;
     float su = 0.f, sp = 0.f, sn = 0.f, sl = 0.f;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.heavy) a.heavy[0] = 0;
     for (int64_t b = gid; b < a.B; b += gstride) {
         const int64_t ru = a.iu ? a.iu[b] : b, rp = a.ip ? a.ip[b] : b, rn = a.in_ ? a.in_[b] : b;
         const f32x4* pu = reinterpret_cast<const f32x4*>(a.tu + ru * a.d);
@@ -194,14 +191,18 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_kernel(BprArgs a) {
 //   [0] nu  [1] ni  [2] L = layout batch size (>= the batch; one stride for all batches of an epoch)
 //   [3 .. 3+L)  user rows touched (ascending), then (L+1) offsets into the user list, L triple ids
 //   grouped by user row; then 2L item rows, (2L+1) offsets, 2L entries  b | (role << 30)
-//   (role 0 = positive, 1 = negative).
+//   (role 0 = positive, 1 = negative); then [n_heavy, heavy row slots...] (see plan_heavy_off).
 // One lane group owns one touched row and sums its contributions in list order, then STORES the
 // row of the dense gradient table (which is zero everywhere else): no atomics, bit-reproducible.
-__host__ __device__ inline int64_t plan_ints(int64_t L) { return 3 + (3 * L + 1) + (6 * L + 1); }
+// The plan ends with the list of HEAVY rows (more than BPR_HEAVY entries): [n_heavy, slot, slot, ...] where a slot
+// is the row's position w in the concatenated (user rows, item rows) list; at most 3L/(BPR_HEAVY+1) of them.
+__host__ __device__ inline int64_t plan_heavy_cap(int64_t L) { return 3 * L / BPR_HEAVY + 2; }
+__host__ __device__ inline int64_t plan_heavy_off(int64_t L) { return 3 + (3 * L + 1) + (6 * L + 1); }
+__host__ __device__ inline int64_t plan_ints(int64_t L) { return plan_heavy_off(L) + 1 + plan_heavy_cap(L); }
 
 struct PlanView {
-    int n_u, n_i;
-    const int32_t *urow, *uptr, *ulist, *irow, *iptr, *ilist;
+    int n_u, n_i, n_heavy;
+    const int32_t *urow, *uptr, *ulist, *irow, *iptr, *ilist, *heavy;
 };
 
 __device__ __forceinline__ PlanView plan_view(const int32_t* pl) {
@@ -215,6 +216,8 @@ __device__ __forceinline__ PlanView plan_view(const int32_t* pl) {
     v.irow = v.ulist + L;
     v.iptr = v.irow + 2 * L;
     v.ilist = v.iptr + (2 * L + 1);
+    v.n_heavy = pl[plan_heavy_off(L)];
+    v.heavy = pl + plan_heavy_off(L) + 1;
     return v;
 }
 
@@ -332,67 +335,43 @@ __device__ __forceinline__ BwdCoef bwd_coef(const BprArgs& a, const float* tot) 
     return k;
 }
 
-// Light pass: one lane group per touched row with <= BPR_HEAVY entries (the row is summed in list order and
-// STORED); heavier rows are queued for bpr_bwd_heavy_kernel.  d <= 256 (one 16-B slice per lane).
+// Deterministic backward, ONE launch.  Blocks [0, light_blocks): one lane group per touched row with <= BPR_HEAVY
+// entries -- the row is summed in list order and STORED.  Blocks beyond: one block per heavy row of the plan's
+// heavy list; its lane groups split the row's entry list into contiguous chunks and the partial sums meet in a
+// fixed order (shuffle tree inside a wave, the 4 waves through LDS).  d <= 256 (one 16-B slice per lane).
 template <int G>
-__global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a) {
-    __shared__ float red[4];
-    __shared__ float tot[4];
-    batch_totals(a, tot, red);
-    const BwdCoef k = bwd_coef(a, tot);
-    const PlanView pv = plan_view(a.plan);
-    const int lig = threadIdx.x % G;
-    const int64_t gid = (int64_t)blockIdx.x * (BPR_THREADS / G) + threadIdx.x / G;
-    const int64_t gstride = (int64_t)gridDim.x * (BPR_THREADS / G);
-    const int nvec = a.d >> 2;
-    const bool on = lig < nvec;
-    for (int64_t w = gid; w < (int64_t)pv.n_u + pv.n_i; w += gstride) {
-        const bool user_side = w < pv.n_u;
-        const int64_t row = user_side ? pv.urow[w] : pv.irow[w - pv.n_u];
-        const int e0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
-        const int e1 = user_side ? pv.uptr[w + 1] : pv.iptr[w - pv.n_u + 1];
-        if (e1 - e0 > BPR_HEAVY) {
-            if (lig == 0) a.heavy[4 + atomicAdd(a.heavy, 1)] = (int32_t)w;
-            continue;
-        }
-        f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
-        if (on) own = reinterpret_cast<const f32x4*>((user_side ? a.tu : a.tp) + row * a.d)[lig];
-        grad_row_entries<G>(a, k, user_side, user_side ? pv.ulist : pv.ilist, e0, e1, lig, on, lig, own, acc);
-        if (on) *reinterpret_cast<f32x4*>((user_side ? a.gu : a.gp) + row * a.d + lig * 4) = acc;
-    }
-}
-
-// Heavy pass: block i takes queued row i; its lane groups split the row's entry list into contiguous chunks
-// and the partial sums meet in a fixed order (shuffle tree inside a wave, the 4 waves through LDS), so the
-// result does not depend on the order in which rows were queued.
-template <int G>
-__global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_heavy_kernel(BprArgs a) {
+__global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a, int light_blocks) {
     __shared__ float red[4];
     __shared__ float tot[4];
     __shared__ f32x4 wsum[4][G];
-    const int n_heavy = a.heavy[0];
-    if ((int)blockIdx.x >= n_heavy) return;
-    if (a.totals) {
-        if (threadIdx.x < 4) tot[threadIdx.x] = a.totals[threadIdx.x];
-        __syncthreads();
-    } else {
-        batch_totals(a, tot, red);
-    }
-    BwdCoef k;
-    {
-        k.invB = 1.0f / (float)a.B_global;
-        const float nu_ = sqrtf(tot[0]), np_ = sqrtf(tot[1]), nn = sqrtf(tot[2]);
-        k.cu = nu_ > 0.f ? a.reg * k.invB / nu_ : 0.f;
-        k.cp = np_ > 0.f ? a.reg * k.invB / np_ : 0.f;
-        k.cn = nn > 0.f ? a.reg * k.invB / nn : 0.f;
-    }
     const PlanView pv = plan_view(a.plan);
-    constexpr int NGB = BPR_THREADS / G;
-    const int lig = threadIdx.x % G, gg = threadIdx.x / G;
+    if ((int)blockIdx.x >= light_blocks && (int)blockIdx.x - light_blocks >= pv.n_heavy) return;   // surplus block
+    batch_totals(a, tot, red);
+    const BwdCoef k = bwd_coef(a, tot);
+    const int lig = threadIdx.x % G;
     const int nvec = a.d >> 2;
     const bool on = lig < nvec;
-    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const int64_t w = a.heavy[4 + h];
+    if ((int)blockIdx.x < light_blocks) {
+        const int64_t gid = (int64_t)blockIdx.x * (BPR_THREADS / G) + threadIdx.x / G;
+        const int64_t gstride = (int64_t)light_blocks * (BPR_THREADS / G);
+        for (int64_t w = gid; w < (int64_t)pv.n_u + pv.n_i; w += gstride) {
+            const bool user_side = w < pv.n_u;
+            const int64_t row = user_side ? pv.urow[w] : pv.irow[w - pv.n_u];
+            const int e0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
+            const int e1 = user_side ? pv.uptr[w + 1] : pv.iptr[w - pv.n_u + 1];
+            if (e1 - e0 > BPR_HEAVY) continue;                    // on the heavy list
+            f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
+            if (on) own = reinterpret_cast<const f32x4*>((user_side ? a.tu : a.tp) + row * a.d)[lig];
+            grad_row_entries<G>(a, k, user_side, user_side ? pv.ulist : pv.ilist, e0, e1, lig, on, lig, own, acc);
+            if (on) *reinterpret_cast<f32x4*>((user_side ? a.gu : a.gp) + row * a.d + lig * 4) = acc;
+        }
+        return;
+    }
+    constexpr int NGB = BPR_THREADS / G;
+    const int gg = threadIdx.x / G;
+    const int heavy_blocks = (int)gridDim.x - light_blocks;
+    for (int h = (int)blockIdx.x - light_blocks; h < pv.n_heavy; h += heavy_blocks) {
+        const int64_t w = pv.heavy[h];
         const bool user_side = w < pv.n_u;
         const int64_t row = user_side ? pv.urow[w] : pv.irow[w - pv.n_u];
         const int r0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
@@ -528,10 +507,20 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
     __syncthreads();
     bitonic_sort_lds(keys, P);
     const int ni = plan_emit(keys, P, irow, iptr, ilist, scan);
+    // heavy rows (order irrelevant: every heavy row is summed on its own, in a fixed order)
+    int32_t* hv = pl + plan_heavy_off(L);
+    if (threadIdx.x == 0) scan[0] = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < nu + ni; r += PLAN_THREADS) {
+        const int c = r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu];
+        if (c > BPR_HEAVY) hv[1 + atomicAdd(&scan[0], 1)] = r;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         pl[0] = nu;
         pl[1] = ni;
         pl[2] = L;
+        hv[0] = scan[0];
     }
 }
 
@@ -733,6 +722,13 @@ extern "C" int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32
     iptr[ni] = (int32_t)(2 * B);
     pl[0] = nu;
     pl[1] = ni;
+    int32_t* hv = pl + plan_heavy_off(L);
+    int nh = 0;
+    for (int r = 0; r < nu; ++r)
+        if (uptr[r + 1] - uptr[r] > BPR_HEAVY) hv[1 + nh++] = r;
+    for (int r = 0; r < ni; ++r)
+        if (iptr[r + 1] - iptr[r] > BPR_HEAVY) hv[1 + nh++] = nu + r;
+    hv[0] = nh;
     return CRH_OK;
 }
 
@@ -758,9 +754,8 @@ extern "C" int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_id
 
 extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {
     if (batch <= 0) return 0;
-    // forward partials, per-triple score differences, queue of heavy gradient rows (<= 3B/33 of them)
-    return (size_t)BPR_MAX_BLOCKS * 16 + (((size_t)batch * 4 + 255) & ~(size_t)255) +
-           (size_t)(3 * batch / BPR_HEAVY + 8) * 4 + 256;
+    // forward partials, per-triple score differences
+    return (size_t)BPR_MAX_BLOCKS * 16 + (((size_t)batch * 4 + 255) & ~(size_t)255) + 256;
 }
 
 namespace {
@@ -793,7 +788,6 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
     a.gu = grad_user; a.gp = grad_pos; a.gn = grad_neg;
     a.partials = reinterpret_cast<float*>(workspace);
     a.xbuf = a.partials + (size_t)BPR_MAX_BLOCKS * 4;
-    a.heavy = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.xbuf) + (((size_t)batch * 4 + 255) & ~(size_t)255));
     a.loss_out = loss_out;
     a.plan = plan;
     a.totals = totals;
@@ -822,12 +816,9 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
         if (plan) {
             int64_t rb = (3 * batch + per_block - 1) / per_block;      // <= 3B touched rows
             if (rb > BPR_MAX_BLOCKS) rb = BPR_MAX_BLOCKS;
-            if (!(phases & 1)) CRH_HIP(hipMemsetAsync(a.heavy, 0, 4, st));   // the forward normally zeroes it
-            hipLaunchKernelGGL(bpr_bwd_rows_kernel<GG>, dim3((unsigned)rb), dim3(BPR_THREADS), 0, st, a);
-            CRH_HIP(hipGetLastError());
             int64_t hb = 3 * batch / BPR_HEAVY + 1;                     // worst case; surplus blocks exit at once
             if (hb > 512) hb = 512;
-            hipLaunchKernelGGL(bpr_bwd_heavy_kernel<GG>, dim3((unsigned)hb), dim3(BPR_THREADS), 0, st, a);
+            hipLaunchKernelGGL(bpr_bwd_rows_kernel<GG>, dim3((unsigned)(rb + hb)), dim3(BPR_THREADS), 0, st, a, (int)rb);
             CRH_HIP(hipGetLastError());
         } else if (bwd_blocks) {
             hipLaunchKernelGGL(bpr_bwd_kernel<GG>, dim3(bwd_blocks), dim3(BPR_THREADS), 0, st, a);

@@ -300,8 +300,25 @@ def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Ten
         return nseg.to(torch.int32)
 
     plans[:, 2] = L
-    plans[:, 0] = side([user_idx], [bl], L, 3)
-    plans[:, 1] = side([pos_idx, neg_idx], [bl, bl + (1 << 30)], 2 * L, 3 + 3 * L + 1)
+    nu = side([user_idx], [bl], L, 3)
+    ni = side([pos_idx, neg_idx], [bl, bl + (1 << 30)], 2 * L, 3 + 3 * L + 1)
+    plans[:, 0], plans[:, 1] = nu, ni
+    # heavy rows (more than HEAVY entries): [count, slots...] behind the item lists; slot = position in (users, items)
+    HEAVY = 32                                       # BPR_HEAVY of csrc/bpr_adam.hip
+    hoff = 3 + (3 * L + 1) + (6 * L + 1)
+    uptr = plans[:, 3 + L: 3 + 2 * L + 1].to(torch.int64)
+    off_i = 3 + 3 * L + 1
+    iptr = plans[:, off_i + 2 * L: off_i + 4 * L + 1].to(torch.int64)
+    ar_u = torch.arange(L, device=dev)[None, :]
+    ar_i = torch.arange(2 * L, device=dev)[None, :]
+    hu = ((uptr[:, 1:] - uptr[:, :-1]) > HEAVY) & (ar_u < nu[:, None])
+    hi = ((iptr[:, 1:] - iptr[:, :-1]) > HEAVY) & (ar_i < ni[:, None])
+    mask = torch.cat([hu, hi], dim=1)
+    slots = torch.cat([ar_u.expand(nb, -1), nu[:, None].to(torch.int64) + ar_i.expand(nb, -1)], dim=1)
+    pos = torch.cumsum(mask, dim=1) - 1
+    t_idx, c_idx = torch.nonzero(mask, as_tuple=True)
+    plans[t_idx, hoff + 1 + pos[t_idx, c_idx]] = slots[t_idx, c_idx].to(torch.int32)
+    plans[:, hoff] = mask.sum(1).to(torch.int32)
     return plans
 
 

@@ -128,9 +128,11 @@ int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, in
  * grad_* are dense tables the gradients are ACCUMULATED into (zero them first; pos and neg may be the
  * same table); pass all three NULL for forward only.  loss_out[0] = bpr, loss_out[1] = l2 (device).
  * plan (device int32, or NULL): the batch's reverse index -- [nu, ni, L, user rows[L], offsets[L+1],
- * triple ids[L], item rows[2L], offsets[2L+1], entries[2L] = b | role<<30], L >= batch the layout size --
- * built by crh_bpr_plan_build_host or on the device (coldrec_amd/train.py build_plans_device).  With a plan every touched gradient row is summed in a fixed order by one
- * lane group and STORED (deterministic, no atomics; rows not touched are left as they are, i.e. zero);
+ * triple ids[L], item rows[2L], offsets[2L+1], entries[2L] = b | role<<30, n_heavy, heavy slots[3L/32+2]],
+ * L >= batch the layout size; a heavy slot names a row with more than 32 entries (r < nu: user row r, else item
+ * row r - nu), in any order -- built by crh_bpr_plan_build_host or on the device (crh_bpr_plan_build).  With a
+ * plan every touched gradient row is summed in a fixed order (by one lane group; a heavy row by one workgroup, in
+ * the same launch) and STORED (deterministic, no atomics; rows not touched are left as they are, i.e. zero);
  * it requires pos_table == neg_table and grad_pos == grad_neg.  Without a plan rows are accumulated
  * with fp32 atomics.
  */

@@ -51,8 +51,12 @@ def _plan_views(plan):
     urow, uptr, ulist = plan[3:3 + L], plan[3 + L:4 + 2 * L], plan[4 + 2 * L:4 + 3 * L]
     o = 4 + 3 * L
     irow, iptr, ilist = plan[o:o + 2 * L], plan[o + 2 * L:o + 4 * L + 1], plan[o + 4 * L + 1:o + 6 * L + 1]
+    ho = 3 + (3 * L + 1) + (6 * L + 1)                       # heavy rows: [count, slots...] (any order)
+    heavy = np.sort(plan[ho + 1: ho + 1 + int(plan[ho])])
+    cnt = np.concatenate([np.diff(uptr[:nu + 1]), np.diff(iptr[:ni + 1])])
+    assert np.array_equal(heavy, np.nonzero(cnt > 32)[0]), "heavy list != rows with more than 32 entries"
     return dict(urow=urow[:nu], uptr=uptr[:nu + 1], ulist=ulist[:uptr[nu]], irow=irow[:ni], iptr=iptr[:ni + 1],
-                ilist=ilist[:iptr[ni]])
+                ilist=ilist[:iptr[ni]], heavy=heavy)
 
 
 @pytest.mark.parametrize("B,L", [(1, 1), (37, 64), (4096, 4096)])
@@ -98,7 +102,7 @@ def test_plan_kernel_whole_epoch_with_short_last_batch():
     u, p, n = (rng.integers(0, 700, n_rec).astype(np.int32) for _ in range(3))
     dev = ops.build_plans_device(t(u), t(p), t(n), L).cpu().numpy()
     host = ops.build_plans(u, p, n, L)
-    assert dev.shape == host.shape == (3, 9 * L + 5)
+    assert dev.shape == host.shape == (3, 9 * L + 5 + 1 + (3 * L // 32 + 2))   # + [n_heavy, slots...]
     for b in range(3):
         for k, v in _plan_views(host[b]).items():
             assert np.array_equal(v, _plan_views(dev[b])[k]), (b, k)
