@@ -65,6 +65,14 @@ SIGNATURES = {
     "crh_sampler_get_state": (_i32, [_vp, _vp, _vp]),
     "crh_sampler_num_records": (_i64, [_vp]),
     "crh_sampler_epoch": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "crh_sampler_set_catalogue": (_i32, [_vp, _i32, _vp]),
+    "crh_sampler_set_py_state": (_i32, [_vp, _vp, _i32]),
+    "crh_sampler_get_py_state": (_i32, [_vp, _vp, _vp]),
+    "crh_sampler_min_candidates": (_i64, [_vp]),
+    "crh_sampler_epoch_lara": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "crh_sampler_epoch_clcrec": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "crh_sampler_epoch_ccfcrec": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crh_sampler_epoch_cgrc": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64]),
 }
 
 

@@ -7,6 +7,13 @@
 // masked rejection over 32-bit draws and shuffle is Fisher-Yates from the top with the same
 // bounded draw -- all restated here so a whole epoch of triples is produced
 // in a few milliseconds on one host thread, off the GPU's critical path.  Pure host code: no HIP call.
+//
+// The other samplers of util/utils.py are restated below the same way:
+// next_batch_pairwise_LARA (:160-188), _CLCRec (:191-233), _CCFCRec (:237-300) draw from CPython's `random`
+// module (also MT19937: getrandbits(k) = top k bits of one 32-bit output, _randbelow(n) = rejection over
+// getrandbits(n.bit_length()), shuffle = Fisher-Yates from the top, sample = pool / selected-set), CCFCRec
+// additionally from NumPy's stream for the positives; next_batch_cgrc (:303-336) draws from NumPy only and
+// returns list(set(...)), whose order is CPython's set-table slot order (restated in IntSet).
 #include <stdint.h>
 #include <string.h>
 
@@ -59,6 +66,61 @@ struct MT19937 {
         while ((v = (next() & mask)) > max) {}
         return v;
     }
+    // CPython random._randbelow_with_getrandbits(n), n < 2^32: k = n.bit_length(); r = getrandbits(k) until r < n
+    inline uint32_t py_randbelow(uint32_t n) {
+        if (n == 0) return 0;
+        const int shift = __builtin_clz(n);          // 32 - bit_length
+        uint32_t r;
+        while ((r = (next() >> shift)) >= n) {}
+        return r;
+    }
+};
+
+// Order of list(set_of_small_ints) in CPython 3.7 - 3.12 (Objects/setobject.c): open addressing, hash(i) = i,
+// 9 linear probes then the perturbed jump; the table is rebuilt (slot order) at 4x (2x beyond 50000) the used
+// count once fill * 5 >= mask * 3.  No deletions happen on this path, so there are no dummy entries.
+struct IntSet {
+    std::vector<int32_t> tab;      // -1 = unused
+    size_t mask = 7, used = 0;
+    IntSet() : tab(8, -1) {}
+    void clear() { tab.assign(8, -1); mask = 7; used = 0; }
+    static void insert_clean(std::vector<int32_t>& t, size_t m, int32_t key) {
+        size_t perturb = (size_t)key, i = (size_t)key & m;
+        for (;;) {
+            if (t[i] < 0) { t[i] = key; return; }
+            if (i + 9 <= m)
+                for (size_t j = 1; j <= 9; ++j)
+                    if (t[i + j] < 0) { t[i + j] = key; return; }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & m;
+        }
+    }
+    void add(int32_t key) {
+        size_t perturb = (size_t)key, i = (size_t)key & mask;
+        for (;;) {
+            const size_t probes = (i + 9 <= mask) ? 9 : 0;
+            for (size_t j = 0; j <= probes; ++j) {
+                if (tab[i + j] == key) return;
+                if (tab[i + j] < 0) {
+                    tab[i + j] = key;
+                    ++used;
+                    if (used * 5 >= mask * 3) {
+                        const size_t want = used > 50000 ? used * 2 : used * 4;
+                        size_t size = 8;
+                        while (size <= want) size <<= 1;
+                        std::vector<int32_t> nt(size, -1);
+                        for (int32_t k : tab)
+                            if (k >= 0) insert_clean(nt, size - 1, k);
+                        tab.swap(nt);
+                        mask = size - 1;
+                    }
+                    return;
+                }
+            }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
 };
 
 }  // namespace
@@ -73,7 +135,47 @@ struct crh_sampler {
     std::vector<int32_t> check, next_check;
     std::vector<uint64_t> bits;           // users x items membership bitmap when it is small enough to stay cached
     int64_t words_per_user = 0;
+    // --- the other samplers (set by crh_sampler_set_catalogue) ---
+    MT19937 pyrng;                        // CPython `random` module stream
+    int32_t n_users_seen = 0;             // len(data.user): the negative-user pool of LARA / CCFCRec
+    std::vector<int64_t> first_ptr;       // per user: distinct training items in first-appearance (dict) order
+    std::vector<int32_t> first_items;
+    std::vector<int32_t> warm_items;      // non-cold item ids ascending = the CLCRec / CCFCRec candidate pool order
+    std::vector<int64_t> rw_ptr;          // per user: ranks (in warm_items) of its distinct training items, ascending
+    std::vector<int32_t> rw_rank;
+    std::vector<int32_t> picked;          // random.sample scratch (copy-the-pool branch)
+    std::vector<int32_t> cand_list;       // one user's candidate list, materialised when a record draws many times
+    std::vector<uint32_t> stamp;          // random.sample's "selected" set as per-position stamps
+    uint32_t stamp_now = 0;
+    std::vector<int32_t> item_users;      // per item: distinct training users (a full item has no negative user)
+    IntSet bset;
+    bool catalogue = false;
+    int64_t n_candidates(int32_t u) const { return (int64_t)warm_items.size() - (rw_ptr[u + 1] - rw_ptr[u]); }
+    // j-th (0-based) entry of [k for k in warm item order if k not in training_set_u[user]]
+    int32_t candidate(int32_t u, int64_t j) const {
+        const int32_t* r = rw_rank.data() + rw_ptr[u];
+        int64_t lo = 0, hi = rw_ptr[u + 1] - rw_ptr[u];          // count of i with r[i] - i <= j (non-decreasing in i)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)r[mid] - mid <= j) lo = mid + 1; else hi = mid;
+        }
+        return warm_items[(size_t)(j + lo)];
+    }
+    // the whole list (merge of the pool with the user's sorted ranks): pays off from about pool/16 draws per record
+    const int32_t* materialise(int32_t u) {
+        const int32_t* r = rw_rank.data() + rw_ptr[u];
+        const int64_t nr = rw_ptr[u + 1] - rw_ptr[u], nw = (int64_t)warm_items.size();
+        cand_list.resize((size_t)(nw - nr));
+        int64_t w = 0, k = 0;
+        for (int64_t i = 0; i <= nr; ++i) {
+            const int64_t stop = i < nr ? r[i] : nw;
+            for (; k < stop; ++k) cand_list[(size_t)w++] = warm_items[(size_t)k];
+            ++k;
+        }
+        return cand_list.data();
+    }
     bool rated(int32_t u, int32_t it) const {
+        if (u >= n_users) return false;
         if (words_per_user) return (bits[(size_t)u * words_per_user + (it >> 6)] >> (it & 63)) & 1u;
         const int32_t* lo = items.data() + rowptr[u];
         const int32_t* hi = items.data() + rowptr[u + 1];
@@ -178,6 +280,246 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
                 if (s->rated(user_out_host[t], neg_out_host[t])) s->next_check.push_back(t);
             s->check.swap(s->next_check);
         }
+    }
+    return CRH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The other samplers of util/utils.py.  All of them walk the shuffled records one by one, so
+// the batch size only cuts the output (except next_batch_cgrc, whose item set is per batch).
+// ------------------------------------------------------------------------------------------------------------
+
+extern "C" int crh_sampler_set_catalogue(crh_sampler* s, int32_t n_users_seen, const uint8_t* item_is_cold_host) {
+    CRH_CHECK_ARG(s && n_users_seen > 0, "crh_sampler_set_catalogue: bad arguments");
+    const int64_t n = (int64_t)s->rec_u.size();
+    s->n_users_seen = n_users_seen;
+    // dict order of training_set_u[user]: distinct items by first appearance in the (unshuffled) records
+    std::vector<int64_t> cnt((size_t)s->n_users + 1, 0);
+    std::vector<uint8_t> first(n, 0);
+    {
+        std::vector<int64_t> idx(n);
+        for (int64_t r = 0; r < n; ++r) idx[r] = r;
+        std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+            return s->rec_u[a] != s->rec_u[b] ? s->rec_u[a] < s->rec_u[b] : s->rec_i[a] < s->rec_i[b];
+        });
+        for (int64_t t = 0; t < n; ++t) {
+            const int64_t r = idx[t];
+            if (t == 0 || s->rec_u[idx[t - 1]] != s->rec_u[r] || s->rec_i[idx[t - 1]] != s->rec_i[r]) {
+                first[r] = 1;                               // stable sort: the earliest record of each (user, item)
+                cnt[s->rec_u[r] + 1]++;
+            }
+        }
+    }
+    s->item_users.assign((size_t)s->n_items, 0);
+    for (int64_t r = 0; r < n; ++r)
+        if (first[r]) s->item_users[s->rec_i[r]]++;
+    s->first_ptr.assign(cnt.begin(), cnt.end());
+    for (int32_t u = 0; u < s->n_users; ++u) s->first_ptr[u + 1] += s->first_ptr[u];
+    s->first_items.resize((size_t)s->first_ptr[s->n_users]);
+    std::vector<int64_t> fill(s->first_ptr.begin(), s->first_ptr.end() - 1);
+    for (int64_t r = 0; r < n; ++r)
+        if (first[r]) s->first_items[(size_t)fill[s->rec_u[r]]++] = s->rec_i[r];
+    // candidate pool: items in id order that are not cold; per user the pool ranks of its training items
+    std::vector<int32_t> rank((size_t)s->n_items, -1);
+    s->warm_items.clear();
+    for (int32_t it = 0; it < s->n_items; ++it)
+        if (!item_is_cold_host || !item_is_cold_host[it]) {
+            rank[it] = (int32_t)s->warm_items.size();
+            s->warm_items.push_back(it);
+        }
+    s->rw_ptr.assign((size_t)s->n_users + 1, 0);
+    s->rw_rank.clear();
+    for (int32_t u = 0; u < s->n_users; ++u) {
+        int32_t prev = -1;
+        for (int64_t e = s->rowptr[u]; e < s->rowptr[u + 1]; ++e) {      // ascending ids, duplicates adjacent
+            const int32_t it = s->items[e];
+            if (it != prev && rank[it] >= 0) s->rw_rank.push_back(rank[it]);
+            prev = it;
+        }
+        s->rw_ptr[u + 1] = (int64_t)s->rw_rank.size();
+    }
+    s->pyrng.seed(5489u);
+    s->catalogue = true;
+    return CRH_OK;
+}
+
+extern "C" int crh_sampler_set_py_state(crh_sampler* s, const uint32_t* key624_host, int pos) {
+    CRH_CHECK_ARG(s && key624_host && pos >= 0 && pos <= 624, "crh_sampler_set_py_state: bad arguments");
+    memcpy(s->pyrng.key, key624_host, sizeof(s->pyrng.key));
+    s->pyrng.pos = pos;
+    return CRH_OK;
+}
+
+extern "C" int crh_sampler_get_py_state(const crh_sampler* s, uint32_t* key624_host, int* pos_host) {
+    CRH_CHECK_ARG(s && key624_host && pos_host, "crh_sampler_get_py_state: bad arguments");
+    memcpy(key624_host, s->pyrng.key, sizeof(s->pyrng.key));
+    *pos_host = s->pyrng.pos;
+    return CRH_OK;
+}
+
+extern "C" int64_t crh_sampler_min_candidates(const crh_sampler* s) {
+    if (!s || !s->catalogue) return -1;
+    int64_t m = (int64_t)s->warm_items.size();
+    for (int32_t u = 0; u < s->n_users; ++u)
+        if (s->rowptr[u + 1] > s->rowptr[u]) m = std::min(m, s->n_candidates(u));
+    return m;
+}
+
+namespace {
+// random.shuffle(training_data): for i = n-1 .. 1: j = _randbelow(i + 1); swap
+void py_shuffle(crh_sampler* s) {
+    for (int64_t i = (int64_t)s->order.size() - 1; i >= 1; --i)
+        std::swap(s->order[i], s->order[s->pyrng.py_randbelow((uint32_t)(i + 1))]);
+}
+// neg_user = choice(user_list) until it is not in training_set_i[item]      (utils.py:183-185, 263-265)
+inline int32_t draw_neg_user(crh_sampler* s, int32_t item) {
+    int32_t v;
+    do { v = (int32_t)s->pyrng.py_randbelow((uint32_t)s->n_users_seen); } while (s->rated(v, item));
+    return v;
+}
+}  // namespace
+
+// util/utils.py:160-188.  neg_* hold n_records * n_negs entries (the reference appends n_negs per record).
+extern "C" int crh_sampler_epoch_lara(crh_sampler* s, int32_t n_negs, int32_t* user_out_host, int32_t* item_out_host,
+                                      int32_t* neg_user_out_host, int32_t* neg_item_out_host) {
+    CRH_CHECK_ARG(s && s->catalogue, "crh_sampler_epoch_lara: call crh_sampler_set_catalogue first");
+    CRH_CHECK_ARG(user_out_host && item_out_host && neg_user_out_host && neg_item_out_host && n_negs >= 0,
+                  "crh_sampler_epoch_lara: bad arguments");
+    py_shuffle(s);
+    const int64_t n = (int64_t)s->order.size();
+    for (int64_t t = 0; t < n; ++t) {
+        const int32_t u = s->rec_u[s->order[t]], it = s->rec_i[s->order[t]];
+        user_out_host[t] = u;
+        item_out_host[t] = it;
+        // the reference's rejection loops never end for these records; fail instead of hanging the host
+        CRH_CHECK_ARG(n_negs == 0 || (s->first_ptr[u + 1] - s->first_ptr[u] < s->n_items && s->item_users[it] < s->n_users_seen),
+                      "crh_sampler_epoch_lara: user %d rated every item or item %d is rated by every user", (int)u, (int)it);
+        for (int32_t m = 0; m < n_negs; ++m) {
+            int32_t v;
+            do { v = (int32_t)s->pyrng.py_randbelow((uint32_t)s->n_items); } while (s->rated(u, v));
+            neg_item_out_host[t * n_negs + m] = v;
+            neg_user_out_host[t * n_negs + m] = draw_neg_user(s, it);
+        }
+    }
+    return CRH_OK;
+}
+
+// util/utils.py:191-233.  item_out (n_records, 1 + n_negs): the positive, then random.sample(candidates, n_negs).
+// sample_setsize = 21 (+ 4 ** ceil(log(3 * n_negs, 4)) when n_negs > 5), computed by the caller with Python's
+// own math so that the pool / selected-set switch of random.sample falls where CPython puts it.
+extern "C" int crh_sampler_epoch_clcrec(crh_sampler* s, int32_t n_negs, int64_t sample_setsize, int32_t* user_out_host,
+                                        int32_t* item_out_host) {
+    CRH_CHECK_ARG(s && s->catalogue, "crh_sampler_epoch_clcrec: call crh_sampler_set_catalogue first");
+    CRH_CHECK_ARG(user_out_host && item_out_host && n_negs >= 0 && sample_setsize >= 21,
+                  "crh_sampler_epoch_clcrec: bad arguments");
+    CRH_CHECK_ARG(!s->warm_items.empty(), "next_batch_pairwise_CLCRec: warm-item negative pool is empty; check cold_item split.");
+    py_shuffle(s);
+    const int64_t n = (int64_t)s->order.size(), w = 1 + n_negs;
+    for (int64_t t = 0; t < n; ++t) {
+        const int32_t u = s->rec_u[s->order[t]];
+        user_out_host[t] = u;
+        int32_t* row = item_out_host + t * w;
+        row[0] = s->rec_i[s->order[t]];
+        const int64_t nc = s->n_candidates(u);
+        CRH_CHECK_ARG(nc >= n_negs, "next_batch_pairwise_CLCRec: user has only %lld warm negatives available but n_negs=%d.",
+                      (long long)nc, (int)n_negs);
+        if (nc <= sample_setsize) {                       // pool = list(population); result[i] = pool[j]; pool[j] = pool[n-i-1]
+            s->picked.resize((size_t)nc);
+            for (int64_t c = 0; c < nc; ++c) s->picked[c] = s->candidate(u, c);
+            for (int32_t i = 0; i < n_negs; ++i) {
+                const uint32_t j = s->pyrng.py_randbelow((uint32_t)(nc - i));
+                row[1 + i] = s->picked[j];
+                s->picked[j] = s->picked[nc - i - 1];
+            }
+        } else {                                          // selected-set variant: redraw positions already taken
+            if (s->stamp.size() < (size_t)nc) s->stamp.resize(s->warm_items.size(), 0);
+            if (++s->stamp_now == 0) { std::fill(s->stamp.begin(), s->stamp.end(), 0u); s->stamp_now = 1; }
+            const int32_t* list = (int64_t)n_negs * 16 > nc ? s->materialise(u) : nullptr;
+            for (int32_t i = 0; i < n_negs; ++i) {
+                uint32_t j;
+                do { j = s->pyrng.py_randbelow((uint32_t)nc); } while (s->stamp[j] == s->stamp_now);
+                s->stamp[j] = s->stamp_now;
+                row[1 + i] = list ? list[j] : s->candidate(u, j);
+            }
+        }
+    }
+    return CRH_OK;
+}
+
+// util/utils.py:237-300.  pos_items_out (n, P) from NumPy's stream; neg_items_out (n, P, N) and self_neg_out (n, S)
+// from CPython's.
+extern "C" int crh_sampler_epoch_ccfcrec(crh_sampler* s, int32_t positive_number, int32_t negative_number,
+                                         int32_t self_neg_number, int32_t* user_out_host, int32_t* item_out_host,
+                                         int32_t* neg_user_out_host, int32_t* pos_items_out_host,
+                                         int32_t* neg_items_out_host, int32_t* self_neg_out_host) {
+    CRH_CHECK_ARG(s && s->catalogue, "crh_sampler_epoch_ccfcrec: call crh_sampler_set_catalogue first");
+    CRH_CHECK_ARG(user_out_host && item_out_host && neg_user_out_host && pos_items_out_host && neg_items_out_host &&
+                  self_neg_out_host && positive_number >= 0 && negative_number >= 0 && self_neg_number >= 0,
+                  "crh_sampler_epoch_ccfcrec: bad arguments");
+    CRH_CHECK_ARG(!s->warm_items.empty(),
+                  "next_batch_pairwise_CCFCRec: warm-item candidate pool is empty; check the cold item split.");
+    py_shuffle(s);
+    const int64_t n = (int64_t)s->order.size(), P = positive_number, PN = P * negative_number, S = self_neg_number;
+    for (int64_t t = 0; t < n; ++t) {
+        const int32_t u = s->rec_u[s->order[t]], it = s->rec_i[s->order[t]];
+        user_out_host[t] = u;
+        item_out_host[t] = it;
+        CRH_CHECK_ARG(s->item_users[it] < s->n_users_seen,
+                      "crh_sampler_epoch_ccfcrec: item %d is rated by every user (no negative user exists)", (int)it);
+        neg_user_out_host[t] = draw_neg_user(s, it);
+        // np.random.choice(list(training_set_u[user]), P, replace=True) = list[randint(0, len, P)]
+        const int32_t* pos = s->first_items.data() + s->first_ptr[u];
+        const uint32_t np1 = (uint32_t)(s->first_ptr[u + 1] - s->first_ptr[u]) - 1u;
+        for (int64_t m = 0; m < P; ++m) pos_items_out_host[t * P + m] = pos[s->rng.bounded(np1)];
+        const int64_t nc = s->n_candidates(u);
+        CRH_CHECK_ARG(nc > 0, "next_batch_pairwise_CCFCRec: user %d has no warm negative items available after "
+                              "excluding cold items and training positives.", (int)u);
+        if ((PN + S) * 16 > nc) {
+            const int32_t* list = s->materialise(u);
+            for (int64_t m = 0; m < PN; ++m) neg_items_out_host[t * PN + m] = list[s->pyrng.py_randbelow((uint32_t)nc)];
+            for (int64_t m = 0; m < S; ++m) self_neg_out_host[t * S + m] = list[s->pyrng.py_randbelow((uint32_t)nc)];
+        } else {
+            for (int64_t m = 0; m < PN; ++m) neg_items_out_host[t * PN + m] = s->candidate(u, s->pyrng.py_randbelow((uint32_t)nc));
+            for (int64_t m = 0; m < S; ++m) self_neg_out_host[t * S + m] = s->candidate(u, s->pyrng.py_randbelow((uint32_t)nc));
+        }
+    }
+    return CRH_OK;
+}
+
+// util/utils.py:303-336.  Per batch the shared item set B = positives U up to ranking_neg_per_user non-rated draws
+// per record (at most 50x that many tries), returned in CPython's list(set) order: bset_out[bset_ptr[b] ..
+// bset_ptr[b+1]).  bset_ptr_out holds n_batches + 1 offsets; capacity = entries bset_out can take.
+extern "C" int crh_sampler_epoch_cgrc(crh_sampler* s, int64_t batch_size, int32_t ranking_neg_per_user,
+                                      int32_t* user_out_host, int32_t* item_out_host, int64_t* bset_ptr_out_host,
+                                      int32_t* bset_out_host, int64_t capacity) {
+    CRH_CHECK_ARG(s && user_out_host && item_out_host && bset_ptr_out_host && bset_out_host && batch_size > 0 &&
+                  ranking_neg_per_user >= 0, "crh_sampler_epoch_cgrc: bad arguments");
+    const int64_t n = (int64_t)s->order.size();
+    for (int64_t i = n - 1; i >= 1; --i) std::swap(s->order[i], s->order[s->rng.bounded((uint32_t)i)]);   // np.random.shuffle
+    const uint32_t imax = (uint32_t)(s->n_items - 1);
+    const int64_t max_tries = (int64_t)ranking_neg_per_user * 50;
+    int64_t w = 0, b = 0;
+    bset_ptr_out_host[0] = 0;
+    for (int64_t lo = 0; lo < n; lo += batch_size, ++b) {
+        const int64_t hi = std::min(lo + batch_size, n);
+        s->bset.clear();
+        for (int64_t t = lo; t < hi; ++t) {
+            user_out_host[t] = s->rec_u[s->order[t]];
+            item_out_host[t] = s->rec_i[s->order[t]];
+            s->bset.add(item_out_host[t]);
+        }
+        for (int64_t t = lo; t < hi; ++t) {
+            int64_t added = 0, tries = 0;
+            while (added < ranking_neg_per_user && tries < max_tries) {
+                ++tries;
+                const int32_t j = (int32_t)s->rng.bounded(imax);
+                if (!s->rated(user_out_host[t], j)) { s->bset.add(j); ++added; }
+            }
+        }
+        CRH_CHECK_ARG(w + (int64_t)s->bset.used <= capacity, "crh_sampler_epoch_cgrc: item-set buffer too small");
+        for (int32_t k : s->bset.tab)
+            if (k >= 0) bset_out_host[w++] = k;
+        bset_ptr_out_host[b + 1] = w;
     }
     return CRH_OK;
 }

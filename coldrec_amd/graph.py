@@ -36,6 +36,10 @@ class _SpmmFn(torch.autograd.Function):
         return None, gx
 
 
+_KEEP_WRAPPED = (torch.Tensor.to, torch.Tensor.cuda, torch.Tensor.cpu, torch.Tensor.float, torch.Tensor.detach,
+                 torch.Tensor.clone, torch.Tensor.coalesce)
+
+
 class HipSparseAdj(torch.Tensor):
     @staticmethod
     def from_scipy(X) -> "HipSparseAdj":
@@ -69,9 +73,12 @@ class HipSparseAdj(torch.Tensor):
         if func is torch.sparse.mm and len(args) == 2 and isinstance(args[0], HipSparseAdj) \
                 and isinstance(args[1], torch.Tensor) and args[1].is_cuda and args[1].shape[1] % 4 == 0:
             return _SpmmFn.apply(args[0], args[1])
-        if func in (torch.Tensor.to, torch.Tensor.cuda, torch.Tensor.cpu) and isinstance(args[0], HipSparseAdj):
+        if func in _KEEP_WRAPPED and isinstance(args[0], HipSparseAdj):
+            # device moves, and what nn.Module._apply does to a registered buffer (model/FSGNN.py:249-272)
             moved = func(args[0]._coo, *args[1:], **kwargs)
-            return HipSparseAdj._wrap(moved, args[0]._csr_host)
+            if moved.layout == torch.sparse_coo and moved.dtype == torch.float32:
+                return HipSparseAdj._wrap(moved, args[0]._csr_host)
+            return moved
         plain = [a._coo if isinstance(a, HipSparseAdj) else a for a in args]
         with torch._C.DisableTorchFunctionSubclass():
             return func(*plain, **kwargs)

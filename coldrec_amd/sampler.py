@@ -7,6 +7,8 @@ milliseconds instead of seconds, as three int32 arrays ready for one host-to-dev
 from __future__ import annotations
 
 import ctypes
+import math
+import random
 
 import numpy as np
 
@@ -25,6 +27,7 @@ class PairwiseSampler:
         if not self._h:
             raise RuntimeError("crh_sampler_create failed: " + self._L.crh_last_error().decode())
         self.n_records = int(ru.shape[0])
+        self._n_items = int(n_items_seen)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -59,3 +62,90 @@ class PairwiseSampler:
         _lib.check(self._L.crh_sampler_epoch(self._h, int(batch_size), u.ctypes.data, i.ctypes.data,
                                              j.ctypes.data), "crh_sampler_epoch")
         return u, i, j
+
+    # ------------------------------------------------------------------ the other samplers
+    def set_catalogue(self, n_users_seen: int, cold_item_idx=None) -> None:
+        """``len(data.user)`` and ``data.mapped_cold_item_idx`` (util/utils.py:176, 198-199, 243-246)."""
+        flags = np.zeros(self._n_items, np.uint8)
+        if cold_item_idx is not None and len(cold_item_idx):
+            flags[np.asarray(cold_item_idx, dtype=np.int64)] = 1
+        _lib.check(self._L.crh_sampler_set_catalogue(self._h, int(n_users_seen), flags.ctypes.data),
+                   "crh_sampler_set_catalogue")
+        self._has_catalogue = True
+
+    def pull_python_state(self) -> None:
+        """Adopt the state of CPython's global ``random`` module (version-3 state: 624 words + position)."""
+        ver, internal, _gauss = random.getstate()
+        assert ver == 3 and len(internal) == 625
+        key = np.array(internal[:624], dtype=np.uint32)
+        _lib.check(self._L.crh_sampler_set_py_state(self._h, key.ctypes.data, int(internal[624])),
+                   "crh_sampler_set_py_state")
+
+    def push_python_state(self) -> None:
+        key = np.empty(624, dtype=np.uint32)
+        pos = ctypes.c_int(0)
+        _lib.check(self._L.crh_sampler_get_py_state(self._h, key.ctypes.data, ctypes.addressof(pos)),
+                   "crh_sampler_get_py_state")
+        st = random.getstate()
+        random.setstate((st[0], tuple(int(x) for x in key) + (int(pos.value),), st[2]))
+
+    def _need_catalogue(self):
+        if not getattr(self, "_has_catalogue", False):
+            raise RuntimeError("PairwiseSampler.set_catalogue(n_users_seen, cold_item_idx) has not been called")
+
+    def _check_value(self, rc: int, what: str) -> None:
+        """The reference raises ValueError for empty / too small candidate pools (util/utils.py:201-204, 223-227)."""
+        if rc != 0:
+            msg = self._L.crh_last_error().decode("utf-8", "replace")
+            if msg.startswith("next_batch_pairwise_"):
+                raise ValueError(msg)
+            raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+    def epoch_lara(self, n_negs: int = 1):
+        """util/utils.py:160-188 -> user (n,), item (n,), neg_user (n, n_negs), neg_item (n, n_negs)."""
+        self._need_catalogue()
+        n = self.n_records
+        u, i = np.empty(n, np.int32), np.empty(n, np.int32)
+        nu, ni = np.empty((n, n_negs), np.int32), np.empty((n, n_negs), np.int32)
+        self._check_value(self._L.crh_sampler_epoch_lara(self._h, int(n_negs), u.ctypes.data, i.ctypes.data,
+                                                         nu.ctypes.data, ni.ctypes.data), "crh_sampler_epoch_lara")
+        return u, i, nu, ni
+
+    @staticmethod
+    def sample_setsize(k: int) -> int:
+        """The population size up to which random.sample copies the population (CPython Lib/random.py)."""
+        setsize = 21
+        if k > 5:
+            setsize += 4 ** math.ceil(math.log(k * 3, 4))
+        return setsize
+
+    def epoch_clcrec(self, n_negs: int = 1):
+        """util/utils.py:191-233 -> user (n,), item (n, 1 + n_negs): positive first, then the sampled negatives."""
+        self._need_catalogue()
+        n = self.n_records
+        u, it = np.empty(n, np.int32), np.empty((n, 1 + n_negs), np.int32)
+        self._check_value(self._L.crh_sampler_epoch_clcrec(self._h, int(n_negs), self.sample_setsize(int(n_negs)),
+                                                           u.ctypes.data, it.ctypes.data), "crh_sampler_epoch_clcrec")
+        return u, it
+
+    def epoch_ccfcrec(self, positive_number: int, negative_number: int, self_neg_number: int):
+        """util/utils.py:237-300 -> user, item, neg_user (n,), pos_items (n, P), neg_items (n, P, N), self_neg (n, S)."""
+        self._need_catalogue()
+        n, P, N, S = self.n_records, int(positive_number), int(negative_number), int(self_neg_number)
+        u, i, nu = (np.empty(n, np.int32) for _ in range(3))
+        pos, neg, sneg = np.empty((n, P), np.int32), np.empty((n, P, N), np.int32), np.empty((n, S), np.int32)
+        self._check_value(self._L.crh_sampler_epoch_ccfcrec(self._h, P, N, S, u.ctypes.data, i.ctypes.data,
+                                                            nu.ctypes.data, pos.ctypes.data, neg.ctypes.data,
+                                                            sneg.ctypes.data), "crh_sampler_epoch_ccfcrec")
+        return u, i, nu, pos, neg, sneg
+
+    def epoch_cgrc(self, batch_size: int, ranking_neg_per_user: int = 32):
+        """util/utils.py:303-336 -> user (n,), item (n,), bset_ptr (n_batches + 1,), bset (concatenated item sets)."""
+        n, bs, R = self.n_records, int(batch_size), int(ranking_neg_per_user)
+        nb = (n + bs - 1) // bs
+        cap = nb * min(self._n_items, bs * (1 + R))
+        u, i = np.empty(n, np.int32), np.empty(n, np.int32)
+        ptr, bset = np.empty(nb + 1, np.int64), np.empty(max(cap, 1), np.int32)
+        self._check_value(self._L.crh_sampler_epoch_cgrc(self._h, bs, R, u.ctypes.data, i.ctypes.data, ptr.ctypes.data,
+                                                         bset.ctypes.data, cap), "crh_sampler_epoch_cgrc")
+        return u, i, ptr, bset[:ptr[-1]]

@@ -192,6 +192,7 @@ class ColdStartDataBuilder(object):
         if self._sampler is None:
             from ..sampler import PairwiseSampler
             self._sampler = PairwiseSampler(self.train_u, self.train_i, self.user_num, len(self.item))
+            self._sampler.set_catalogue(len(self.user), self.mapped_cold_item_idx)
         return self._sampler
 
     # ------------------------------------------------------------------ small accessors of the reference

@@ -2,6 +2,8 @@
 
 * ``next_batch_pairwise(data, batch_size, n_negs=1)`` -- same generator contract and the same
   NumPy-global-RNG stream as util/utils.py:123-157, produced by the C++ host sampler.
+* ``next_batch_pairwise_LARA`` / ``_CLCRec`` / ``_CCFCRec`` / ``next_batch_cgrc`` -- the other samplers
+  (util/utils.py:160-336), same generator contracts, CPython ``random`` / NumPy streams restated in C++.
 * ``bpr_loss(u, p, n)`` / ``l2_reg_loss(reg, *embs)`` -- differentiable scalars
   (util/utils.py:25-29, 44-48) whose forward and backward run in crh_bpr_fwd_bwd_f32.
 * ``set_seed(seed, cuda)`` -- seeds the same three generators (util/utils.py:339-348).
@@ -46,6 +48,60 @@ def next_batch_pairwise(data, batch_size, n_negs=1):
     for lo in range(0, u.shape[0], batch_size):
         hi = min(lo + batch_size, u.shape[0])
         yield u[lo:hi].tolist(), i[lo:hi].tolist(), j[lo:hi].tolist()
+
+
+def _batches(n, batch_size):
+    return ((lo, min(lo + batch_size, n)) for lo in range(0, n, batch_size))
+
+
+def next_batch_pairwise_LARA(data, batch_size, n_negs=1):
+    """util/utils.py:160-188: per record ``n_negs`` x (a non-rated item, a user that has not rated the positive),
+    drawn from CPython's global ``random`` stream.  Yields (u_idx, i_idx, u_neg_idx, i_neg_idx) lists."""
+    s = data.sampler
+    s.pull_python_state()
+    u, i, nu, ni = s.epoch_lara(n_negs)
+    s.push_python_state()
+    for lo, hi in _batches(u.shape[0], batch_size):
+        yield u[lo:hi].tolist(), i[lo:hi].tolist(), nu[lo:hi].reshape(-1).tolist(), ni[lo:hi].reshape(-1).tolist()
+
+
+def next_batch_pairwise_CLCRec(data, batch_size, n_negs=1):
+    """util/utils.py:191-233: per record the positive plus ``random.sample`` of ``n_negs`` warm items the user
+    has not rated.  Yields (u_idx, i_idx), both [batch, 1 + n_negs] nested lists."""
+    s = data.sampler
+    s.pull_python_state()
+    u, it = s.epoch_clcrec(n_negs)
+    s.push_python_state()
+    for lo, hi in _batches(u.shape[0], batch_size):
+        yield np.repeat(u[lo:hi, None], 1 + n_negs, 1).tolist(), it[lo:hi].tolist()
+
+
+def next_batch_pairwise_CCFCRec(data, batch_size, positive_number, negative_number, self_neg_number):
+    """util/utils.py:237-300.  Yields (u_idx, i_idx, neg_u_idx, pos_i_list [B][P], neg_i_list [B][P][N],
+    self_neg_list [B][S]); positives come from NumPy's global stream, everything else from ``random``."""
+    s = data.sampler
+    s.pull_python_state()
+    s.pull_numpy_state()
+    u, i, nu, pos, neg, sneg = s.epoch_ccfcrec(positive_number, negative_number, self_neg_number)
+    s.push_numpy_state()
+    s.push_python_state()
+    for lo, hi in _batches(u.shape[0], batch_size):
+        yield (u[lo:hi].tolist(), i[lo:hi].tolist(), nu[lo:hi].tolist(), pos[lo:hi].tolist(),
+               neg[lo:hi].tolist() if positive_number > 0 else [],       # the reference only appends inside the loops
+               sneg[lo:hi].tolist() if self_neg_number > 0 else [])
+
+
+def next_batch_cgrc(data, batch_size, ranking_neg_per_user=32):
+    """util/utils.py:303-336.  Yields (u_idx, i_idx, B_list): B_list = the batch's positives plus up to
+    ``ranking_neg_per_user`` non-rated draws per record, in the order ``list(set)`` gives on CPython."""
+    if len(data.item) == 0:
+        raise ValueError('next_batch_cgrc: empty item set')
+    s = data.sampler
+    s.pull_numpy_state()
+    u, i, ptr, bset = s.epoch_cgrc(batch_size, ranking_neg_per_user)
+    s.push_numpy_state()
+    for b, (lo, hi) in enumerate(_batches(u.shape[0], batch_size)):
+        yield u[lo:hi].tolist(), i[lo:hi].tolist(), bset[ptr[b]:ptr[b + 1]].tolist()
 
 
 class _BprFn(torch.autograd.Function):

@@ -265,6 +265,40 @@ int64_t crh_sampler_num_records(const crh_sampler* s);
 int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host,
                       int32_t* pos_out_host, int32_t* neg_out_host);
 
+/*
+ * The other samplers of util/utils.py, same conventions (host pointers, internal ids, one call
+ * per epoch, records concatenated in shuffled order, the cumulative shuffle shared with crh_sampler_epoch).
+ * They draw from CPython's `random` module stream (set/get_py_state exchange random.getstate()[1] = 624 key
+ * words + position) and, where the reference does, from NumPy's (set/get_state above).
+ * crh_sampler_set_catalogue must be called once first: n_users_seen = len(data.user) (pool of negative users),
+ * item_is_cold[n_items_seen] = 1 for data.mapped_cold_item_idx (excluded from the CLCRec / CCFCRec candidate
+ * pools), NULL = no cold item.
+ *   crh_sampler_epoch_lara     util/utils.py:160-188  neg_user/neg_item: (n_records, n_negs)
+ *   crh_sampler_epoch_clcrec   util/utils.py:191-233  item_out: (n_records, 1 + n_negs) = positive, then
+ *                              random.sample(candidates, n_negs); sample_setsize = 21 (+ 4**ceil(log(3*n_negs, 4))
+ *                              when n_negs > 5), the pool / selected-set switch of random.sample
+ *   crh_sampler_epoch_ccfcrec  util/utils.py:237-300  pos_items (n, P) [NumPy stream], neg_items (n, P*N),
+ *                              self_neg (n, S), neg_user (n)
+ *   crh_sampler_epoch_cgrc     util/utils.py:303-336  NumPy stream only; per batch the item set in CPython's
+ *                              list(set) order: bset_out[bset_ptr_out[b] .. bset_ptr_out[b+1]), n_batches + 1 offsets
+ * crh_sampler_min_candidates = the smallest candidate pool over the training users (-1 before set_catalogue).
+ */
+int crh_sampler_set_catalogue(crh_sampler* s, int32_t n_users_seen, const uint8_t* item_is_cold_host);
+int crh_sampler_set_py_state(crh_sampler* s, const uint32_t* key624_host, int pos);
+int crh_sampler_get_py_state(const crh_sampler* s, uint32_t* key624_host, int* pos_host);
+int64_t crh_sampler_min_candidates(const crh_sampler* s);
+int crh_sampler_epoch_lara(crh_sampler* s, int32_t n_negs, int32_t* user_out_host, int32_t* item_out_host,
+                           int32_t* neg_user_out_host, int32_t* neg_item_out_host);
+int crh_sampler_epoch_clcrec(crh_sampler* s, int32_t n_negs, int64_t sample_setsize, int32_t* user_out_host,
+                             int32_t* item_out_host);
+int crh_sampler_epoch_ccfcrec(crh_sampler* s, int32_t positive_number, int32_t negative_number,
+                              int32_t self_neg_number, int32_t* user_out_host, int32_t* item_out_host,
+                              int32_t* neg_user_out_host, int32_t* pos_items_out_host,
+                              int32_t* neg_items_out_host, int32_t* self_neg_out_host);
+int crh_sampler_epoch_cgrc(crh_sampler* s, int64_t batch_size, int32_t ranking_neg_per_user,
+                           int32_t* user_out_host, int32_t* item_out_host, int64_t* bset_ptr_out_host,
+                           int32_t* bset_out_host, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

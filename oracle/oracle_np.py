@@ -171,6 +171,102 @@ class PairwiseSampler:
             yield u.copy(), i.copy(), j
 
 
+class OtherSamplers:
+    """util/utils.py:160-336 on internal ids, drawing from CPython's global ``random`` and
+    NumPy's legacy global RNG exactly where the reference does.  Plain Python loops: small cases only.
+
+    ``data.item`` / ``data.user`` are insertion-ordered dicts original id -> internal id, so
+    ``list(data.item.keys())[k]`` has internal id k and ``choice(item_list)`` draws an internal id directly;
+    ``training_set_u[user]`` is a dict in first-appearance order of the unshuffled records.
+    """
+
+    def __init__(self, rec_u, rec_i, n_users_seen: int, n_items_seen: int, cold_items=()):
+        self.rec = list(zip(np.asarray(rec_u).tolist(), np.asarray(rec_i).tolist()))   # shuffled in place, cumulative
+        self.n_users, self.n_items = int(n_users_seen), int(n_items_seen)
+        self.by_user, self.by_item = {}, {}
+        for u, i in self.rec:
+            self.by_user.setdefault(u, {})[i] = 1.0
+            self.by_item.setdefault(i, {})[u] = 1.0
+        cold = frozenset(int(c) for c in cold_items)
+        self.pool = [k for k in range(self.n_items) if k not in cold]                 # utils.py:198-199, 245-246
+        self._cand = {}
+
+    def _candidates(self, u):
+        if u not in self._cand:                                                       # utils.py:205-208, 252-255
+            self._cand[u] = [k for k in self.pool if k not in self.by_user.get(u, {})]
+        return self._cand[u]
+
+    def lara_epoch(self, n_negs=1):                                                   # utils.py:160-188
+        import random
+        random.shuffle(self.rec)
+        users, items = list(range(self.n_users)), list(range(self.n_items))
+        out = ([], [], [], [])
+        for u, i in self.rec:
+            out[0].append(u); out[1].append(i)
+            for _ in range(n_negs):
+                j = random.choice(items)
+                while j in self.by_user[u]:
+                    j = random.choice(items)
+                out[3].append(j)
+                v = random.choice(users)
+                while v in self.by_item[i]:
+                    v = random.choice(users)
+                out[2].append(v)
+        return out
+
+    def clcrec_epoch(self, n_negs=1):                                                 # utils.py:191-233
+        import random
+        random.shuffle(self.rec)
+        if not self.pool:
+            raise ValueError("empty warm pool")
+        us, rows = [], []
+        for u, i in self.rec:
+            cand = self._candidates(u)
+            if len(cand) < n_negs:
+                raise ValueError("too few warm negatives")
+            us.append(u)
+            rows.append([i] + random.sample(cand, n_negs))
+        return us, rows
+
+    def ccfcrec_epoch(self, P, N, S):                                                 # utils.py:237-300
+        import random
+        random.shuffle(self.rec)
+        users = list(range(self.n_users))
+        out = ([], [], [], [], [], [])
+        for u, i in self.rec:
+            out[0].append(u); out[1].append(i)
+            v = random.choice(users)
+            while v in self.by_item[i]:
+                v = random.choice(users)
+            out[2].append(v)
+            out[3].append(np.random.choice(list(self.by_user[u]), P, replace=True).tolist())
+            cand = self._candidates(u)
+            if not cand:
+                raise ValueError("no warm negatives")
+            flat = [random.choice(cand) for _ in range(P * N)]
+            out[4].append([flat[m * N:(m + 1) * N] for m in range(P)])
+            out[5].append([random.choice(cand) for _ in range(S)])
+        return out
+
+    def cgrc_epoch(self, batch_size, ranking_neg_per_user=32):                        # utils.py:303-336
+        order = np.arange(len(self.rec))
+        np.random.shuffle(order)                          # == np.random.shuffle(list): same draws, same permutation
+        self.rec = [self.rec[k] for k in order.tolist()]
+        keys = list(range(self.n_items))
+        for lo in range(0, len(self.rec), batch_size):
+            part = self.rec[lo:lo + batch_size]
+            bset = set(i for _, i in part)
+            for u, _ in part:
+                added = tries = 0
+                while added < ranking_neg_per_user and tries < ranking_neg_per_user * 50:
+                    tries += 1
+                    j = int(np.random.choice(keys))
+                    if j not in self.by_user[u]:
+                        bset.add(j)
+                        added += 1
+            yield [u for u, _ in part], [i for _, i in part], list(bset)
+
+
 # ----------------------------------------------------------------------------- A2
 def bpr_l2_fwd_bwd(U, V, ui, pi, ni, reg: float):
     """util/utils.py:25-29 + :44-48 and the gradients autograd produces at MF.py:22-27.

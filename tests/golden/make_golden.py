@@ -21,6 +21,7 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g7_metrics.npz   util/evaluator.py:153-187  ranking_evaluation on the g6 lists
   g8_e2e.json      model/BaseRecommender.py:353-370  MF.run() d=64, 3 epochs, test metrics
   g9_dropoutnet.*  model/DropoutNet.py:12-72  DropoutNet.run() on the g8 tables, 2 epochs: losses, tables, metrics
+  g10_samplers.npz util/utils.py:160-336   next_batch_pairwise_LARA / _CLCRec / _CCFCRec / next_batch_cgrc, 2 epochs each
 """
 import json
 import os
@@ -46,6 +47,8 @@ _m.__path__ = [os.path.join(REF, "model")]
 sys.modules["model"] = _m
 
 from util.utils import next_batch_pairwise, bpr_loss, l2_reg_loss, set_seed  # noqa: E402  (reference)
+from util.utils import (next_batch_pairwise_LARA, next_batch_pairwise_CLCRec,  # noqa: E402  (reference)
+                        next_batch_pairwise_CCFCRec, next_batch_cgrc)
 from util.databuilder import ColdStartDataBuilder, TorchGraphInterface  # noqa: E402  (reference)
 from util.evaluator import ranking_evaluation  # noqa: E402  (reference)
 from model.MF import MF, Matrix_Factorization  # noqa: E402  (reference)
@@ -419,7 +422,46 @@ def g9_dropoutnet(split):
                         V=trainer.item_emb.detach().numpy())
 
 
+def g10_samplers(split):
+    """The other samplers: 2 epochs each from random.seed(2024) / np.random.seed(2024) on a fresh
+    builder, batch 1000 (short last batch), plus a probe of both generators afterwards."""
+    import random
+    res = dict(seed=2024, batch_size=1000, epochs=2)
+
+    def run(tag, fn, *a):
+        data = ref_builder(split)
+        random.seed(2024)
+        np.random.seed(2024)
+        batches = [b for _ in range(2) for b in fn(data, 1000, *a)]
+        res[tag + "_tail"] = np.array([random.getrandbits(30), int(np.random.randint(0, 1 << 30))], np.int64)
+        res[tag + "_sizes"] = np.array([len(b[0]) for b in batches], np.int64)
+        return batches
+
+    cat = lambda bs, k: np.concatenate([np.asarray(b[k], np.int16) for b in bs], 0)   # toy ids are < 500
+    b = run("lara", next_batch_pairwise_LARA)
+    for k, name in enumerate(("u", "i", "nu", "ni")):
+        res["lara_" + name] = cat(b, k)
+    b = run("lara3", next_batch_pairwise_LARA, 3)
+    for k, name in enumerate(("u", "i", "nu", "ni")):
+        res["lara3_" + name] = cat(b, k)
+    for tag, n_negs in (("clc1", 1), ("clc8", 8)):               # 8 > 5: the enlarged set-size branch of random.sample
+        b = run(tag, next_batch_pairwise_CLCRec, n_negs)
+        res[tag + "_u"], res[tag + "_i"] = cat(b, 0), cat(b, 1)
+    b = run("ccf", next_batch_pairwise_CCFCRec, 3, 4, 5)
+    for k, name in enumerate(("u", "i", "nu", "pos", "neg", "sneg")):
+        res["ccf_" + name] = cat(b, k)
+    for tag, r in (("cgrc32", 32), ("cgrc2", 2)):
+        b = run(tag, next_batch_cgrc, r)
+        res[tag + "_u"], res[tag + "_i"] = cat(b, 0), cat(b, 1)
+        res[tag + "_bset"] = cat(b, 2)
+        res[tag + "_bptr"] = np.cumsum([0] + [len(x[2]) for x in b]).astype(np.int64)
+    np.savez_compressed(out("g10_samplers.npz"), **res)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":         # add the sampler fixture without redoing G1-G9
+        g10_samplers(make_dataset("toy", "item", seed=1))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g9":          # add the DropoutNet fixture without redoing G1-G8
         g9_dropoutnet(make_dataset("toy", "item", seed=1))
         return
@@ -441,6 +483,7 @@ def main():
     g7_metrics(lists)
     g8_e2e(split_i)
     g9_dropoutnet(split_i)
+    g10_samplers(split_i)
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

@@ -258,3 +258,94 @@ def test_mf_trainer_with_lazy_adam_matches_dense_trainer():
     assert outs[0][3] is False and outs[1][3] is True
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2]
+
+
+def _weighted_knn_graph(n, k, rng, loops=True):
+    """FSGNN-style graph: weighted, NOT symmetric (each row keeps its own k neighbours), optional self loops,
+    D^-1/2 A D^-1/2 by row sums (model/FSGNN.py:35-42, 262-272)."""
+    import scipy.sparse as sp
+    rows = np.repeat(np.arange(n), k)
+    cols = rng.integers(0, n, n * k)
+    a = sp.csr_matrix((rng.random(n * k).astype(np.float32) + 0.1, (rows, cols)), shape=(n, n))
+    a.sum_duplicates()
+    if loops:
+        a = (a + sp.eye(n, format="csr", dtype=np.float32)).tocsr()
+    dinv = np.power(np.asarray(a.sum(1)).ravel(), -0.5)
+    return (sp.diags(dinv) @ a @ sp.diags(dinv)).tocsr().astype(np.float32)
+
+
+def test_fsgnn_style_weighted_buffers_and_cgrc_style_rebuilt_graphs():
+    """the other torch.sparse.mm consumers through the unchanged boundary.
+    (1) FSGNN keeps weighted, non-symmetric, self-looped graphs as module BUFFERS (register_buffer + .to(device),
+        model/FSGNN.py:249-272) and runs relu(sparse.mm(adj, lin(x))) (:402-405);
+    (2) CGRC rebuilds a normalised bipartite graph per batch from an edge-dropped R and overwrites rows of the
+        product in place (model/CGRC.py:80-93, 313-319).
+    Forward and gradients must equal stock torch.sparse.mm on the CPU."""
+    import scipy.sparse as sp
+    from coldrec_amd.graph import HipSparseAdj
+    from coldrec_amd.util.databuilder import TorchGraphInterface
+    rng = np.random.default_rng(9)
+    n, d = 700, 32
+    a_host = _weighted_knn_graph(n, 12, rng)
+    assert abs(a_host - a_host.T).max() > 1e-3                     # backward needs the real transpose
+
+    class Struct(nn.Module):
+        def __init__(self, adj):
+            super().__init__()
+            self.register_buffer("adj_uu", adj, persistent=False)
+            self.sc = nn.ModuleList([nn.Linear(d, d), nn.Linear(d, d)])
+
+        def forward(self, h):
+            for lin in self.sc:
+                h = torch.relu(torch.sparse.mm(self.adj_uu, lin(h)))
+            return h
+
+    torch.manual_seed(3)
+    ours = Struct(TorchGraphInterface.convert_sparse_mat_to_tensor(a_host))
+    coo = sp.coo_matrix(a_host)
+    stock_adj = torch.sparse_coo_tensor(np.vstack((coo.row, coo.col)), coo.data, coo.shape).coalesce()
+    stock = Struct(stock_adj)
+    stock.load_state_dict(ours.state_dict())
+    ours = ours.to(DEV)
+    assert isinstance(ours.adj_uu, HipSparseAdj) and ours.adj_uu._coo.is_cuda
+    x = torch.randn(n, d)
+    xg, xc = x.clone().to(DEV).requires_grad_(), x.clone().requires_grad_()
+    yg, yc = ours(xg), stock(xc)
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-4, atol=1e-6)
+    w = torch.randn(n, d)
+    (yg * w.to(DEV)).sum().backward()
+    (yc * w).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-6)
+    for pg, pc in zip(ours.parameters(), stock.parameters()):
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), pc.grad.numpy(), rtol=2e-4, atol=1e-5)
+
+    # (2) per-batch rebuilt bipartite graphs
+    _, data = builder()
+    n_u, n_i = data.user_num, data.item_num
+    R = data.interaction_mat.tocsr() if hasattr(data.interaction_mat, "tocsr") else sp.csr_matrix(data.interaction_mat)
+    emb_g = (torch.randn(n_u + n_i, d) * 0.1).to(DEV).requires_grad_()
+    emb_c = emb_g.detach().cpu().clone().requires_grad_()
+    for step in range(3):
+        cold = rng.choice(n_i, 20, replace=False)
+        Rm = R.tolil(copy=True)
+        Rm[:, cold] = 0                                             # drop every edge into the sampled items
+        Rm = Rm.tocsr(); Rm.eliminate_zeros()
+        bip = sp.bmat([[None, Rm], [Rm.T, None]], format="csr", dtype=np.float32)
+        adj_m = data.normalize_graph_mat(bip)
+        adj_g = TorchGraphInterface.convert_sparse_mat_to_tensor(adj_m).to(DEV)
+        c2 = sp.coo_matrix(adj_m)
+        adj_c = torch.sparse_coo_tensor(np.vstack((c2.row, c2.col)), c2.data.astype(np.float32), c2.shape).coalesce()
+        outs = []
+        for adj, emb, dev in ((adj_g, emb_g, DEV), (adj_c, emb_c, "cpu")):
+            cold_rows = torch.as_tensor(cold + n_u, device=dev)
+            h, layers = emb, [emb]
+            for _ in range(2):
+                h = torch.sparse.mm(adj, h)
+                h[cold_rows] = emb[cold_rows]                       # frozen cold rows, in place (model/CGRC.py:90-92)
+                layers.append(h)
+            out = torch.stack(layers[1:], 1).mean(1)
+            emb.grad = None
+            out.pow(2).sum().backward()
+            outs.append((out.detach().cpu().numpy(), emb.grad.cpu().numpy()))
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-7)
