@@ -42,6 +42,7 @@ SIGNATURES = {
     "crh_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "crh_bpr_workspace_bytes": (_sz, [_i64]),
     "crh_bpr_plan_ints": (_i64, [_i64]),
+    "crh_bpr_heavy_threshold": (_i32, []),
     "crh_bpr_plan_build_host": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "crh_bpr_plan_build": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "crh_bpr_fwd_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -58,6 +59,12 @@ SIGNATURES = {
     "crh_spmm_segment_edges": (_i32, []),
     "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),
     "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _sz, _vp]),
+    "crh_bpr_fwd_parts": (_i32, [_i64, _i32]),
+    "crh_mf_step_parts": (_i32, [_i64, _i32]),
+    "crh_mf_step_tables": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "crh_mf_step_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp,
+                               _vp, _i32, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _vp, _vp]),
+    "crh_mf_step_finish": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "crh_sampler_create": (_vp, [_vp, _vp, _i64, _i32, _i32]),
     "crh_sampler_destroy": (None, [_vp]),
     "crh_sampler_seed": (_i32, [_vp, ctypes.c_uint32]),

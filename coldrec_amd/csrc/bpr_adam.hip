@@ -27,7 +27,9 @@ namespace {
 
 constexpr int BPR_THREADS = 256;
 constexpr int BPR_MAX_BLOCKS = 1024;
-constexpr int BPR_HEAVY = 32;      // entries of one gradient row above which a whole block sums it
+// entries of one gradient row above which a whole block sums it: a lane group walks a row's list sequentially (one
+// round trip per 4 entries), so the longest "light" row sets the kernel's critical path -- 8 keeps it at two trips
+constexpr int BPR_HEAVY = 8;
 
 struct BprArgs {
     const float* tu;   // user-side table      (rows x d)
@@ -507,21 +509,33 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
     __syncthreads();
     bitonic_sort_lds(keys, P);
     const int ni = plan_emit(keys, P, irow, iptr, ilist, scan);
-    // heavy rows (order irrelevant: every heavy row is summed on its own, in a fixed order)
+    // heavy rows, ascending (a fixed order: the one-launch MF step sums per-block partials, and which block takes
+    // which heavy row follows the list): count per thread chunk, serial scan of the 256 counts, ordered write
     int32_t* hv = pl + plan_heavy_off(L);
-    if (threadIdx.x == 0) scan[0] = 0;
+    const int rchunk = (nu + ni + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int r0 = threadIdx.x * rchunk, r1 = min(r0 + rchunk, nu + ni);
+    int nh = 0;
+    for (int r = r0; r < r1; ++r)
+        nh += (r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY;
     __syncthreads();
-    for (int r = threadIdx.x; r < nu + ni; r += PLAN_THREADS) {
-        const int c = r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu];
-        if (c > BPR_HEAVY) hv[1 + atomicAdd(&scan[0], 1)] = r;
-    }
+    scan[threadIdx.x] = nh;
     __syncthreads();
     if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < PLAN_THREADS; ++i) {
+            const int c = scan[i];
+            scan[i] = acc;
+            acc += c;
+        }
         pl[0] = nu;
         pl[1] = ni;
         pl[2] = L;
-        hv[0] = scan[0];
+        hv[0] = acc;
     }
+    __syncthreads();
+    int w = scan[threadIdx.x];
+    for (int r = r0; r < r1; ++r)
+        if ((r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY) hv[1 + w++] = r;
 }
 
 // ---------------------------------------------------------------- dense Adam (+ zero the gradient)
@@ -677,9 +691,350 @@ int dispatch_group(int g, F&& f) {
     }
 }
 
+
+// ---------------------------------------------------------------- whole MF step in ONE launch
+// At MovieLens size a step is latency: three dependent launches (forward, row gradients, dense Adam) of a few
+// microseconds each over ~20 MB of cache-resident state.  mf_step_kernel does the step in one launch, organised by
+// TABLE ROW (dense Adam touches every row anyway):
+//   * a lane group owns a row: if the batch touches it, the row's gradient is summed in plan-list order as in
+//     bpr_bwd_rows_kernel, but the score difference x_b of each entry is RECOMPUTED from the rows themselves (user
+//     entry: u.(p-n) from the two rows it gathers anyway; item entry: one extra row) -- no forward pass, no xbuf;
+//     then Adam is applied to the row in registers and the new row is written to the OTHER parameter buffer
+//     (ping-pong: groups still reading the old rows are never overtaken); m, v in place.  No gradient table
+//     exists at all (24 instead of 32 B per element of optimiser traffic).
+//   * the three Frobenius norms of the NEXT batch -- the only grid-wide dependency of a step -- are accumulated
+//     here from the freshly updated rows: sum_b |u_b|^2 = sum over rows of multiplicity(row, next batch) * |row|^2,
+//     as per-block partials that every block of the next launch re-reduces in a fixed order.  The first step of
+//     an epoch takes its norms from bpr_fwd_kernel's partials (same layout).
+//   * the BPR loss of the batch is summed by the user rows (every triple is in exactly one user list), also as
+//     block partials: the NEXT launch (or crh_mf_step_finish) turns them into the reported value.
+// What bounds the kernel is the CHAIN of dependent memory round trips of a row, so the plan is flattened once per
+// epoch (mf_tables_kernel) into per-row arrays the kernel can read at once: range[b][row] = the row's slice of the
+// batch's entry array, entry = the two OTHER rows of the triple (ids resolved), mult[b][row] = the row's multiplicities
+// in batch b.  A row then costs three round trips: {range, mult, p, m, v} -> entries -> gathered rows.
+// Heavy rows (more than BPR_HEAVY entries) are done by the extra blocks, one block per row, exactly as before.
+// Deterministic: no atomics, fixed summation orders.  d <= 256, batch < 32768.
+constexpr int MF_MAX_LIGHT = 2048, MF_HEAVY_BLOCKS = 256;
+
+struct MfStepArgs {
+    const float* pin;      // (U + I, d) parameters before the step, users first
+    float* pout;           // parameters after the step (another buffer)
+    float* m;
+    float* v;
+    int64_t U, I;
+    int d;
+    int64_t B;
+    float reg;
+    const int32_t* plan;   // this batch (heavy list)
+    const int2* range;     // (U + I): [e0, e1) of the row in `entries`, (0, 0) if the batch does not touch it
+    const int2* entries;   // (3 L): x = first other row | role << 30, y = second other row (table rows, users first)
+    const int32_t* mult2;  // (U + I) multiplicities in the NEXT batch: user rows count, item rows pos | neg << 16; or NULL
+    const float* part_in;  // [n_in][4]: norms^2 of THIS batch (u, p, n) and the loss sum of the PREVIOUS one
+    int n_in;
+    float* part_out;       // [gridDim.x][4]: norms^2 of the NEXT batch, loss sum of THIS one
+    float* loss_prev;      // [2] of the previous step (its bpr is known only now) or NULL
+    float inv_b_prev;
+    float* loss_now;       // [2] of this step: l2 is written now
+    AdamK k;
+    const float* step_scalars;
+    int light_blocks;
+    int ablate;            // measurement only (CRH_MF_ABLATE): 1 no entries, 2 no batch sums, 4 no norms, 8 no stores
+};
+
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
+#pragma clang fp contract(off)      // the same bits wherever a score difference is recomputed
+    return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w;
+}
+
+// NQ consecutive entries (lanes t .. t+NQ-1 of the group hold their metadata) of one row: acc += d(loss)/d(row)
+// contributions, loss += -log(1e-5 + sigmoid(x)) on the user side.
+//   user row (own = u): entry rows (p, n);  item row as positive (own = p): (u, n);  as negative (own = n): (u, p)
+template <int G, int NQ>
+__device__ __forceinline__ void mf_entries_chunk(const MfStepArgs& a, const BwdCoef& k, bool user_side, const int2& en, int t,
+                                                 bool on, int lig, const f32x4& own, f32x4& acc, float& loss) {
+    int aa[NQ], bb[NQ];
+    f32x4 xa[NQ], xb[NQ];
+    float dp[NQ], dn[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        aa[q] = __shfl(en.x, t + q, G);
+        bb[q] = __shfl(en.y, t + q, G);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        xa[q] = xb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            xa[q] = reinterpret_cast<const f32x4*>(a.pin + (int64_t)(aa[q] & 0x3fffffff) * a.d)[lig];
+            xb[q] = reinterpret_cast<const f32x4*>(a.pin + (int64_t)bb[q] * a.d)[lig];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        // x = u.p - u.n with the same per-lane products and the same group tree on all three rows of a triple
+        if (user_side) {                    // own = u, xa = p, xb = n
+            dp[q] = dot4(own, xa[q]);
+            dn[q] = dot4(own, xb[q]);
+        } else if ((aa[q] >> 30) == 0) {    // own = p, xa = u, xb = n
+            dp[q] = dot4(xa[q], own);
+            dn[q] = dot4(xa[q], xb[q]);
+        } else {                            // own = n, xa = u, xb = p
+            dp[q] = dot4(xa[q], xb[q]);
+            dn[q] = dot4(xa[q], own);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        dp[q] = group_sum<G>(dp[q]);
+        dn[q] = group_sum<G>(dn[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float x = dp[q] - dn[q];
+        const float sig = 1.0f / (1.0f + expf(-x));
+        const float g = -k.invB * sig * (1.0f - sig) / (1e-5f + sig);
+        if (user_side) {
+            loss += -logf(1e-5f + sig);
+            acc.x += g * (xa[q].x - xb[q].x) + k.cu * own.x;
+            acc.y += g * (xa[q].y - xb[q].y) + k.cu * own.y;
+            acc.z += g * (xa[q].z - xb[q].z) + k.cu * own.z;
+            acc.w += g * (xa[q].w - xb[q].w) + k.cu * own.w;
+        } else {
+            const bool pos = (aa[q] >> 30) == 0;
+            const float sg = pos ? g : -g;
+            const float cc = pos ? k.cp : k.cn;
+            acc.x += sg * xa[q].x + cc * own.x;
+            acc.y += sg * xa[q].y + cc * own.y;
+            acc.z += sg * xa[q].z + cc * own.z;
+            acc.w += sg * xa[q].w + cc * own.w;
+        }
+    }
+}
+
+// Entries [e0, e1) of one row, in list order: metadata one entry per lane, rows fetched 4 entries at a time while
+// four are left, one at a time after that (most rows of a batch have one or two entries).
+template <int G>
+__device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoef& k, bool user_side, int e0, int e1,
+                                               bool on, int lig, const f32x4& own, f32x4& acc, float& loss) {
+    for (int base = e0; base < e1; base += G) {
+        const int e = base + lig;
+        int2 en = {0, 0};
+        if (e < e1) en = a.entries[e];
+        const int cnt = (e1 - base) < G ? (e1 - base) : G;
+        int t = 0;
+        for (; t + 4 <= cnt; t += 4) mf_entries_chunk<G, 4>(a, k, user_side, en, t, on, lig, own, acc, loss);
+        for (; t < cnt; ++t) mf_entries_chunk<G, 1>(a, k, user_side, en, t, on, lig, own, acc, loss);
+    }
+}
+
+// Adam on one row slice + what the updated row contributes to the norms of the next batch.
+template <int G>
+__device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, bool on, int lig, f32x4 p, f32x4 m, f32x4 v,
+                                              const f32x4& grad, int mult, float bc2_sqrt, float nss, float& su, float& sp,
+                                              float& sn) {
+    const int64_t o = row * a.d + lig * 4;
+    if (on) {
+        adam_elem4(p, m, v, grad, a.k, bc2_sqrt, nss);
+        if (!(a.ablate & 8) || p.x == 123.f) {
+            *reinterpret_cast<f32x4*>(a.pout + o) = p;
+            *reinterpret_cast<f32x4*>(a.m + o) = m;
+            *reinterpret_cast<f32x4*>(a.v + o) = v;
+        }
+    }
+    if (mult == 0) return;                                       // uniform over the lane group
+    const float nsq = group_sum<G>(on ? dot4(p, p) : 0.f);
+    if (lig == 0) {
+        if (row < a.U) {
+            su += (float)mult * nsq;
+        } else {
+            sp += (float)(mult & 0xffff) * nsq;
+            sn += (float)(mult >> 16) * nsq;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(BPR_THREADS) void mf_step_kernel(MfStepArgs a) {
+    __shared__ f32x4 red4[4];
+    __shared__ float red[4];
+    __shared__ f32x4 wsum[4][G];
+    const int lig = threadIdx.x % G;
+    const bool on = lig < (a.d >> 2);
+    const int64_t R = a.U + a.I;
+    // heavy rows take the longest: their blocks come FIRST in the grid so that they start with the launch
+    const int heavy_blocks = (int)gridDim.x - a.light_blocks;
+    const bool light = (int)blockIdx.x >= heavy_blocks;
+    const int64_t gid = (int64_t)((int)blockIdx.x - heavy_blocks) * (BPR_THREADS / G) + threadIdx.x / G;
+    const int64_t gstride = (int64_t)a.light_blocks * (BPR_THREADS / G);
+    // first round trip of the row chain, issued before the batch sums are reduced
+    int2 rg = {0, 0};
+    int mult = 0;
+    f32x4 own = {0.f, 0.f, 0.f, 0.f}, m0 = own, v0 = own;
+    if (light && gid < R) {
+        if (!(a.ablate & 1)) rg = a.range[gid];
+        if (a.mult2 && !(a.ablate & 4)) mult = a.mult2[gid];
+        if (on) {
+            const int64_t o = gid * a.d + lig * 4;
+            own = *reinterpret_cast<const f32x4*>(a.pin + o);
+            m0 = *reinterpret_cast<const f32x4*>(a.m + o);
+            v0 = *reinterpret_cast<const f32x4*>(a.v + o);
+        }
+    }
+    // batch sums: every block reduces the previous launch's partials in the same order (one 16-B load per partial)
+    f32x4 tot;
+    {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int i = threadIdx.x; i < ((a.ablate & 2) ? 1 : a.n_in); i += BPR_THREADS) {
+            const f32x4 x = reinterpret_cast<const f32x4*>(a.part_in)[i];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s.x += __shfl_xor(s.x, off); s.y += __shfl_xor(s.y, off);
+            s.z += __shfl_xor(s.z, off); s.w += __shfl_xor(s.w, off);
+        }
+        if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const f32x4 t0 = red4[0], t1 = red4[1], t2 = red4[2], t3 = red4[3];
+        tot.x = (t0.x + t1.x) + (t2.x + t3.x);
+        tot.y = (t0.y + t1.y) + (t2.y + t3.y);
+        tot.z = (t0.z + t1.z) + (t2.z + t3.z);
+        tot.w = (t0.w + t1.w) + (t2.w + t3.w);
+    }
+    BwdCoef k;
+    k.invB = 1.0f / (float)a.B;
+    {
+        const float nu_ = sqrtf(tot.x), np_ = sqrtf(tot.y), nn = sqrtf(tot.z);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.loss_now) a.loss_now[1] = a.reg * (nu_ * k.invB + np_ * k.invB + nn * k.invB);
+            if (a.loss_prev) a.loss_prev[0] = tot.w * a.inv_b_prev;
+        }
+        k.cu = nu_ > 0.f ? a.reg * k.invB / nu_ : 0.f;
+        k.cp = np_ > 0.f ? a.reg * k.invB / np_ : 0.f;
+        k.cn = nn > 0.f ? a.reg * k.invB / nn : 0.f;
+    }
+    const float bc2_sqrt = a.step_scalars[0], nss = a.step_scalars[1];
+    float su = 0.f, sp = 0.f, sn = 0.f, sl = 0.f;
+    if (light) {
+        for (int64_t row = gid; row < R; row += gstride) {
+            if (row != gid) {                                      // tables beyond MF_MAX_LIGHT blocks of rows
+                rg = a.range[row];
+                mult = a.mult2 ? a.mult2[row] : 0;
+                if (on) {
+                    const int64_t o = row * a.d + lig * 4;
+                    own = *reinterpret_cast<const f32x4*>(a.pin + o);
+                    m0 = *reinterpret_cast<const f32x4*>(a.m + o);
+                    v0 = *reinterpret_cast<const f32x4*>(a.v + o);
+                }
+            }
+            if (rg.y - rg.x > BPR_HEAVY) continue;                // a heavy block does this row, Adam included
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float loss = 0.f;
+            if (rg.y > rg.x) mf_row_entries<G>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
+            if (lig == 0) sl += loss;
+            mf_row_update<G>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn);
+        }
+    } else {
+        const PlanView pv = plan_view(a.plan);
+        constexpr int NGB = BPR_THREADS / G;
+        const int gg = threadIdx.x / G;
+        for (int h = (int)blockIdx.x; h < pv.n_heavy; h += heavy_blocks) {
+            const int64_t w = pv.heavy[h];
+            const bool user_side = w < pv.n_u;
+            const int64_t row = user_side ? (int64_t)pv.urow[w] : a.U + pv.irow[w - pv.n_u];
+            const int2 hr = a.range[row];
+            int chunk = (hr.y - hr.x + NGB - 1) / NGB;
+            chunk = (chunk + 3) & ~3;
+            const int e0 = hr.x + gg * chunk;
+            const int e1 = e0 + chunk < hr.y ? e0 + chunk : hr.y;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            own = acc;
+            if (on) own = reinterpret_cast<const f32x4*>(a.pin + row * a.d)[lig];
+            float loss = 0.f;
+            if (e0 < hr.y) mf_row_entries<G>(a, k, user_side, e0, e1, on, lig, own, acc, loss);
+            if (lig == 0) sl += loss;
+#pragma unroll
+            for (int off = G; off < 64; off <<= 1) {
+                acc.x += __shfl_down(acc.x, off);
+                acc.y += __shfl_down(acc.y, off);
+                acc.z += __shfl_down(acc.z, off);
+                acc.w += __shfl_down(acc.w, off);
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) < G) wsum[threadIdx.x >> 6][lig] = acc;
+            __syncthreads();
+            if (threadIdx.x < G) {
+                const f32x4 t0 = wsum[0][lig], t1 = wsum[1][lig], t2 = wsum[2][lig], t3 = wsum[3][lig];
+                f32x4 r;
+                r.x = (t0.x + t1.x) + (t2.x + t3.x);
+                r.y = (t0.y + t1.y) + (t2.y + t3.y);
+                r.z = (t0.z + t1.z) + (t2.z + t3.z);
+                r.w = (t0.w + t1.w) + (t2.w + t3.w);
+                m0 = v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (on) {
+                    m0 = *reinterpret_cast<const f32x4*>(a.m + row * a.d + lig * 4);
+                    v0 = *reinterpret_cast<const f32x4*>(a.v + row * a.d + lig * 4);
+                }
+                mf_row_update<G>(a, row, on, lig, own, m0, v0, r, a.mult2 ? a.mult2[row] : 0, bc2_sqrt, nss, su, sp, sn);
+            }
+        }
+    }
+    su = block_sum(su, red);
+    sp = block_sum(sp, red);
+    sn = block_sum(sn, red);
+    sl = block_sum(sl, red);
+    if (threadIdx.x == 0) {
+        float* o = a.part_out + (size_t)blockIdx.x * 4;
+        o[0] = su; o[1] = sp; o[2] = sn; o[3] = sl;
+    }
+}
+
+// Flatten the plans of an epoch for mf_step_kernel (grid.y = batch): per table row its entry range and its
+// multiplicities, per entry the two other rows of the triple.  range / mult must be zero on entry.
+__global__ void mf_tables_kernel(const int32_t* plans, int64_t stride, const int32_t* iu, const int32_t* ip,
+                                 const int32_t* in_, int64_t L, int64_t U, int64_t R, int2* range, int32_t* mult,
+                                 int2* entries) {
+    const int64_t bt = blockIdx.y;
+    const PlanView pv = plan_view(plans + bt * stride);
+    const int32_t *bu = iu + bt * L, *bp = ip + bt * L, *bn = in_ + bt * L;
+    int2* rg = range + bt * R;
+    int32_t* mu = mult + bt * R;
+    int2* en = entries + bt * 3 * L;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < pv.n_u + pv.n_i; w += gridDim.x * blockDim.x) {
+        if (w < pv.n_u) {
+            const int e0 = pv.uptr[w], e1 = pv.uptr[w + 1];
+            rg[pv.urow[w]] = int2{e0, e1};
+            mu[pv.urow[w]] = e1 - e0;
+            for (int e = e0; e < e1; ++e) {
+                const int b = pv.ulist[e];
+                en[e] = int2{(int)(U + bp[b]), (int)(U + bn[b])};
+            }
+        } else {
+            const int wi = w - pv.n_u;
+            const int e0 = pv.iptr[wi], e1 = pv.iptr[wi + 1];
+            int negs = 0;
+            for (int e = e0; e < e1; ++e) {
+                const int ent = pv.ilist[e], b = ent & 0x3fffffff, role = ent >> 30;
+                negs += role;
+                en[L + e] = int2{bu[b] | (role << 30), (int)(U + (role == 0 ? bn[b] : bp[b]))};
+            }
+            rg[U + pv.irow[wi]] = int2{(int)L + e0, (int)L + e1};
+            mu[U + pv.irow[wi]] = (e1 - e0 - negs) | (negs << 16);
+        }
+    }
+}
+
+__global__ void mf_finish_kernel(const float* part_in, int n_in, float inv_b, float* loss_out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_in; i += BPR_THREADS) s += part_in[(size_t)i * 4 + 3];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss_out[0] = s * inv_b;
+}
+
 }  // namespace
 
 extern "C" int64_t crh_bpr_plan_ints(int64_t batch) { return batch > 0 ? plan_ints(batch) : 0; }
+extern "C" int crh_bpr_heavy_threshold(void) { return BPR_HEAVY; }
 
 // HOST function: reverse index of one batch of triples (see bpr_bwd_rows_kernel).  Item-side
 // gradients of positives and negatives land in the SAME table (grad_pos == grad_neg).
@@ -940,4 +1295,103 @@ extern "C" void crh_adam_step_scalars_host(double lr, double beta1, double beta2
     const double bc2 = 1.0 - pow(beta2, (double)step);
     out2_host[0] = (float)sqrt(bc2);
     out2_host[1] = (float)(-(lr / bc1));
+}
+
+
+// ---------------------------------------------------------------- MF step in one launch (see mf_step_kernel)
+extern "C" int crh_mf_step_parts(int64_t n_rows, int d) {
+    if (n_rows <= 0 || d < 4 || d > 256 || d % 4) return 0;
+    const int64_t per_block = BPR_THREADS / pick_group(d);
+    int64_t light = (n_rows + per_block - 1) / per_block;
+    if (light > MF_MAX_LIGHT) light = MF_MAX_LIGHT;
+    return (int)light + MF_HEAVY_BLOCKS;
+}
+
+// number of [4]-float partial sums crh_bpr_fwd_f32 leaves at the start of its workspace for a batch
+extern "C" int crh_bpr_fwd_parts(int64_t batch, int d) {
+    if (batch <= 0 || d < 4 || d % 4) return 0;
+    const int64_t per_block = BPR_THREADS / pick_group(d);
+    const int64_t blocks = (batch + per_block - 1) / per_block;
+    return (int)(blocks > BPR_MAX_BLOCKS ? BPR_MAX_BLOCKS : blocks);
+}
+
+// Flattened per-epoch tables for crh_mf_step_f32 from the epoch's plans and triples (n_records triples in batches of
+// batch_size, the last one short): range_out (n_batches, rows) int2, mult_out (n_batches, rows) int32, entries_out
+// (n_batches, 3 * batch_size) int2.  batch_size < 32768; user-row ids < 2^30.
+extern "C" int crh_mf_step_tables(const int32_t* plans, const int32_t* user_idx, const int32_t* pos_idx,
+                                  const int32_t* neg_idx, int64_t n_records, int64_t batch_size, int64_t user_rows,
+                                  int64_t item_rows, int32_t* range_out, int32_t* mult_out, int32_t* entries_out,
+                                  void* stream) {
+    CRH_CHECK_ARG(plans && user_idx && pos_idx && neg_idx && range_out && mult_out && entries_out,
+                  "crh_mf_step_tables: NULL pointer");
+    CRH_CHECK_ARG(n_records > 0 && batch_size > 0 && batch_size < 32768 && user_rows > 0 && item_rows > 0 &&
+                  user_rows + item_rows < ((int64_t)1 << 30), "crh_mf_step_tables: bad sizes");
+    const int64_t nb = (n_records + batch_size - 1) / batch_size, R = user_rows + item_rows;
+    CRH_CHECK_ARG(nb <= 65535, "crh_mf_step_tables: more than 65535 batches");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CRH_HIP(hipMemsetAsync(range_out, 0, (size_t)(nb * R) * sizeof(int2), st));
+    CRH_HIP(hipMemsetAsync(mult_out, 0, (size_t)(nb * R) * sizeof(int32_t), st));
+    const unsigned bx = (unsigned)std::min<int64_t>((3 * batch_size + 255) / 256, 64);
+    hipLaunchKernelGGL(mf_tables_kernel, dim3(bx, (unsigned)nb), dim3(256), 0, st, plans, plan_ints(batch_size), user_idx,
+                       pos_idx, neg_idx, batch_size, user_rows, R, reinterpret_cast<int2*>(range_out), mult_out,
+                       reinterpret_cast<int2*>(entries_out));
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+// One optimiser step of model/MF.py:19-27 (gather, bpr_loss + l2_reg_loss, backward, dense Adam) in one launch.
+// table_in/table_out: (user_rows + item_rows, d) parameters before / after (two different buffers); m, v in place.
+// plan: this batch's plan (heavy-row list); range/entries: this batch's rows of crh_mf_step_tables' outputs;
+// mult_next: the NEXT batch's row of mult_out, NULL for the last step of the epoch.  part_in: [n_parts_in][4]
+// partial sums left by the previous call's part_out (n_parts_in = crh_mf_step_parts) or, for the first step of an
+// epoch, by crh_bpr_fwd_f32's workspace (crh_bpr_fwd_parts x 4 floats).  loss_out[1] (l2) is written by this call,
+// loss_out[0] (bpr) by the next call through loss_prev_out (batch_prev = that step's batch size) or by
+// crh_mf_step_finish.
+extern "C" int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v, int64_t user_rows,
+                               int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan,
+                               const int32_t* range, const int32_t* entries, const int32_t* mult_next,
+                               const float* part_in, int n_parts_in, float* part_out, float* loss_prev_out,
+                               int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
+                               const float* step_scalars, void* stream) {
+    CRH_CHECK_ARG(table_in && table_out && m && v && table_in != table_out, "crh_mf_step_f32: NULL / aliased tables");
+    CRH_CHECK_ARG(user_rows > 0 && item_rows > 0 && batch > 0, "crh_mf_step_f32: empty table or batch");
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "crh_mf_step_f32: d=%d must be a multiple of 4, at most 256", d);
+    CRH_CHECK_ARG(plan && range && entries, "crh_mf_step_f32: NULL plan / step tables");
+    CRH_CHECK_ARG(part_in && n_parts_in > 0 && part_out && step_scalars, "crh_mf_step_f32: NULL partial sums / step scalars");
+    CRH_CHECK_ARG(!loss_prev_out || batch_prev > 0, "crh_mf_step_f32: loss_prev_out needs batch_prev");
+    CRH_CHECK_ARG((((uintptr_t)table_in | (uintptr_t)table_out | (uintptr_t)m | (uintptr_t)v | (uintptr_t)part_in) & 15) == 0,
+                  "crh_mf_step_f32: tables and partial sums must be 16-byte aligned");
+    MfStepArgs a;
+    a.pin = table_in; a.pout = table_out; a.m = m; a.v = v;
+    a.U = user_rows; a.I = item_rows; a.d = d;
+    a.B = batch; a.reg = reg;
+    a.plan = plan;
+    a.range = reinterpret_cast<const int2*>(range);
+    a.entries = reinterpret_cast<const int2*>(entries);
+    a.mult2 = mult_next;
+    a.part_in = part_in; a.n_in = n_parts_in; a.part_out = part_out;
+    a.loss_prev = loss_prev_out; a.inv_b_prev = loss_prev_out ? 1.0f / (float)batch_prev : 0.f;
+    a.loss_now = loss_out;
+    a.k = AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
+    a.step_scalars = step_scalars;
+    const int parts = crh_mf_step_parts(user_rows + item_rows, d);
+    a.light_blocks = parts - MF_HEAVY_BLOCKS;
+    static const int ablate = getenv("CRH_MF_ABLATE") ? atoi(getenv("CRH_MF_ABLATE")) : 0;
+    a.ablate = ablate;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dispatch_group(pick_group(d), [&](auto gc) -> int {
+        constexpr int GG = decltype(gc)::value;
+        hipLaunchKernelGGL(mf_step_kernel<GG>, dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    });
+}
+
+// bpr loss of the LAST step of an epoch from its partial sums.
+extern "C" int crh_mf_step_finish(const float* part_in, int n_parts_in, int64_t batch, float* loss_out, void* stream) {
+    CRH_CHECK_ARG(part_in && n_parts_in > 0 && batch > 0 && loss_out, "crh_mf_step_finish: bad arguments");
+    hipLaunchKernelGGL(mf_finish_kernel, dim3(1), dim3(BPR_THREADS), 0, reinterpret_cast<hipStream_t>(stream), part_in,
+                       n_parts_in, 1.0f / (float)batch, loss_out);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
 }

@@ -259,6 +259,58 @@ def build_plans_device(user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: t
     return _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size)
 
 
+# ----------------------------------------------------------------------------- MF step in one launch
+def mf_step_parts(n_rows: int, d: int) -> int:
+    return int(_lib.lib().crh_mf_step_parts(int(n_rows), int(d)))
+
+
+def bpr_fwd_parts(batch: int, d: int) -> int:
+    return int(_lib.lib().crh_bpr_fwd_parts(int(batch), int(d)))
+
+
+def mf_step_tables(plans: torch.Tensor, user_idx, pos_idx, neg_idx, batch_size: int, user_rows: int, item_rows: int,
+                   out=None):
+    """Flattened per-epoch tables of crh_mf_step_f32: (range (nb, rows, 2), mult (nb, rows), entries (nb, 3B, 2))."""
+    _need_cuda(plans, user_idx, pos_idx, neg_idx)
+    nb, R, n_rec = plans.shape[0], int(user_rows) + int(item_rows), user_idx.numel()
+    assert nb == (n_rec + batch_size - 1) // batch_size
+    if out is None:
+        i32 = dict(dtype=torch.int32, device=plans.device)
+        out = (torch.empty((nb, R, 2), **i32), torch.empty((nb, R), **i32), torch.zeros((nb, 3 * batch_size, 2), **i32))
+    rng, mult, ent = out
+    assert rng.shape == (nb, R, 2) and mult.shape == (nb, R) and ent.shape == (nb, 3 * batch_size, 2)
+    _lib.check(_lib.lib().crh_mf_step_tables(_lib.ptr(plans), _lib.ptr(user_idx), _lib.ptr(pos_idx), _lib.ptr(neg_idx),
+                                             n_rec, int(batch_size), int(user_rows), int(item_rows), _lib.ptr(rng),
+                                             _lib.ptr(mult), _lib.ptr(ent), _lib.current_stream()),
+               "crh_mf_step_tables")
+    return out
+
+
+def mf_step(table_in, table_out, m, v, user_rows: int, batch: int, reg: float, plan, rng, entries, mult_next,
+            part_in, n_parts_in: int, part_out, loss_prev, batch_prev: int, loss_out, step_scalars,
+            beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """One whole optimiser step of model/MF.py:19-27 in one launch (crh_mf_step_f32, see include/coldrec_hip.h)."""
+    _need_cuda(table_in, table_out, m, v, plan, rng, entries, part_in, part_out, step_scalars)
+    R, d = table_in.shape
+    for t in (table_in, table_out, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (R, d)
+    for t in (plan, rng, entries):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    assert rng.shape == (R, 2) and (mult_next is None or (mult_next.shape == (R,) and mult_next.is_contiguous()))
+    rc = _lib.lib().crh_mf_step_f32(
+        _lib.ptr(table_in), _lib.ptr(table_out), _lib.ptr(m), _lib.ptr(v), int(user_rows), R - int(user_rows), d,
+        int(batch), float(reg), _lib.ptr(plan), _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(mult_next),
+        _lib.ptr(part_in), int(n_parts_in), _lib.ptr(part_out), _lib.ptr(loss_prev), int(batch_prev),
+        _lib.ptr(loss_out), beta1, beta2, eps, _lib.ptr(step_scalars), _lib.current_stream())
+    _lib.check(rc, "crh_mf_step_f32")
+
+
+def mf_step_finish(part_in, n_parts_in: int, batch: int, loss_out) -> None:
+    _need_cuda(part_in, loss_out)
+    _lib.check(_lib.lib().crh_mf_step_finish(_lib.ptr(part_in), int(n_parts_in), int(batch), _lib.ptr(loss_out),
+                                             _lib.current_stream()), "crh_mf_step_finish")
+
+
 def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Tensor:
     dev, L = user_idx.device, int(batch_size)
     n_rec = user_idx.numel()
@@ -304,7 +356,7 @@ def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Ten
     ni = side([pos_idx, neg_idx], [bl, bl + (1 << 30)], 2 * L, 3 + 3 * L + 1)
     plans[:, 0], plans[:, 1] = nu, ni
     # heavy rows (more than HEAVY entries): [count, slots...] behind the item lists; slot = position in (users, items)
-    HEAVY = 32                                       # BPR_HEAVY of csrc/bpr_adam.hip
+    HEAVY = int(_lib.lib().crh_bpr_heavy_threshold())
     hoff = 3 + (3 * L + 1) + (6 * L + 1)
     uptr = plans[:, 3 + L: 3 + 2 * L + 1].to(torch.int64)
     off_i = 3 + 3 * L + 1

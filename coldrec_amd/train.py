@@ -8,6 +8,8 @@ LightGCN; nothing is copied to the host unless the caller asks for the loss.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import numpy as np
@@ -131,6 +133,49 @@ class MFEngine(_TableState):
         self._table_steps = 0
         self._dirty = False
 
+    # ---------------------------------------------------------------- one launch per step (cache-resident tables)
+    fused = False
+    FUSED_MAX_MAP_BYTES = 1 << 29        # the (batches, rows) per-row tables of an epoch (12 B per row and batch)
+
+    def can_fuse(self, n_batches: int, batch_size: int) -> bool:
+        return (self.k is ops and not self.lazy and self.dp is None and self.d <= 256 and self.E.is_cuda
+                and batch_size <= 8192 and n_batches * self.E.shape[0] * 12 <= self.FUSED_MAX_MAP_BYTES)
+
+    def enable_fused_step(self) -> None:
+        """Whole step (gather, loss, backward, dense Adam) in one launch, crh_mf_step_f32: the parameters
+        ping-pong between ``E`` and a second buffer, no gradient table is used.  Driven by ``fused_epoch``."""
+        assert self.k is ops and not self.lazy and self.dp is None and self.d <= 256
+        self.fused = True
+        self.E2 = torch.empty_like(self.E)
+        self._nparts = ops.mf_step_parts(self.E.shape[0], self.d)
+        self._parts = [torch.zeros(self._nparts * 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._fws, self._fws_cap = None, 0
+        self._fsums = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    def fused_epoch(self, u, i, j, steps, plans, tables, losses, scalars) -> None:
+        """All optimiser steps of one epoch (``steps`` = [(lo, hi)] into the triple arrays), one launch each; the
+        Frobenius norms of the first batch come from a forward pass, those of batch s+1 from launch s."""
+        U, (lo, hi) = self.user_num, steps[0]
+        if self._fws is None or self._fws_cap < hi - lo:
+            self._fws_cap = hi - lo
+            self._fws = ops.bpr_workspace(self._fws_cap, self.device)
+        ops.bpr_fwd(self.E[:U], self.E[U:], self.E[U:], u[lo:hi], i[lo:hi], j[lo:hi], self._fsums, self._fws)
+        part_in, n_in = self._fws.view(torch.float32), ops.bpr_fwd_parts(hi - lo, self.d)
+        src, dst, prev = self.E, self.E2, 0
+        rng, mult, ent = tables
+        for s, (lo, hi) in enumerate(steps):
+            part_out = self._parts[s & 1]
+            ops.mf_step(src, dst, self.M, self.V, U, hi - lo, self.reg, plans[s], rng[s], ent[s],
+                        mult[s + 1] if s + 1 < len(steps) else None, part_in, n_in, part_out,
+                        losses[s - 1] if s else None, prev, losses[s], scalars[s])
+            part_in, n_in, prev = part_out, self._nparts, hi - lo
+            src, dst = dst, src
+        ops.mf_step_finish(part_in, n_in, prev, losses[len(steps) - 1])
+        if src is not self.E:
+            self.E.copy_(src)
+        self.loss.copy_(losses[len(steps) - 1])
+        self.step_count += len(steps)
+
     def _scalar_table(self, upto: int) -> torch.Tensor:
         if self._table is None or upto > self._table_steps:
             n = max(1024, 2 * upto)
@@ -248,7 +293,7 @@ class EpochRunner:
     (= hipGraph) and every later epoch is one ``replay()`` after the buffers were refreshed.
     """
 
-    def __init__(self, engine, n_records: int, batch_size: int, use_graph: bool = True):
+    def __init__(self, engine, n_records: int, batch_size: int, use_graph: bool = True, fused: Optional[bool] = None):
         self.eng, self.n, self.B = engine, int(n_records), int(batch_size)
         dev = engine.device
         self.steps = [(lo, min(lo + self.B, self.n)) for lo in range(0, self.n, self.B)]
@@ -257,8 +302,17 @@ class EpochRunner:
         self.scalars = torch.empty((len(self.steps), 2), dtype=torch.float32, device=dev)
         self.losses = torch.zeros((len(self.steps), 2), dtype=torch.float32, device=dev)
         self.use_graph, self.graph, self.epochs_done = use_graph and not getattr(engine, "lazy", False), None, 0
+        # BPR-MF with cache-resident tables: the whole step is one launch (CRH_MF_FUSED=0 keeps the three-kernel step)
+        self.tables = None
+        if fused is None:
+            fused = os.environ.get("CRH_MF_FUSED", "1") != "0"
+        if fused and isinstance(engine, MFEngine) and engine.can_fuse(len(self.steps), self.B):
+            engine.enable_fused_step()
 
     def _all_steps(self):
+        if getattr(self.eng, "fused", False):
+            return self.eng.fused_epoch(self.u, self.i, self.j, self.steps, self.plans, self.tables, self.losses,
+                                        self.scalars)
         for s, (lo, hi) in enumerate(self.steps):
             self.eng.step(self.u[lo:hi], self.i[lo:hi], self.j[lo:hi], self.plans[s], self.losses[s], self.scalars[s])
 
@@ -273,6 +327,9 @@ class EpochRunner:
             self.plans = plans
         else:
             self.plans.copy_(plans)
+        if getattr(eng, "fused", False):
+            self.tables = ops.mf_step_tables(self.plans, self.u, self.i, self.j, self.B, eng.user_num, eng.item_num,
+                                             out=self.tables)
         sc = ops.adam_step_scalars(eng.step_count + 1, len(self.steps), eng.lr)
         self.scalars.copy_(torch.from_numpy(sc), non_blocking=True)
         if self.graph is not None:

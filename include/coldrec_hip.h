@@ -128,9 +128,9 @@ int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, in
  * grad_* are dense tables the gradients are ACCUMULATED into (zero them first; pos and neg may be the
  * same table); pass all three NULL for forward only.  loss_out[0] = bpr, loss_out[1] = l2 (device).
  * plan (device int32, or NULL): the batch's reverse index -- [nu, ni, L, user rows[L], offsets[L+1],
- * triple ids[L], item rows[2L], offsets[2L+1], entries[2L] = b | role<<30, n_heavy, heavy slots[3L/32+2]],
- * L >= batch the layout size; a heavy slot names a row with more than 32 entries (r < nu: user row r, else item
- * row r - nu), in any order -- built by crh_bpr_plan_build_host or on the device (crh_bpr_plan_build).  With a
+ * triple ids[L], item rows[2L], offsets[2L+1], entries[2L] = b | role<<30, n_heavy, heavy slots[3L/T+2]], T = crh_bpr_heavy_threshold(),
+ * L >= batch the layout size; a heavy slot names a row with more than T entries (r < nu: user row r, else item
+ * row r - nu), ascending -- built by crh_bpr_plan_build_host or on the device (crh_bpr_plan_build).  With a
  * plan every touched gradient row is summed in a fixed order (by one lane group; a heavy row by one workgroup, in
  * the same launch) and STORED (deterministic, no atomics; rows not touched are left as they are, i.e. zero);
  * it requires pos_table == neg_table and grad_pos == grad_neg.  Without a plan rows are accumulated
@@ -138,6 +138,7 @@ int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, in
  */
 size_t crh_bpr_workspace_bytes(int64_t batch);
 int64_t crh_bpr_plan_ints(int64_t batch);
+int crh_bpr_heavy_threshold(void);   /* a row with more entries than this is on the plan's heavy list */
 int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx_host,
                             const int32_t* neg_idx_host, int64_t batch, int64_t layout_batch,
                             int32_t* plan_out_host);   /* crh_bpr_plan_ints(layout_batch) ints */
@@ -244,6 +245,43 @@ int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val
                      const float* x, int d, float* y, const float* acc_in, float s_in,
                      float* acc_out, float s_out, const crh_spmm_sched* sched, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/*
+ * One optimiser step of model/MF.py:19-27 (gather, bpr_loss + l2_reg_loss, backward, torch.optim.Adam) in ONE
+ * launch, for tables that live in cache (MovieLens / CiteULike scale) where a step is launch and memory latency.
+ * Organised by table row: each row's gradient is summed in plan-list order (score differences recomputed from the
+ * rows, no forward pass, no gradient table), Adam is applied in registers and the new row goes to the OTHER
+ * parameter buffer (table_in != table_out; m, v in place).  The Frobenius norms a step needs are produced by
+ * the PREVIOUS call from the rows it has just updated (multiplicity in the next batch x |row|^2), as partial sums:
+ *   part_in   [n_parts_in][4]: (sum u^2, sum p^2, sum n^2) of THIS batch and the loss sum of the PREVIOUS one;
+ *             from the previous call's part_out (n_parts_in = crh_mf_step_parts(rows, d)) or, for the first step
+ *             of an epoch, the first crh_bpr_fwd_parts(batch, d) x 4 floats of crh_bpr_fwd_f32's workspace
+ *   part_out  [crh_mf_step_parts][4]
+ *   crh_mf_step_tables flattens an epoch's plans once: range (n_batches, rows) int2 = the row's slice of the
+ *             batch's entries, (0,0) if untouched; entries (n_batches, 3*batch_size) int2 = the two other rows of
+ *             the triple (table rows, users first; role << 30 in .x on the item side); mult (n_batches, rows) =
+ *             multiplicities of the row in the batch (user rows: count; item rows: positives | negatives << 16)
+ *   a step takes its batch's plan (heavy-row list), range and entries rows, and the NEXT batch's mult row
+ *             (NULL for the last step of the epoch)
+ *   loss_out[1] (l2) is written by this call; loss_out[0] (bpr) by the NEXT call through loss_prev_out
+ *   (batch_prev = this call's batch) or by crh_mf_step_finish after the last step.
+ *   step_scalars: device {sqrt(1-beta2^step), -lr/(1-beta1^step)} (crh_adam_step_scalars_range_host).
+ * Deterministic (no atomics); equal to crh_bpr_fwd_bwd_f32(plan) + crh_adam_dense_f32 up to fp32 summation
+ * order of the three norms.  d % 4 == 0, d <= 256, batch_size < 32768.
+ */
+int crh_bpr_fwd_parts(int64_t batch, int d);
+int crh_mf_step_parts(int64_t n_rows, int d);
+int crh_mf_step_tables(const int32_t* plans, const int32_t* user_idx, const int32_t* pos_idx,
+                       const int32_t* neg_idx, int64_t n_records, int64_t batch_size, int64_t user_rows,
+                       int64_t item_rows, int32_t* range_out, int32_t* mult_out, int32_t* entries_out,
+                       void* stream);
+int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v, int64_t user_rows,
+                    int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan,
+                    const int32_t* range, const int32_t* entries, const int32_t* mult_next,
+                    const float* part_in, int n_parts_in, float* part_out, float* loss_prev_out,
+                    int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
+                    const float* step_scalars, void* stream);
+int crh_mf_step_finish(const float* part_in, int n_parts_in, int64_t batch, float* loss_out, void* stream);
 
 /*
  * HOST-side negative sampler reproducing util/utils.py:123-157 (next_batch_pairwise) and NumPy's

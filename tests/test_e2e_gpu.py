@@ -243,10 +243,12 @@ print("RCCL_OK")
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
-def test_mf_trainer_with_lazy_adam_matches_dense_trainer():
+def test_mf_trainer_with_lazy_adam_matches_dense_trainer(monkeypatch):
     """--lazy_adam on: the MF trainer (eager epochs, touched-rows optimiser, flush before every validation) must
-    end with exactly the tables and metrics of the dense trainer."""
+    end with exactly the tables and metrics of the dense trainer (its three-kernel step: the one-launch step sums
+    the norms in another order, so it is close but not bit-equal)."""
     from coldrec_amd.model import AVAILABLE_MODELS
+    monkeypatch.setenv("CRH_MF_FUSED", "0")
     from coldrec_amd.util.utils import set_seed
     outs = []
     for mode in ("off", "on"):

@@ -51,10 +51,12 @@ def _plan_views(plan):
     urow, uptr, ulist = plan[3:3 + L], plan[3 + L:4 + 2 * L], plan[4 + 2 * L:4 + 3 * L]
     o = 4 + 3 * L
     irow, iptr, ilist = plan[o:o + 2 * L], plan[o + 2 * L:o + 4 * L + 1], plan[o + 4 * L + 1:o + 6 * L + 1]
-    ho = 3 + (3 * L + 1) + (6 * L + 1)                       # heavy rows: [count, slots...] (any order)
-    heavy = np.sort(plan[ho + 1: ho + 1 + int(plan[ho])])
+    ho = 3 + (3 * L + 1) + (6 * L + 1)                       # heavy rows: [count, slots ascending...]
+    heavy = plan[ho + 1: ho + 1 + int(plan[ho])]
     cnt = np.concatenate([np.diff(uptr[:nu + 1]), np.diff(iptr[:ni + 1])])
-    assert np.array_equal(heavy, np.nonzero(cnt > 32)[0]), "heavy list != rows with more than 32 entries"
+    from coldrec_amd import _lib
+    T = int(_lib.lib().crh_bpr_heavy_threshold())
+    assert np.array_equal(heavy, np.nonzero(cnt > T)[0]), "heavy list != rows with more than T entries"
     return dict(urow=urow[:nu], uptr=uptr[:nu + 1], ulist=ulist[:uptr[nu]], irow=irow[:ni], iptr=iptr[:ni + 1],
                 ilist=ilist[:iptr[ni]], heavy=heavy)
 
@@ -102,7 +104,9 @@ def test_plan_kernel_whole_epoch_with_short_last_batch():
     u, p, n = (rng.integers(0, 700, n_rec).astype(np.int32) for _ in range(3))
     dev = ops.build_plans_device(t(u), t(p), t(n), L).cpu().numpy()
     host = ops.build_plans(u, p, n, L)
-    assert dev.shape == host.shape == (3, 9 * L + 5 + 1 + (3 * L // 32 + 2))   # + [n_heavy, slots...]
+    from coldrec_amd import _lib
+    T = int(_lib.lib().crh_bpr_heavy_threshold())
+    assert dev.shape == host.shape == (3, 9 * L + 5 + 1 + (3 * L // T + 2))   # + [n_heavy, slots...]
     for b in range(3):
         for k, v in _plan_views(host[b]).items():
             assert np.array_equal(v, _plan_views(dev[b])[k]), (b, k)
@@ -335,7 +339,7 @@ def test_epoch_runner_graph_replay_equals_eager():
     for make in (lambda: MFEngine(g["d16_U0"], g["d16_V0"], 1e-3, 1e-4, DEV),
                  lambda: LGCNEngine(g5["U0"], g5["V0"], rowptr, col, val, 2, 1e-3, 1e-4, DEV)):
         a, b = make(), make()
-        runner = EpochRunner(a, n, B)
+        runner = EpochRunner(a, n, B, fused=False)       # the one-launch MF step has its own test (not bit-equal)
         for epoch in range(4):
             u = rng.integers(0, a.user_num, n).astype(np.int32)
             i = rng.integers(0, a.item_num, n).astype(np.int32)
@@ -472,3 +476,82 @@ def test_lazy_adam_replay_is_bitwise_dense_adam(d, B):
     lazy.step(tu, ti, tj)
     lazy.sync_tables()
     assert torch.equal(dense.E.view(torch.int32), lazy.E.view(torch.int32))
+
+
+@pytest.mark.parametrize("d,n_rec,B", [(128, 3 * 512 + 77, 512), (64, 4 * 300, 300), (200, 700, 256), (8, 5000, 4096)])
+def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B):
+    """crh_mf_step_f32 (one launch per step: recomputed score differences, Adam in registers, norms of the next
+    batch from the updated rows) against forward + plan backward + dense Adam: same losses and tables up to the
+    fp32 summation order of the three norms; bit-reproducible; hot items exercise the heavy-row blocks; odd and
+    even step counts exercise the ping-pong copy-back; the last batch is short."""
+    from coldrec_amd.train import EpochRunner, MFEngine
+    rng = np.random.default_rng(d + B)
+    n_u, n_i = 300, 500
+    U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
+    epochs = []
+    for _ in range(3):
+        u = rng.integers(0, n_u, n_rec).astype(np.int32)
+        hot = rng.random(n_rec) < 0.3
+        i = np.where(hot, rng.integers(0, 3, n_rec), rng.integers(0, n_i, n_rec)).astype(np.int32)
+        j = rng.integers(0, n_i, n_rec).astype(np.int32)
+        j = np.where(j == i, (j + 1) % n_i, j).astype(np.int32)
+        epochs.append((u, i, j))
+    runs = {}
+    for tag, fused in (("fused", True), ("fused2", True), ("plain", False)):
+        eng = MFEngine(U0, V0, 1e-2, 1e-3, DEV)
+        runner = EpochRunner(eng, n_rec, B, fused=fused)
+        assert eng.fused == fused
+        losses = [runner.run(*ep).clone() for ep in epochs]           # eager, captured + replayed, replayed
+        torch.cuda.synchronize()
+        runs[tag] = (torch.cat(losses).cpu().numpy(), eng.E.cpu().numpy(), eng.M.cpu().numpy(), eng.V.cpu().numpy(),
+                     eng.step_count)
+    for a, b in zip(runs["fused"][:4], runs["fused2"][:4]):
+        assert np.array_equal(a, b)                                   # deterministic
+    assert runs["fused"][4] == runs["plain"][4] == 3 * ((n_rec + B - 1) // B)
+    np.testing.assert_allclose(runs["fused"][0], runs["plain"][0], rtol=2e-6, atol=1e-9)
+    for a, b in zip(runs["fused"][1:4], runs["plain"][1:4]):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max())
+
+
+def test_fused_mf_step_first_step_against_oracle():
+    """One fused step from the C ABI against the fp64 closed form + the oracle's Adam."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(77)
+    n_u, n_i, d, B = 90, 140, 64, 333
+    U0 = (rng.standard_normal((n_u, d)) * 0.2).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.2).astype(np.float32)
+    ui = rng.integers(0, n_u, B).astype(np.int32)
+    pi = np.where(rng.random(B) < 0.4, 7, rng.integers(0, n_i, B)).astype(np.int32)      # item 7 is a heavy row
+    ni = rng.integers(0, n_i, B).astype(np.int32)
+    ni = np.where(ni == pi, (ni + 1) % n_i, ni).astype(np.int32)
+    reg, lr = 0.05, 1e-2
+    bpr, l2, gU, gV, _ = orc.bpr_l2_fwd_bwd(U0, V0, ui, pi, ni, reg)
+    E0 = np.concatenate([U0, V0])
+    z = np.zeros_like(E0)
+    want_p, want_m, want_v = orc.adam_dense(E0, np.concatenate([gU, gV]).astype(np.float32), z, z, 1, lr=lr)
+    E, E2 = t(E0), torch.empty_like(t(E0))
+    M, V = torch.zeros_like(E), torch.zeros_like(E)
+    tu, tp, tn = t(ui), t(pi), t(ni)
+    plans = ops.build_plans_device(tu, tp, tn, B)
+    rng_t, mult_t, ent_t = ops.mf_step_tables(plans, tu, tp, tn, B, n_u, n_i)
+    touched = (rng_t[0, :, 1] > rng_t[0, :, 0]).cpu().numpy()
+    assert touched.sum() == len(np.unique(ui)) + len(np.unique(np.concatenate([pi, ni])))
+    mu = mult_t[0].cpu().numpy()
+    assert np.array_equal(mu[:n_u], np.bincount(ui, minlength=n_u))
+    assert np.array_equal(mu[n_u:] & 0xffff, np.bincount(pi, minlength=n_i))
+    assert np.array_equal(mu[n_u:] >> 16, np.bincount(ni, minlength=n_i))
+    ws = ops.bpr_workspace(B, DEV)
+    ops.bpr_fwd(E[:n_u], E[n_u:], E[n_u:], tu, tp, tn, torch.zeros(4, device=DEV), ws)
+    parts = torch.zeros(4 * ops.mf_step_parts(n_u + n_i, d), device=DEV)
+    loss = torch.zeros(2, device=DEV)
+    sc = torch.from_numpy(ops.adam_step_scalars(1, 1, lr)).to(DEV)
+    ops.mf_step(E, E2, M, V, n_u, B, reg, plans[0], rng_t[0], ent_t[0], None, ws.view(torch.float32),
+                ops.bpr_fwd_parts(B, d), parts, None, 0, loss, sc[0])
+    ops.mf_step_finish(parts, ops.mf_step_parts(n_u + n_i, d), B, loss)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss.cpu().numpy(), [bpr, l2], rtol=1e-5)
+    np.testing.assert_allclose(M.cpu().numpy(), want_m, rtol=1e-4, atol=1e-9)
+    # the first Adam step moves an element by lr * g / (|g| + 1e-8): ill-conditioned where |g| ~ 1e-8, hence lr-scaled
+    np.testing.assert_allclose(E2.cpu().numpy(), want_p, rtol=1e-5, atol=1e-3 * lr)
+    assert torch.equal(E, t(E0))                                       # the input buffer is left alone
