@@ -411,7 +411,7 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a, in
 // One workgroup per batch sorts the batch's (row << 31 | entry) keys in LDS (bitonic, 64-bit keys) and
 // emits the reverse index in the layout bpr_bwd_rows_kernel reads.  An epoch of S-ML (159 batches of
 // 4096 triples) is one launch of 159 workgroups.
-constexpr int PLAN_THREADS = 256;
+constexpr int PLAN_THREADS = 1024;
 
 __device__ inline void bitonic_sort_lds(unsigned long long* keys, int P) {
     for (int k = 2; k <= P; k <<= 1) {
@@ -447,7 +447,7 @@ __device__ inline int plan_emit(const unsigned long long* keys, int P, int32_t* 
     scan[threadIdx.x] = starts;
     scan[PLAN_THREADS + threadIdx.x] = valid;
     __syncthreads();
-    if (threadIdx.x == 0) {                       // 256-entry serial scan: negligible next to the sort
+    if (threadIdx.x == 0) {                       // PLAN_THREADS-entry serial scan: negligible next to the sort
         int acc = 0, tv = 0;
         for (int i = 0; i < PLAN_THREADS; ++i) {
             const int c = scan[i];
@@ -714,7 +714,7 @@ int dispatch_group(int g, F&& f) {
 // in batch b.  A row then costs three round trips: {range, mult, p, m, v} -> entries -> gathered rows.
 // Heavy rows (more than BPR_HEAVY entries) are done by the extra blocks, one block per row, exactly as before.
 // Deterministic: no atomics, fixed summation orders.  d <= 256, batch < 32768.
-constexpr int MF_MAX_LIGHT = 2048, MF_HEAVY_BLOCKS = 256;
+constexpr int MF_MAX_LIGHT = 2048, MF_HEAVY_BLOCKS = 96;
 
 struct MfStepArgs {
     const float* pin;      // (U + I, d) parameters before the step, users first
@@ -810,8 +810,8 @@ __device__ __forceinline__ void mf_entries_chunk(const MfStepArgs& a, const BwdC
     }
 }
 
-// Entries [e0, e1) of one row, in list order: metadata one entry per lane, rows fetched 4 entries at a time while
-// four are left, one at a time after that (most rows of a batch have one or two entries).
+// Entries [e0, e1) of one row, in list order: metadata one entry per lane, rows fetched 2 entries at a time (most rows
+// of a batch have one or two entries; 4 at a time costs the registers of a fourth wave per SIMD).
 template <int G>
 __device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoef& k, bool user_side, int e0, int e1,
                                                bool on, int lig, const f32x4& own, f32x4& acc, float& loss) {
@@ -821,8 +821,8 @@ __device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoe
         if (e < e1) en = a.entries[e];
         const int cnt = (e1 - base) < G ? (e1 - base) : G;
         int t = 0;
-        for (; t + 4 <= cnt; t += 4) mf_entries_chunk<G, 4>(a, k, user_side, en, t, on, lig, own, acc, loss);
-        for (; t < cnt; ++t) mf_entries_chunk<G, 1>(a, k, user_side, en, t, on, lig, own, acc, loss);
+        for (; t + 2 <= cnt; t += 2) mf_entries_chunk<G, 2>(a, k, user_side, en, t, on, lig, own, acc, loss);
+        if (t < cnt) mf_entries_chunk<G, 1>(a, k, user_side, en, t, on, lig, own, acc, loss);
     }
 }
 
@@ -853,7 +853,7 @@ __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, 
 }
 
 template <int G>
-__global__ __launch_bounds__(BPR_THREADS) void mf_step_kernel(MfStepArgs a) {
+__global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     __shared__ f32x4 red4[4];
     __shared__ float red[4];
     __shared__ f32x4 wsum[4][G];

@@ -511,7 +511,7 @@ def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B):
     assert runs["fused"][4] == runs["plain"][4] == 3 * ((n_rec + B - 1) // B)
     np.testing.assert_allclose(runs["fused"][0], runs["plain"][0], rtol=2e-6, atol=1e-9)
     for a, b in zip(runs["fused"][1:4], runs["plain"][1:4]):
-        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6 * np.abs(b).max())
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-5 * np.abs(b).max())   # sums with cancellation
 
 
 def test_fused_mf_step_first_step_against_oracle():

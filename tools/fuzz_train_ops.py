@@ -6,7 +6,9 @@ Per case: random table sizes / widths / batch sizes / duplicate patterns, then
     closed form (1e-5 on the losses, 5e-4 / scaled absolute on gradients); the plan backward twice -> identical bits;
   * crh_spmm_csr_f32 with and without the schedule on a random Zipf graph vs the C oracle: rows in one piece
     bit-exact, heavy rows to rounding;
-  * a few optimiser steps with the dense Adam and with the touched-rows replay -> identical bits after the flush.
+  * a few optimiser steps with the dense Adam and with the touched-rows replay -> identical bits after the flush;
+  * whole epochs with the one-launch MF step (crh_mf_step_f32) against the three-kernel step -> same losses and tables
+    up to the summation order of the norms, and bit-identical when repeated.
 
     python tools/fuzz_train_ops.py --minutes 5 [--seed 0]
 """
@@ -139,6 +141,45 @@ def case_adam(rng):
             fail("lazy adam", what=name, d=d, B=B)
 
 
+def case_fused(rng):
+    from coldrec_amd.train import EpochRunner
+    d = int(rng.choice([4, 16, 64, 128, 200, 256]))
+    n_u, n_i = int(rng.integers(2, 900)), int(rng.integers(3, 1500))
+    B = int(rng.choice([3, 64, 1000, 4096]))
+    n_rec = int(rng.integers(1, 4 * B + 2))
+    U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
+    hot_frac = float(rng.choice([0.0, 0.3, 0.95]))
+    epochs = []
+    for _ in range(int(rng.integers(1, 4))):
+        u = rng.integers(0, n_u, n_rec).astype(np.int32)
+        i = np.where(rng.random(n_rec) < hot_frac, rng.integers(0, min(3, n_i), n_rec), rng.integers(0, n_i, n_rec)).astype(np.int32)
+        j = rng.integers(0, n_i, n_rec).astype(np.int32)
+        j = np.where(j == i, (j + 1) % n_i, j).astype(np.int32)
+        epochs.append((u, i, j))
+    res = []
+    for fused in (True, True, False):
+        eng = MFEngine(U0, V0, 1e-2, 1e-3, DEV)
+        runner = EpochRunner(eng, n_rec, B, fused=fused)
+        losses = torch.cat([runner.run(*ep).clone() for ep in epochs])
+        torch.cuda.synchronize()
+        res.append((losses.cpu().numpy(), eng.E.cpu().numpy(), eng.M.cpu().numpy(), eng.V.cpu().numpy()))
+    for a, b in zip(res[0], res[1]):
+        if not np.array_equal(a, b):
+            fail("fused step not deterministic", d=d, B=B, n_rec=n_rec)
+    if not np.allclose(res[0][0], res[2][0], rtol=1e-5, atol=1e-9):
+        fail("fused losses", d=d, B=B, n_rec=n_rec, err=float(np.abs(res[0][0] - res[2][0]).max()))
+    n_steps = len(epochs) * ((n_rec + B - 1) // B)
+    for name, a, b in zip("EMV", res[0][1:], res[2][1:]):
+        # gradient elements are sums with cancellation (floor 1e-5 of the largest entry).  An element whose gradient is
+        # ~1e-8 (Adam's eps) is ill-conditioned: a step moves it by lr * g / (|g| + eps), anywhere in [-lr, lr] -- allow
+        # a handful of such elements, bounded by what the steps taken can move them
+        bad = ~np.isclose(a, b, rtol=5e-4, atol=1e-5 * np.abs(b).max())
+        if bad.sum() > max(2, 1e-4 * bad.size) or (name == "E" and np.abs(a - b).max() > 2 * 1e-2 * n_steps):
+            fail("fused tables", table=name, d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
+                 err=float(np.abs(a - b).max()), scale=float(np.abs(b).max()), nbad=int(bad.sum()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=5.0)
@@ -146,10 +187,10 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.minutes * 60
-    counts = {"bpr": 0, "spmm": 0, "adam": 0}
+    counts = {"bpr": 0, "spmm": 0, "adam": 0, "fused": 0}
     while time.time() < t_end:
-        which = str(rng.choice(["bpr", "spmm", "adam"]))
-        {"bpr": case_bpr, "spmm": case_spmm, "adam": case_adam}[which](rng)
+        which = str(rng.choice(["bpr", "spmm", "adam", "fused"]))
+        {"bpr": case_bpr, "spmm": case_spmm, "adam": case_adam, "fused": case_fused}[which](rng)
         counts[which] += 1
     print(f"fuzz ok: {counts} random cases within parity, seed {args.seed}")
 
