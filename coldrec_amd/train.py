@@ -3,8 +3,9 @@
 State layout in HBM: ONE (user_num + item_num, d) fp32 buffer per quantity -- parameters E,
 gradient G, Adam moments M and V -- with the user rows first.  ``user_emb`` / ``item_emb`` are
 views, so LightGCN's torch.cat (model/LightGCN.py:87) costs nothing and Adam is one segment.
-A step is 3 kernel launches for MF (forward partials, backward scatter, Adam) and 3 + 2L + 1 for
-LightGCN; nothing is copied to the host unless the caller asks for the loss.
+A step is 3 kernel launches for MF (forward partials, row gradients, Adam) -- or ONE when the tables are
+cache-sized (``MFEngine.enable_fused_step``, the default of ``EpochRunner``) -- and 3 + 2L + 1 for LightGCN;
+nothing is copied to the host unless the caller asks for the loss.
 """
 from __future__ import annotations
 
