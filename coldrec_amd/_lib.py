@@ -58,6 +58,8 @@ SIGNATURES = {
     "crh_adam_step_scalars_range_host": (None, [_f64, _f64, _f64, _i64, _i64, _vp]),
     "crh_spmm_segment_edges": (_i32, []),
     "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),
+    "crh_spmm_csr_adam_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _f32, _vp, _f32, _vp, _vp, _vp, _vp,
+                                     _f64, _f64, _f64, _f64, _i64, _vp, _i32, _vp]),
     "crh_spmm_csr_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _sz, _vp]),
     "crh_bpr_fwd_parts": (_i32, [_i64, _i32]),
     "crh_mf_step_parts": (_i32, [_i64, _i32]),

@@ -37,3 +37,24 @@ __device__ __forceinline__ bool crh_better(float sa, int ia, float sb, int ib) {
 }
 
 #define CRH_NEG_INF (-__builtin_inff())
+
+// One Adam step of one element, op for op what torch/optim/adam.py _single_tensor_adam does.  Shared by the
+// dense kernel, the touched-rows replay, the one-launch MF step and the SpMM epilogue so that all produce the same bits.
+struct AdamK {
+    float one_minus_b1, b2, one_minus_b2, eps;
+};
+__device__ __forceinline__ void adam_elem4(f32x4& p, f32x4& m, f32x4& v, const f32x4& g, const AdamK& k,
+                                           float bc2_sqrt, float neg_step_size) {
+    // every product and sum rounded on its own, as the separate ATen ops of the reference do -- and so that
+    // the compiler cannot fuse differently in the two kernels that share this function
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float mc = m[c] + k.one_minus_b1 * (g[c] - m[c]);        // exp_avg.lerp_(grad, 1-b1)
+        const float vc = v[c] * k.b2 + (k.one_minus_b2 * g[c]) * g[c];  // mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(vc) / bc2_sqrt + k.eps;               // sqrt()/bc2_sqrt + eps
+        p[c] = p[c] + neg_step_size * (mc / denom);                     // addcdiv_(m, denom, -step_size)
+        m[c] = mc;
+        v[c] = vc;
+    }
+}

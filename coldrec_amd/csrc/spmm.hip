@@ -22,6 +22,7 @@
 // slice of it does (CiteULike: 22.5 K rows x 512 B = 11.5 MB; a quarter = 2.9 MB), the feature columns
 // are cut into CS slices and block b works on slice (b % 8) % CS, so every XCD (blocks b % 8) gathers
 // from ONE slice only and its random row reads hit its own L2 instead of going out to the fabric.
+#include <math.h>
 #include <stdlib.h>
 
 #include "crh_common.h"
@@ -36,7 +37,7 @@ struct SpmmArgs {
     const float* X;
     int d;
     float* Y;
-    const float* acc_in;
+    float* acc_in;
     float* acc_out;
     float s_in, s_out;
     crh_spmm_sched sched;   // n_seg == 0: one lane group per row
@@ -44,6 +45,12 @@ struct SpmmArgs {
     int cs;                 // column slices (1, 2 or 4)
     int64_t light_blocks;   // blocks per slice working on light work items; heavy rows follow
     int skip;               // measurement only (CRH_SPMM_SKIP): 1 = no heavy rows, 2 = no light rows
+    // optional optimiser epilogue (crh_spmm_csr_adam_f32): acc is the gradient of p -> one Adam step on (p, m, v)
+    float *adam_p, *adam_m, *adam_v;
+    AdamK k;
+    float bc2_sqrt, neg_step_size;
+    const float* step_scalars;
+    int zero_acc_in;        // clear acc_in's row once it has been consumed (ready for the next step's scatter)
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -55,7 +62,7 @@ __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
 
 __device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc) {
     if (a.Y) *reinterpret_cast<f32x4*>(a.Y + o) = acc;
-    if (a.acc_out) {
+    if (a.acc_out || a.adam_p) {
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if (a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
         f32x4 r;
@@ -63,7 +70,18 @@ __device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f3
         r.y = (z.y * a.s_in + acc.y) * a.s_out;
         r.z = (z.z * a.s_in + acc.z) * a.s_out;
         r.w = (z.w * a.s_in + acc.w) * a.s_out;
-        *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
+        if (a.acc_out) *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
+        if (a.adam_p) {
+            f32x4 p = *reinterpret_cast<const f32x4*>(a.adam_p + o), m = *reinterpret_cast<const f32x4*>(a.adam_m + o);
+            f32x4 v = *reinterpret_cast<const f32x4*>(a.adam_v + o);
+            const float b2s = a.step_scalars ? a.step_scalars[0] : a.bc2_sqrt;
+            const float nss = a.step_scalars ? a.step_scalars[1] : a.neg_step_size;
+            adam_elem4(p, m, v, r, a.k, b2s, nss);
+            *reinterpret_cast<f32x4*>(a.adam_p + o) = p;
+            *reinterpret_cast<f32x4*>(a.adam_m + o) = m;
+            *reinterpret_cast<f32x4*>(a.adam_v + o) = v;
+        }
+        if (a.zero_acc_in && a.acc_in) *reinterpret_cast<f32x4*>(a.acc_in + o) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -200,7 +218,11 @@ int launch_spmm(SpmmArgs a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int crh_spmm_segment_edges(void) { return 64; }
+// 64 measured best at CiteULike size (LightGCN step 0.197 ms; 32: 0.213, 16: 0.406, 128: 0.203 -- CRH_SPMM_SEG)
+extern "C" int crh_spmm_segment_edges(void) {
+    static const int seg = getenv("CRH_SPMM_SEG") ? atoi(getenv("CRH_SPMM_SEG")) : 64;
+    return seg;
+}
 
 extern "C" size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d) {
     (void)sched;
@@ -208,23 +230,25 @@ extern "C" size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d) {
     return 0;   // heavy rows are combined inside their wave: no partial sums in memory any more
 }
 
-extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
-                                const float* x, int d, float* y, const float* acc_in, float s_in,
-                                float* acc_out, float s_out, const crh_spmm_sched* sched, void* workspace,
-                                size_t workspace_bytes, void* stream) {
-    CRH_CHECK_ARG(rowptr && x && n_rows > 0, "crh_spmm_csr_f32: NULL pointer / empty matrix");
-    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_spmm_csr_f32: d=%d must be a positive multiple of 4", d);
-    CRH_CHECK_ARG(y || acc_out, "crh_spmm_csr_f32: nothing to write (y and acc_out both NULL)");
-    CRH_CHECK_ARG(y != x && acc_out != x, "crh_spmm_csr_f32: outputs must not alias x");
-    CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out | (uintptr_t)workspace) & 15) == 0,
-                  "crh_spmm_csr_f32: dense operands must be 16-byte aligned");
+namespace {
+int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* x,
+             int d, float* y, float* acc_in, float s_in, float* acc_out, float s_out, const crh_spmm_sched* sched,
+             float* adam_p, float* adam_m, float* adam_v, AdamK k, float bc2_sqrt, float nss, const float* step_scalars,
+             int zero_acc_in, void* stream) {
+    CRH_CHECK_ARG(rowptr && x && n_rows > 0, "%s: NULL pointer / empty matrix", who);
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "%s: d=%d must be a positive multiple of 4", who, d);
+    CRH_CHECK_ARG(y || acc_out || adam_p, "%s: nothing to write (y and acc_out both NULL)", who);
+    CRH_CHECK_ARG(y != x && acc_out != x && adam_p != x && !(zero_acc_in && acc_in == x),
+                  "%s: outputs must not alias x", who);
+    CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out | (uintptr_t)adam_p |
+                    (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) == 0,
+                  "%s: dense operands must be 16-byte aligned", who);
     static const int skip = getenv("CRH_SPMM_SKIP") ? atoi(getenv("CRH_SPMM_SKIP")) : 0;
-    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0, skip};
-    (void)workspace;
-    (void)workspace_bytes;
+    SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0, skip,
+               adam_p, adam_m, adam_v, k, bc2_sqrt, nss, step_scalars, zero_acc_in};
     if (sched && sched->n_seg > 0) {
-        CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "crh_spmm_csr_f32: incomplete schedule");
-        CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "crh_spmm_csr_f32: incomplete schedule (heavy rows)");
+        CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "%s: incomplete schedule", who);
+        CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "%s: incomplete schedule (heavy rows)", who);
         a.sched = *sched;
     } else {
         a.sched.n_seg = 0;
@@ -246,11 +270,11 @@ extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const
     a.cs = cs;
     int G = 1;
     while (G < nvec / cs && G < 64) G <<= 1;
-    CRH_CHECK_ARG(G * cs == nvec || cs == 1, "crh_spmm_csr_f32: internal slice error");
+    CRH_CHECK_ARG(G * cs == nvec || cs == 1, "%s: internal slice error", who);
     if (G * cs != nvec) {   // d/4 not a power of two (or > 64 lanes): fall back to one slice, padded lane group
         a.cs = 1;
     }
-    CRH_CHECK_ARG(a.cs > 1 || G >= nvec, "crh_spmm_csr_f32: d=%d above 256 is not supported", d);
+    CRH_CHECK_ARG(a.cs > 1 || G >= nvec, "%s: d=%d above 256 is not supported", who, d);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (G) {
         case 1: return launch_spmm<1>(a, st);
@@ -261,4 +285,36 @@ extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const
         case 32: return launch_spmm<32>(a, st);
         default: return launch_spmm<64>(a, st);
     }
+}
+}  // namespace
+
+extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                const float* x, int d, float* y, const float* acc_in, float s_in,
+                                float* acc_out, float s_out, const crh_spmm_sched* sched, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    (void)workspace;
+    (void)workspace_bytes;
+    return spmm_run("crh_spmm_csr_f32", rowptr, col, val, n_rows, x, d, y, const_cast<float*>(acc_in), s_in, acc_out,
+                    s_out, sched, nullptr, nullptr, nullptr, AdamK{}, 0.f, 0.f, nullptr, 0, stream);
+}
+
+// The last SpMM of LightGCN's backward pass with the optimiser fused into its epilogue (model/LightGCN.py:26-28):
+//   g = (acc_in * s_in + A x) * s_out   is the gradient of the embedding table p (also stored to acc_out if given);
+//   one Adam step (torch.optim.Adam defaults, crh_adam_dense_f32's arithmetic, same bits) on (p, m, v) in place;
+//   zero_acc_in != 0: acc_in's row is cleared after it was consumed, ready for the next step's gradient scatter
+//   (acc_in must then not be the gathered operand x).
+// step >= 1 gives the bias corrections; step_scalars (device, {sqrt(1-beta2^step), -lr/(1-beta1^step)}) overrides
+// them for graph replay.
+extern "C" int crh_spmm_csr_adam_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                     const float* x, int d, float* acc_in, float s_in, float* acc_out, float s_out,
+                                     const crh_spmm_sched* sched, float* p, float* m, float* v, double lr,
+                                     double beta1, double beta2, double eps, int64_t step,
+                                     const float* step_scalars, int zero_acc_in, void* stream) {
+    CRH_CHECK_ARG(p && m && v, "crh_spmm_csr_adam_f32: NULL optimiser state");
+    CRH_CHECK_ARG(step >= 1 || step_scalars, "crh_spmm_csr_adam_f32: step starts at 1");
+    if (step < 1) step = 1;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    return spmm_run("crh_spmm_csr_adam_f32", rowptr, col, val, n_rows, x, d, nullptr, acc_in, s_in, acc_out, s_out, sched,
+                    p, m, v, AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps},
+                    (float)sqrt(bc2), (float)(-(lr / bc1)), step_scalars, zero_acc_in, stream);
 }

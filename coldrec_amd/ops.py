@@ -412,6 +412,25 @@ def adam_rows(p, g, m, v, last_step, plan, batch: int, user_rows: int, step: int
     _lib.check(rc, "crh_adam_rows_f32")
 
 
+def spmm_csr_adam(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: float, sched, p, m, v, step: int,
+                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, step_scalars=None,
+                  zero_acc_in: bool = False) -> None:
+    """g = (acc_in*s_in + A @ x)*s_out -> one Adam step on (p, m, v) in the SpMM's epilogue (crh_spmm_csr_adam_f32);
+    ``zero_acc_in`` clears acc_in row by row once consumed.  Same bits as spmm_csr(acc_out=g) + adam_dense."""
+    _need_cuda(rowptr, col, val, x, acc_in, acc_out, p, m, v, step_scalars)
+    assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
+    n_rows, d = rowptr.shape[0] - 1, x.shape[1]
+    for t in (x, p, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n_rows, d)
+    rc = _lib.lib().crh_spmm_csr_adam_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
+                                          _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
+                                          ctypes.byref(sched.c) if sched is not None else None, _lib.ptr(p),
+                                          _lib.ptr(m), _lib.ptr(v), float(lr), float(betas[0]), float(betas[1]),
+                                          float(eps), int(step), _lib.ptr(step_scalars), int(bool(zero_acc_in)),
+                                          _lib.current_stream())
+    _lib.check(rc, "crh_spmm_csr_adam_f32")
+
+
 class SpmmSchedule:
     """Load-balancing schedule of one CSR matrix (see crh_spmm_sched): rows cut into segments of at
     most crh_spmm_segment_edges() edges, built once per graph on the host with numpy."""

@@ -242,6 +242,10 @@ class LGCNEngine(_TableState):
         self.X = [torch.empty_like(self.E) for _ in range(2)]   # layer ping-pong
         self.OUT = torch.empty_like(self.E)                     # mean of the layer outputs
         self.dOUT = torch.zeros_like(self.E)
+        self._dout_clean = True
+        # Adam in the epilogue of the last backward SpMM (CRH_LGCN_FUSED=0: separate gradient table + Adam launch)
+        self.fuse_adam = self.k is ops and os.environ.get("CRH_LGCN_FUSED", "1") != "0"
+        self.keep_grad = False       # also store dE0 into self.G (tests compare it with the reference's autograd)
 
     def _propagate(self, out: torch.Tensor) -> None:
         c = 1.0 / (self.L + 1)
@@ -261,7 +265,8 @@ class LGCNEngine(_TableState):
              step_scalars=None) -> None:
         U, c = self.user_num, 1.0 / (self.L + 1)
         self._propagate(self.OUT)
-        self.dOUT.zero_()
+        if not self._dout_clean:
+            self.dOUT.zero_()
         loss = self.loss if loss_out is None else loss_out
         if self.dp is not None:
             # propagation is replicated; only the loss/gradient of the batch is sharded, and the exchange
@@ -274,12 +279,22 @@ class LGCNEngine(_TableState):
                                self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], loss, plan=plan)
         # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
         x = self.dOUT
+        self.step_count += 1
         for j in range(self.L):
-            dst = self.G if j == self.L - 1 else self.X[j & 1]
+            last = j == self.L - 1
+            if last and self.fuse_adam:
+                # the optimiser runs in the last SpMM's epilogue (no gradient table, no Adam launch); for L >= 2 the
+                # gathered operand is not dOUT, so the same epilogue clears dOUT for the next step's scatter
+                self._dout_clean = self.L >= 2
+                self.k.spmm_csr_adam(self.rowptr, self.col, self.val, x, self.dOUT, 1.0 if j == 0 else c,
+                                     self.G if self.keep_grad else None, c if j == 0 else 1.0, self.sched, self.E, self.M, self.V, self.step_count,
+                                     lr=self.lr, step_scalars=step_scalars, zero_acc_in=self._dout_clean)
+                return
+            dst = self.G if last else self.X[j & 1]
             self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=None, acc_in=self.dOUT,
                             s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, sched=self.sched)
             x = dst
-        self.step_count += 1
+        self._dout_clean = False
         self.k.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False,
                           step_scalars=step_scalars)
 

@@ -247,6 +247,18 @@ int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val
                      size_t workspace_bytes, void* stream);
 
 /*
+ * The last SpMM of LightGCN's backward pass with torch.optim.Adam fused into its epilogue (model/LightGCN.py:26-28):
+ * g = (acc_in * s_in + A x) * s_out is the gradient of the embedding table p (also stored to acc_out if not NULL);
+ * one Adam step with crh_adam_dense_f32's arithmetic (same bits) on (p, m, v) in place; zero_acc_in != 0 clears
+ * acc_in's row after it was consumed (ready for the next step's gradient scatter; acc_in must then differ from x).
+ */
+int crh_spmm_csr_adam_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                          const float* x, int d, float* acc_in, float s_in, float* acc_out, float s_out,
+                          const crh_spmm_sched* sched, float* p, float* m, float* v, double lr,
+                          double beta1, double beta2, double eps, int64_t step,
+                          const float* step_scalars, int zero_acc_in, void* stream);
+
+/*
  * One optimiser step of model/MF.py:19-27 (gather, bpr_loss + l2_reg_loss, backward, torch.optim.Adam) in ONE
  * launch, for tables that live in cache (MovieLens / CiteULike scale) where a step is launch and memory latency.
  * Organised by table row: each row's gradient is summed in plan-list order (score differences recomputed from the

@@ -265,6 +265,7 @@ def test_lgcn_forward_golden_g5_and_training():
         np.testing.assert_allclose(uo.cpu().numpy(), g5[f"L{L}_user_out"], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(io.cpu().numpy(), g5[f"L{L}_item_out"], rtol=1e-5, atol=1e-7)
     eng = LGCNEngine(g5["U0"], g5["V0"], rowptr, col, val, 3, float(g5["lr"]), float(g5["reg"]), DEV)
+    eng.keep_grad = True                     # dE0 is otherwise consumed inside the last SpMM's epilogue
     off = np.concatenate([[0], np.cumsum(g5["train_sizes"])])
     tu, ti, tj = (t(g5[k], torch.int32) for k in ("train_u", "train_i", "train_j"))
     for s in range(20):
@@ -306,6 +307,7 @@ def test_full_size_mf_and_lgcn_steps_vs_oracle():
     U0 = (rng.uniform(-1, 1, (U, d)) * 0.03).astype(np.float32)
     V0 = (rng.uniform(-1, 1, (I, d)) * 0.03).astype(np.float32)
     eng = LGCNEngine(U0, V0, rowptr, col, val, 3, 1e-3, 1e-4, DEV)
+    eng.keep_grad = True
     uo, io = eng.forward()
     wu, wi = orc.lgcn_forward(rowptr, col, val, U0, V0, 3)
     np.testing.assert_allclose(uo.cpu().numpy(), wu, rtol=1e-5, atol=1e-8)
@@ -555,3 +557,33 @@ def test_fused_mf_step_first_step_against_oracle():
     # the first Adam step moves an element by lr * g / (|g| + 1e-8): ill-conditioned where |g| ~ 1e-8, hence lr-scaled
     np.testing.assert_allclose(E2.cpu().numpy(), want_p, rtol=1e-5, atol=1e-3 * lr)
     assert torch.equal(E, t(E0))                                       # the input buffer is left alone
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_lightgcn_adam_in_spmm_epilogue_is_bit_identical(L, monkeypatch):
+    """crh_spmm_csr_adam_f32 (the optimiser in the last backward SpMM's epilogue, dOUT cleared there for L >= 2)
+    == separate gradient table + crh_adam_dense_f32 + dOUT.zero_(): same bits on E, M, V and the losses."""
+    from coldrec_amd.train import LGCNEngine
+    g5 = load_golden("g5_lgcn.npz")
+    rowptr, col, val = _graph()
+    rng = np.random.default_rng(L)
+    engines = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CRH_LGCN_FUSED", fused)
+        eng = LGCNEngine(g5["U0"], g5["V0"], rowptr, col, val, L, 1e-2, 1e-3, DEV)
+        assert eng.fuse_adam == (fused == "1")
+        engines.append(eng)
+    from coldrec_amd import ops
+    for step in range(5):
+        B = 700
+        u = t(rng.integers(0, engines[0].user_num, B).astype(np.int32))
+        i = t(rng.integers(0, engines[0].item_num, B).astype(np.int32))
+        j = t(rng.integers(0, engines[0].item_num, B).astype(np.int32))
+        plan = ops.build_plans_device(u, i, j, B)[0]
+        for eng in engines:
+            eng.step(u, i, j, plan)
+        a, b = engines
+        assert torch.equal(a.loss, b.loss)
+        assert torch.equal(a.E, b.E) and torch.equal(a.M, b.M) and torch.equal(a.V, b.V), (L, step)
+        if L >= 2:
+            assert a._dout_clean and not bool(a.dOUT.any())
