@@ -158,8 +158,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
         if (w >= n_work) return;
         if (seg && a.sched.seg_slot[w] >= 0) return;            // part of a heavy row: done below
         const int64_t row = seg ? a.sched.seg_row[w] : w;
-        const int64_t e0 = seg ? a.sched.seg_ptr[w] : a.rowptr[row];
-        const int64_t e1 = seg ? a.sched.seg_ptr[w + 1] : a.rowptr[row + 1];
+        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];   // a light work item is a whole row
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         row_edges<G>(a, e0, e1, c, on, lig, acc);
         if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);

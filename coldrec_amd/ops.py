@@ -3,6 +3,7 @@ come from PyTorch-ROCm; all arithmetic happens in libcoldrec_hip.so.  No CPU fal
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -432,33 +433,28 @@ def spmm_csr_adam(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: floa
 
 
 class SpmmSchedule:
-    """Load-balancing schedule of one CSR matrix (see crh_spmm_sched): rows cut into segments of at
-    most crh_spmm_segment_edges() edges, built once per graph on the host with numpy."""
+    """Load-balancing schedule of one CSR matrix (see crh_spmm_sched), built once per graph on the host with numpy.
+    Work items are ROWS, ordered by descending length: the lane groups of a wave (8 rows at d=128 with 4 column
+    slices) then walk rows of about the same length instead of waiting for the longest of a Zipf-shaped sample, and
+    the longest rows start first.  Rows with more than crh_spmm_segment_edges() edges are "heavy" (a workgroup
+    each); they sit at the end of the list with seg_slot >= 0 and the light path skips them.  Rows are independent,
+    so the order does not change any result."""
 
     def __init__(self, rowptr, device):
         rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
         rp = rp.astype(np.int64)
         seg = int(_lib.lib().crh_spmm_segment_edges())
         deg = np.diff(rp)
-        nseg_row = np.maximum(1, -(-deg // seg))
-        seg_row = np.repeat(np.arange(len(deg), dtype=np.int32), nseg_row)
-        first_seg = np.zeros(len(deg) + 1, np.int64)
-        np.cumsum(nseg_row, out=first_seg[1:])
-        k_in_row = np.arange(int(first_seg[-1]), dtype=np.int64) - first_seg[seg_row]
-        seg_lo = rp[seg_row] + k_in_row * seg
-        seg_hi = np.minimum(seg_lo + seg, rp[seg_row.astype(np.int64) + 1])
-        seg_ptr = np.concatenate([seg_lo, seg_hi[-1:]]) if len(seg_lo) else np.zeros(1, np.int64)
-        multi = nseg_row > 1
-        multi_row = np.nonzero(multi)[0].astype(np.int32)
-        multi_count = nseg_row[multi].astype(np.int32)
+        heavy = deg > seg
+        order = np.argsort(-deg, kind="stable") if os.environ.get("CRH_SPMM_SORT", "1") != "0" else np.arange(len(deg))
+        order = np.concatenate([order[~heavy[order]], order[heavy[order]]])
+        seg_row = order.astype(np.int32)
+        seg_slot = np.where(heavy[order], 0, -1).astype(np.int32)
+        seg_ptr = np.zeros(len(seg_row) + 1, np.int64)              # not read any more (kept for the ABI struct)
+        multi_row = np.nonzero(heavy)[0].astype(np.int32)
+        multi_count = (-(-deg[heavy] // seg)).astype(np.int32)
         multi_first = np.zeros(len(multi_row) + 1, np.int64)
         np.cumsum(multi_count, out=multi_first[1:])
-        seg_slot = np.full(len(seg_row), -1, np.int32)
-        is_multi_seg = multi[seg_row]
-        seg_slot[is_multi_seg] = np.arange(int(is_multi_seg.sum()), dtype=np.int32)
-        # segments of one row are consecutive and seg_ptr[s+1] == seg_ptr of the next segment, except at
-        # row ends where the next row starts exactly where this one stops (CSR) -> one shared array works
-        assert np.array_equal(seg_ptr[1:], seg_hi)
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.t = (to(seg_row), to(seg_ptr), to(seg_slot), to(multi_row), to(multi_first[:-1].astype(np.int32)),
                   to(multi_count))

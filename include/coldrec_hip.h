@@ -214,10 +214,12 @@ int crh_adam_rows_f32(float* p, float* g, float* m, float* v, int32_t* last_step
  * produce exactly this matrix, as COO); x, y, acc_* are (n_rows, d) fp32, d % 4 == 0.
  * acc_out may alias acc_in; outputs must not alias x.
  * sched (HOST struct of DEVICE pointers, or NULL): optional load-balancing schedule built once per
- * graph -- rows cut into segments of at most crh_spmm_segment_edges() edges:
- *     seg_row[s], seg_ptr[s..s+1] (edge range), seg_slot[s] (-1: the row is in one piece and is
- *     finished by a lane group, bit-identical to the edge-order fma chain; >= 0: the row is "heavy"),
- *     for n_seg segments; multi_row[m]: the n_multi heavy rows -- each is given to a whole workgroup whose
+ * graph -- a list of n_seg work items, each a ROW, in any order (the host mirror orders them by descending
+ * length so that the lane groups of a wave walk rows of similar length):
+ *     seg_row[w] = the row; seg_slot[w] = -1: finished by one lane group, bit-identical to the edge-order fma
+ *     chain; >= 0: the row is "heavy" (more than crh_spmm_segment_edges() edges) and skipped here;
+ *     seg_ptr: not read (kept for layout compatibility, must be non-NULL);
+ *     multi_row[m]: the n_multi heavy rows -- each is given to a whole workgroup whose
  *     lane groups split its edge list and combine their partial sums in a fixed order (deterministic; the
  *     association differs from the single chain); multi_first / multi_count / n_partial describe the
  *     segments of the heavy rows (informational); nnz = number of stored edges.

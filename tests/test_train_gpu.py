@@ -226,7 +226,8 @@ def test_spmm_bit_exact_vs_oracle(d):
 
 
 def test_spmm_segment_schedule_on_skewed_graph():
-    """Zipf catalogue: rows with thousands of edges are cut into 64-edge segments and combined."""
+    """Zipf catalogue: rows with thousands of edges are given to a workgroup each (lane groups split the list, partial
+    sums combined in a fixed order); the other rows are work items ordered by descending length."""
     from coldrec_amd import ops
     rng = np.random.default_rng(11)
     n_u, n_i, d = 3000, 500, 64
@@ -236,8 +237,12 @@ def test_spmm_segment_schedule_on_skewed_graph():
     rowptr, col, val = orc.norm_adj_csr(key // n_i, key % n_i, n_u, n_i)
     deg = np.diff(rowptr)
     sched = ops.SpmmSchedule(rowptr, DEV)
-    assert deg.max() > 1500 and sched.n_seg == np.maximum(1, -(-deg // 64)).sum()
-    assert sched.n_partial == np.where(deg > 64, -(-deg // 64), 0).sum()
+    assert deg.max() > 1500 and sched.n_seg == len(deg) and sched.n_partial == np.where(deg > 64, -(-deg // 64), 0).sum()
+    order, slot = sched.t[0].cpu().numpy(), sched.t[2].cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(len(deg)))                   # every row exactly once
+    n_light = int((deg <= 64).sum())
+    assert (slot[:n_light] == -1).all() and (slot[n_light:] >= 0).all() and (deg[order[n_light:]] > 64).all()
+    assert (np.diff(deg[order[:n_light]]) <= 0).all()                            # light rows by descending length
     X = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
     Z = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
     tX, tZ = t(X), t(Z)
