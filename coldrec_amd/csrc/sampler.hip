@@ -48,14 +48,24 @@ struct MT19937 {
         key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
         pos = 0;
     }
+    // outputs of the current key block, tempered all at once (the loop vectorises); next() is then one load
+    uint32_t out[624];
+    void temper_block() {
+        for (int q = 0; q < 624; ++q) {
+            uint32_t y = key[q];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            out[q] = y;
+        }
+    }
     inline uint32_t next() {
-        if (pos >= 624) gen();
-        uint32_t y = key[pos++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        if (pos >= 624) {
+            gen();
+            temper_block();
+        }
+        return out[pos++];
     }
     // uniform integer in [0, max] by masked rejection over 32-bit draws (numpy legacy, max < 2^32)
     inline uint32_t bounded(uint32_t max) {
@@ -132,7 +142,9 @@ struct crh_sampler {
     std::vector<int64_t> rowptr;          // per user: sorted training items (rejection test)
     std::vector<int32_t> items;
     int32_t n_users, n_items;
-    std::vector<int32_t> check, next_check;
+    std::vector<int32_t> check, next_check, redraw;
+    MT19937 snap_rng, snap_pyrng;         // crh_sampler_snapshot / _restore (speculative sampling of the next epoch)
+    std::vector<int32_t> snap_order;
     std::vector<uint64_t> bits;           // users x items membership bitmap when it is small enough to stay cached
     int64_t words_per_user = 0;
     // --- the other samplers (set by crh_sampler_set_catalogue) ---
@@ -236,6 +248,7 @@ extern "C" int crh_sampler_set_state(crh_sampler* s, const uint32_t* key624_host
     CRH_CHECK_ARG(s && key624_host && pos >= 0 && pos <= 624, "crh_sampler_set_state: bad arguments");
     memcpy(s->rng.key, key624_host, sizeof(s->rng.key));
     s->rng.pos = pos;
+    s->rng.temper_block();
     return CRH_OK;
 }
 
@@ -243,6 +256,24 @@ extern "C" int crh_sampler_get_state(const crh_sampler* s, uint32_t* key624_host
     CRH_CHECK_ARG(s && key624_host && pos_host, "crh_sampler_get_state: bad arguments");
     memcpy(key624_host, s->rng.key, sizeof(s->rng.key));
     *pos_host = s->rng.pos;
+    return CRH_OK;
+}
+
+// Snapshot / restore of everything an epoch call advances (both generators, the cumulative permutation): lets the
+// host sample the NEXT epoch speculatively on a worker thread and take it back if training stops first.
+extern "C" int crh_sampler_snapshot(crh_sampler* s) {
+    CRH_CHECK_ARG(s, "crh_sampler_snapshot: NULL sampler");
+    s->snap_rng = s->rng;
+    s->snap_pyrng = s->pyrng;
+    s->snap_order = s->order;
+    return CRH_OK;
+}
+
+extern "C" int crh_sampler_restore(crh_sampler* s) {
+    CRH_CHECK_ARG(s && s->snap_order.size() == s->order.size(), "crh_sampler_restore: no snapshot");
+    s->rng = s->snap_rng;
+    s->pyrng = s->snap_pyrng;
+    s->order = s->snap_order;
     return CRH_OK;
 }
 
@@ -255,12 +286,44 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     CRH_CHECK_ARG(batch_size > 0, "crh_sampler_epoch: batch_size=%lld", (long long)batch_size);
     const int64_t n = (int64_t)s->order.size();
     CRH_CHECK_ARG(n < ((int64_t)1 << 31), "crh_sampler_epoch: more than 2^31-1 records");
-    // np.random.shuffle(training_data): for i = n-1 .. 1: j = bounded(i); swap   (utils.py:125)
-    for (int64_t i = n - 1; i >= 1; --i) {
-        const int64_t j = (int64_t)s->rng.bounded((uint32_t)i);
-        std::swap(s->order[i], s->order[j]);
+    // np.random.shuffle(training_data): for i = n-1 .. 1: j = bounded(i); swap   (utils.py:125).
+    // Walked per RAW DRAW instead of per element: a rejected draw (v > i) swaps order[i] with itself and leaves i where
+    // it is, so the data-dependent branch of the rejection loop -- mispredicted on a quarter of the draws -- is gone.
+    {
+        int32_t* ord = s->order.data();
+        int64_t i = n - 1;
+        while (i >= 1) {
+            const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);
+            const int64_t stop = (int64_t)(mask >> 1);           // the mask holds while i > mask / 2
+            while (i > stop) {
+                const uint32_t v = s->rng.next() & mask;
+                const bool ok = v <= (uint32_t)i;
+                const int64_t j = ok ? (int64_t)v : i;
+                const int32_t a = ord[i], b = ord[j];
+                ord[i] = b;
+                ord[j] = a;
+                i -= ok;
+            }
+        }
     }
     const uint32_t imax = (uint32_t)(s->n_items - 1);
+    const uint32_t imask = imax ? 0xffffffffu >> __builtin_clz(imax) : 0u;
+    // masked-rejection draws of `cnt` item ids, again walked per raw draw: write, then advance only if accepted
+    auto draw_items = [&](int32_t* dst, int64_t cnt) {
+        if (imax == 0) {                                     // one item: numpy returns 0 without drawing
+            for (int64_t q = 0; q < cnt; ++q) dst[q] = 0;
+            return;
+        }
+        int64_t w = 0;
+        while (w < cnt) {
+            const uint32_t v = s->rng.next() & imask;
+            dst[w] = (int32_t)v;
+            w += v <= imax;
+        }
+    };
+    s->check.resize((size_t)std::min(batch_size, n) + 1);
+    s->next_check.resize(s->check.size());
+    s->redraw.resize(s->check.size());
     for (int64_t lo = 0; lo < n; lo += batch_size) {
         const int64_t hi = std::min(lo + batch_size, n);
         for (int64_t t = lo; t < hi; ++t) {
@@ -269,16 +332,26 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
             pos_out_host[t] = s->rec_i[r];
         }
         // first round over the whole batch without materialising the slot list (utils.py:141-153)
-        for (int64_t t = lo; t < hi; ++t) neg_out_host[t] = (int32_t)s->rng.bounded(imax);
-        s->check.clear();
-        for (int64_t t = lo; t < hi; ++t)
-            if (s->rated(user_out_host[t], neg_out_host[t])) s->check.push_back((int32_t)t);
-        while (!s->check.empty()) {                      // redraw only the rejected slots, in slot order
-            for (int32_t t : s->check) neg_out_host[t] = (int32_t)s->rng.bounded(imax);
-            s->next_check.clear();
-            for (int32_t t : s->check)
-                if (s->rated(user_out_host[t], neg_out_host[t])) s->next_check.push_back(t);
+        draw_items(neg_out_host + lo, hi - lo);
+        int32_t* chk = s->check.data();
+        int64_t nc = 0;
+        for (int64_t t = lo; t < hi; ++t) {                  // compaction without a branch on the outcome
+            chk[nc] = (int32_t)t;
+            nc += s->rated(user_out_host[t], neg_out_host[t]);
+        }
+        while (nc > 0) {                                     // redraw only the rejected slots, in slot order
+            draw_items(s->redraw.data(), nc);
+            int32_t* nxt = s->next_check.data();
+            int64_t nn = 0;
+            for (int64_t q = 0; q < nc; ++q) {
+                const int32_t t = chk[q];
+                neg_out_host[t] = s->redraw[q];
+                nxt[nn] = t;
+                nn += s->rated(user_out_host[t], neg_out_host[t]);
+            }
             s->check.swap(s->next_check);
+            chk = s->check.data();
+            nc = nn;
         }
     }
     return CRH_OK;
@@ -347,6 +420,7 @@ extern "C" int crh_sampler_set_py_state(crh_sampler* s, const uint32_t* key624_h
     CRH_CHECK_ARG(s && key624_host && pos >= 0 && pos <= 624, "crh_sampler_set_py_state: bad arguments");
     memcpy(s->pyrng.key, key624_host, sizeof(s->pyrng.key));
     s->pyrng.pos = pos;
+    s->pyrng.temper_block();
     return CRH_OK;
 }
 

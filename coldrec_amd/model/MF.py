@@ -11,8 +11,8 @@ import os
 import torch
 import torch.nn as nn
 
+from ..sampler import EpochPrefetcher
 from ..train import EpochRunner, MFEngine, dp_from_env
-from ..util.utils import epoch_triples
 from .BaseRecommender import BaseColdStartTrainer
 
 
@@ -60,16 +60,23 @@ class MF(BaseColdStartTrainer):
                 eng.enable_lazy_adam()
         # collectives are kept out of graph capture: the data-parallel epoch is launched eagerly
         runner = EpochRunner(eng, len(self.data.train_u), self.batch_size, use_graph=dp is None)
-        for epoch in range(self.maxEpoch):
-            # one host call samples the epoch, one hipGraph replay trains it; losses come back in bulk
-            losses = runner.run(*epoch_triples(self.data, self.batch_size)).sum(dim=1).cpu().numpy()
-            for n in range(0, len(losses), 50):
-                print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(losses[n]))
-            self.user_emb, self.item_emb = eng.forward()
-            if epoch % self.eval_every == 0:
-                self.fast_evaluation(epoch, valid_type='all')
-                if self.early_stop_flag and self.early_stop_patience <= 0:
-                    break
+        # the host samples epoch e+1 (same NumPy stream, see EpochPrefetcher) while the GPU trains and ranks epoch e
+        triples = EpochPrefetcher(self.data.sampler, self.batch_size)
+        try:
+            for epoch in range(self.maxEpoch):
+                # one host call samples the epoch, one hipGraph replay trains it; losses come back in bulk
+                if epoch == self.maxEpoch - 1:
+                    triples.enabled = False            # nothing follows the last epoch
+                losses = runner.run(*triples.get()).sum(dim=1).cpu().numpy()
+                for n in range(0, len(losses), 50):
+                    print('training:', epoch + 1, 'batch', n, 'batch_loss:', float(losses[n]))
+                self.user_emb, self.item_emb = eng.forward()
+                if epoch % self.eval_every == 0:
+                    self.fast_evaluation(epoch, valid_type='all')
+                    if self.early_stop_flag and self.early_stop_patience <= 0:
+                        break
+        finally:
+            triples.close()
         self.epochs_ran = (epoch + 1) if self.maxEpoch > 0 else 0
         self.timer(start=False)
         self.user_emb, self.item_emb = self.best_user_emb, self.best_item_emb

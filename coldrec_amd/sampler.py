@@ -8,7 +8,9 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 import random
+import threading
 
 import numpy as np
 
@@ -149,3 +151,77 @@ class PairwiseSampler:
         self._check_value(self._L.crh_sampler_epoch_cgrc(self._h, bs, R, u.ctypes.data, i.ctypes.data, ptr.ctypes.data,
                                                          bset.ctypes.data, cap), "crh_sampler_epoch_cgrc")
         return u, i, ptr, bset[:ptr[-1]]
+
+
+class EpochPrefetcher:
+    """Samples the NEXT epoch of ``next_batch_pairwise`` triples on a worker thread while the GPU trains and
+    evaluates the current one (the C++ sampler runs outside the GIL), without changing the stream: the reference
+    draws epoch e+1 from NumPy's global generator right after epoch e, and nothing in the BPR-MF / LightGCN trainers
+    touches that generator in between.  Guarded: ``get()`` publishes the advanced generator state on the calling
+    thread (as if the epoch had been sampled there and then); if somebody did use ``np.random`` since the last
+    ``get()``, the speculative epoch is discarded and redrawn from the current state; ``close()`` takes an unused
+    speculative epoch back (sampler snapshot), so early stopping leaves generator and permutation where the
+    reference leaves them.  ``CRH_SAMPLER_PREFETCH=0`` samples on the calling thread."""
+
+    def __init__(self, sampler: PairwiseSampler, batch_size: int, enabled=None):
+        self.s, self.B = sampler, int(batch_size)
+        self.enabled = (os.environ.get("CRH_SAMPLER_PREFETCH", "1") != "0") if enabled is None else bool(enabled)
+        self._thread = self._result = self._base = None
+
+    @staticmethod
+    def _np_state():
+        st = np.random.get_state()
+        return st[1].copy(), int(st[2])
+
+    def _start(self) -> None:
+        """Begin sampling one epoch from NumPy's CURRENT state (which is left untouched until get())."""
+        self._base = self._np_state()
+        _lib.check(self.s._L.crh_sampler_snapshot(self.s._h), "crh_sampler_snapshot")
+        self.s.pull_numpy_state()
+
+        def work():
+            out = self.s.epoch(self.B)
+            key = np.empty(624, dtype=np.uint32)
+            pos = ctypes.c_int(0)
+            _lib.check(self.s._L.crh_sampler_get_state(self.s._h, key.ctypes.data, ctypes.addressof(pos)),
+                       "crh_sampler_get_state")
+            self._result = (out, key, int(pos.value))
+
+        if self.enabled:
+            self._thread = threading.Thread(target=work, daemon=True)
+            self._thread.start()
+        else:
+            self._thread = None
+            work()
+
+    def _finish(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        res, self._result = self._result, None
+        return res
+
+    def get(self):
+        """The next epoch's (u, i, j); NumPy's global generator advances exactly as ``epoch_triples`` would."""
+        if self._base is not None:
+            key, pos = self._np_state()
+            if pos != self._base[1] or not np.array_equal(key, self._base[0]):     # np.random was used meanwhile
+                self._finish()
+                _lib.check(self.s._L.crh_sampler_restore(self.s._h), "crh_sampler_restore")
+                self._base = None
+        if self._base is None:
+            self._start()
+        out, key, pos = self._finish()
+        st = np.random.get_state()
+        np.random.set_state((st[0], key, pos, st[3], st[4]))
+        self._base = None
+        if self.enabled:
+            self._start()                      # speculate on the following epoch
+        return out
+
+    def close(self) -> None:
+        """Take back a speculative epoch nobody asked for."""
+        if self._base is not None:
+            self._finish()
+            _lib.check(self.s._L.crh_sampler_restore(self.s._h), "crh_sampler_restore")
+            self._base = None

@@ -314,6 +314,9 @@ int crh_sampler_seed(crh_sampler* s, uint32_t seed);
 int crh_sampler_set_state(crh_sampler* s, const uint32_t* key624_host, int pos);
 int crh_sampler_get_state(const crh_sampler* s, uint32_t* key624_host, int* pos_host);
 int64_t crh_sampler_num_records(const crh_sampler* s);
+/* save / bring back everything an epoch call advances (generators + cumulative permutation): speculative sampling */
+int crh_sampler_snapshot(crh_sampler* s);
+int crh_sampler_restore(crh_sampler* s);
 int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host,
                       int32_t* pos_out_host, int32_t* neg_out_host);
 

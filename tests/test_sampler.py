@@ -277,3 +277,53 @@ def test_item_set_order_is_cpythons():
         s.pull_numpy_state()
         u, i, ptr, bset = s.epoch_cgrc(n_rec, 0)          # no negatives: B = set(positives)
         assert bset.tolist() == list(set(i.tolist()))
+
+
+def test_epoch_prefetcher_keeps_the_stream_and_takes_back_unused_epochs():
+    """Sampling the next epoch on a worker thread must be invisible: same triples, same NumPy generator state at
+    every point the main thread can observe, also after an early stop and when somebody else draws from np.random."""
+    from coldrec_amd.sampler import EpochPrefetcher
+    g, ru, ri = _toy()
+    n_u, n_i, B = int(g["user_num"]), len(g["item_keys"]), 512
+
+    def sequential(n_epochs, disturb_after=None):
+        s = PairwiseSampler(ru, ri, n_u, n_i)
+        np.random.seed(5)
+        out = []
+        for e in range(n_epochs):
+            s.pull_numpy_state()
+            out.append(s.epoch(B))
+            s.push_numpy_state()
+            if disturb_after == e:
+                np.random.rand(3)
+        return out, np.random.randint(0, 1 << 30, 4)
+
+    for threaded in (True, False):
+        want, tail = sequential(4)
+        s = PairwiseSampler(ru, ri, n_u, n_i)
+        np.random.seed(5)
+        pf = EpochPrefetcher(s, B, enabled=threaded)
+        got = [pf.get(), pf.get()]
+        pf.close()                                               # "early stop": the speculative third epoch goes back
+        probe = np.random.get_state()
+        pf2 = EpochPrefetcher(s, B, enabled=threaded)
+        got += [pf2.get(), pf2.get()]
+        pf2.close()
+        for a, b in zip(got, want):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        assert np.array_equal(np.random.randint(0, 1 << 30, 4), tail)
+        _, tail2 = sequential(2)
+        np.random.set_state(probe)
+        assert np.array_equal(np.random.randint(0, 1 << 30, 4), tail2)   # state after close() == after 2 epochs
+        # somebody draws from np.random between two epochs: the speculative epoch is dropped and redrawn
+        want, tail = sequential(3, disturb_after=0)
+        s = PairwiseSampler(ru, ri, n_u, n_i)
+        np.random.seed(5)
+        pf = EpochPrefetcher(s, B, enabled=threaded)
+        got = [pf.get()]
+        np.random.rand(3)
+        got += [pf.get(), pf.get()]
+        pf.close()
+        for a, b in zip(got, want):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        assert np.array_equal(np.random.randint(0, 1 << 30, 4), tail)
