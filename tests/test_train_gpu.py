@@ -485,15 +485,16 @@ def test_lazy_adam_replay_is_bitwise_dense_adam(d, B):
     assert torch.equal(dense.E.view(torch.int32), lazy.E.view(torch.int32))
 
 
-@pytest.mark.parametrize("d,n_rec,B", [(128, 3 * 512 + 77, 512), (64, 4 * 300, 300), (200, 700, 256), (8, 5000, 4096)])
-def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B):
+@pytest.mark.parametrize("d,n_rec,B,n_u,n_i", [(128, 3 * 512 + 77, 512, 300, 500), (64, 4 * 300, 300, 300, 500),
+                                               (200, 700, 256, 300, 500), (8, 5000, 4096, 300, 500),
+                                               (128, 2 * 2048 + 9, 2048, 12000, 9000)])   # rows > 2048 blocks x 8: stride loop
+def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B, n_u, n_i):
     """crh_mf_step_f32 (one launch per step: recomputed score differences, Adam in registers, norms of the next
     batch from the updated rows) against forward + plan backward + dense Adam: same losses and tables up to the
     fp32 summation order of the three norms; bit-reproducible; hot items exercise the heavy-row blocks; odd and
     even step counts exercise the ping-pong copy-back; the last batch is short."""
     from coldrec_amd.train import EpochRunner, MFEngine
     rng = np.random.default_rng(d + B)
-    n_u, n_i = 300, 500
     U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
     V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
     epochs = []
