@@ -29,7 +29,10 @@ constexpr int BPR_THREADS = 256;
 constexpr int BPR_MAX_BLOCKS = 1024;
 // entries of one gradient row above which a whole block sums it: a lane group walks a row's list sequentially (one
 // round trip per 4 entries), so the longest "light" row sets the kernel's critical path -- 8 keeps it at two trips
-constexpr int BPR_HEAVY = 8;
+#ifndef BPR_HEAVY_N
+#define BPR_HEAVY_N 8
+#endif
+constexpr int BPR_HEAVY = BPR_HEAVY_N;
 
 struct BprArgs {
     const float* tu;   // user-side table      (rows x d)
@@ -476,6 +479,91 @@ __device__ inline int plan_emit(const unsigned long long* keys, int P, int32_t* 
     return nseg;
 }
 
+// Heavy rows of one plan, ascending (a fixed order: the one-launch MF step sums per-block partials, and which block
+// takes which heavy row follows the list): count per thread chunk, serial scan of the counts, ordered write.
+// Also writes the plan header.  scan: PLAN_THREADS ints of LDS.
+__device__ inline void plan_emit_heavy(int32_t* pl, int64_t L, int nu, int ni, const int32_t* uptr, const int32_t* iptr,
+                                       int* scan) {
+    int32_t* hv = pl + plan_heavy_off(L);
+    const int rchunk = (nu + ni + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int r0 = threadIdx.x * rchunk, r1 = min(r0 + rchunk, nu + ni);
+    int nh = 0;
+    for (int r = r0; r < r1; ++r)
+        nh += (r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY;
+    __syncthreads();
+    scan[threadIdx.x] = nh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < PLAN_THREADS; ++i) {
+            const int c = scan[i];
+            scan[i] = acc;
+            acc += c;
+        }
+        pl[0] = nu;
+        pl[1] = ni;
+        pl[2] = (int32_t)L;
+        hv[0] = acc;
+    }
+    __syncthreads();
+    int w = scan[threadIdx.x];
+    for (int r = r0; r < r1; ++r)
+        if ((r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY) hv[1 + w++] = r;
+}
+
+// Heavy lists for plans whose row lists were built elsewhere (ops._build_plans_torch, batches beyond the LDS sort:
+// up to 3 x 65536 rows per plan).  Two passes over HV_BLOCKS chunks per plan: count, then ordered write.
+constexpr int HV_BLOCKS = 64, HV_THREADS = 256;
+
+__device__ __forceinline__ int plan_row_heavy(const int32_t* uptr, const int32_t* iptr, int nu, int r) {
+    return (r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY;
+}
+
+__global__ __launch_bounds__(HV_THREADS) void plan_heavy_pass_kernel(int32_t* plans, int64_t stride, int32_t* counts,
+                                                                      int write) {
+    __shared__ int scan[HV_THREADS];
+    __shared__ int base_s;
+    int32_t* pl = plans + (int64_t)blockIdx.y * stride;
+    const int64_t L = pl[2];
+    const int nu = pl[0], ni = pl[1], n = nu + ni;
+    const int32_t* uptr = pl + 3 + L;
+    const int32_t* iptr = pl + 3 + (3 * L + 1) + 2 * L;
+    const int per_block = (n + HV_BLOCKS - 1) / HV_BLOCKS;
+    const int b0 = blockIdx.x * per_block, b1 = min(b0 + per_block, n);
+    const int rc = (max(b1 - b0, 0) + HV_THREADS - 1) / HV_THREADS;
+    const int t0 = b0 + threadIdx.x * rc, t1 = min(t0 + rc, b1);
+    int nh = 0;
+    for (int r = t0; r < t1; ++r) nh += plan_row_heavy(uptr, iptr, nu, r);
+    scan[threadIdx.x] = nh;
+    __syncthreads();
+    int32_t* cnt = counts + (int64_t)blockIdx.y * HV_BLOCKS;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < HV_THREADS; ++i) {
+            const int c = scan[i];
+            scan[i] = acc;
+            acc += c;
+        }
+        if (!write) {
+            cnt[blockIdx.x] = acc;
+        } else {
+            int base = 0, total = 0;
+            for (int i = 0; i < HV_BLOCKS; ++i) {
+                if (i < (int)blockIdx.x) base += cnt[i];
+                total += cnt[i];
+            }
+            base_s = base;
+            if (blockIdx.x == 0) pl[plan_heavy_off(L)] = total;
+        }
+    }
+    if (!write) return;
+    __syncthreads();
+    int32_t* hv = pl + plan_heavy_off(L) + 1;
+    int w = base_s + scan[threadIdx.x];
+    for (int r = t0; r < t1; ++r)
+        if (plan_row_heavy(uptr, iptr, nu, r)) hv[w++] = r;
+}
+
 __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* __restrict__ iu,
                                                                 const int32_t* __restrict__ ip,
                                                                 const int32_t* __restrict__ in_, int64_t n_rec,
@@ -509,33 +597,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
     __syncthreads();
     bitonic_sort_lds(keys, P);
     const int ni = plan_emit(keys, P, irow, iptr, ilist, scan);
-    // heavy rows, ascending (a fixed order: the one-launch MF step sums per-block partials, and which block takes
-    // which heavy row follows the list): count per thread chunk, serial scan of the 256 counts, ordered write
-    int32_t* hv = pl + plan_heavy_off(L);
-    const int rchunk = (nu + ni + PLAN_THREADS - 1) / PLAN_THREADS;
-    const int r0 = threadIdx.x * rchunk, r1 = min(r0 + rchunk, nu + ni);
-    int nh = 0;
-    for (int r = r0; r < r1; ++r)
-        nh += (r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY;
-    __syncthreads();
-    scan[threadIdx.x] = nh;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int i = 0; i < PLAN_THREADS; ++i) {
-            const int c = scan[i];
-            scan[i] = acc;
-            acc += c;
-        }
-        pl[0] = nu;
-        pl[1] = ni;
-        pl[2] = L;
-        hv[0] = acc;
-    }
-    __syncthreads();
-    int w = scan[threadIdx.x];
-    for (int r = r0; r < r1; ++r)
-        if ((r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY) hv[1 + w++] = r;
+    plan_emit_heavy(pl, L, nu, ni, uptr, iptr, scan);
 }
 
 // ---------------------------------------------------------------- dense Adam (+ zero the gradient)
@@ -1015,6 +1077,28 @@ __global__ void mf_finish_kernel(const float* part_in, int n_in, float inv_b, fl
 
 extern "C" int64_t crh_bpr_plan_ints(int64_t batch) { return batch > 0 ? plan_ints(batch) : 0; }
 extern "C" int crh_bpr_heavy_threshold(void) { return BPR_HEAVY; }
+
+// (Re)build the heavy-row lists of n_batches plans whose header and row lists are in place.
+extern "C" size_t crh_bpr_plan_heavy_workspace_bytes(int64_t n_batches) {
+    return n_batches > 0 ? (size_t)n_batches * HV_BLOCKS * sizeof(int32_t) : 0;
+}
+
+extern "C" int crh_bpr_plan_heavy_lists(int32_t* plans, int64_t n_batches, int64_t layout_batch, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    CRH_CHECK_ARG(plans && n_batches > 0 && n_batches <= 65535 && layout_batch > 0, "crh_bpr_plan_heavy_lists: bad arguments");
+    if (!workspace || workspace_bytes < crh_bpr_plan_heavy_workspace_bytes(n_batches)) {
+        crh_set_error("crh_bpr_plan_heavy_lists: workspace %zu < %zu bytes", workspace_bytes,
+                      crh_bpr_plan_heavy_workspace_bytes(n_batches));
+        return CRH_ERR_WS;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(plan_heavy_pass_kernel, dim3(HV_BLOCKS, (unsigned)n_batches), dim3(HV_THREADS), 0, st, plans,
+                           plan_ints(layout_batch), reinterpret_cast<int32_t*>(workspace), pass);
+        CRH_HIP(hipGetLastError());
+    }
+    return CRH_OK;
+}
 
 // HOST function: reverse index of one batch of triples (see bpr_bwd_rows_kernel).  Item-side
 // gradients of positives and negatives land in the SAME table (grad_pos == grad_neg).

@@ -356,22 +356,11 @@ def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Ten
     nu = side([user_idx], [bl], L, 3)
     ni = side([pos_idx, neg_idx], [bl, bl + (1 << 30)], 2 * L, 3 + 3 * L + 1)
     plans[:, 0], plans[:, 1] = nu, ni
-    # heavy rows (more than HEAVY entries): [count, slots...] behind the item lists; slot = position in (users, items)
-    HEAVY = int(_lib.lib().crh_bpr_heavy_threshold())
-    hoff = 3 + (3 * L + 1) + (6 * L + 1)
-    uptr = plans[:, 3 + L: 3 + 2 * L + 1].to(torch.int64)
-    off_i = 3 + 3 * L + 1
-    iptr = plans[:, off_i + 2 * L: off_i + 4 * L + 1].to(torch.int64)
-    ar_u = torch.arange(L, device=dev)[None, :]
-    ar_i = torch.arange(2 * L, device=dev)[None, :]
-    hu = ((uptr[:, 1:] - uptr[:, :-1]) > HEAVY) & (ar_u < nu[:, None])
-    hi = ((iptr[:, 1:] - iptr[:, :-1]) > HEAVY) & (ar_i < ni[:, None])
-    mask = torch.cat([hu, hi], dim=1)
-    slots = torch.cat([ar_u.expand(nb, -1), nu[:, None].to(torch.int64) + ar_i.expand(nb, -1)], dim=1)
-    pos = torch.cumsum(mask, dim=1) - 1
-    t_idx, c_idx = torch.nonzero(mask, as_tuple=True)
-    plans[t_idx, hoff + 1 + pos[t_idx, c_idx]] = slots[t_idx, c_idx].to(torch.int32)
-    plans[:, hoff] = mask.sum(1).to(torch.int32)
+    # heavy rows (more than crh_bpr_heavy_threshold() entries): [count, slots ascending...] behind the item lists,
+    # one small launch over the finished row lists (a torch formulation costs ~20 launches per call)
+    ws = torch.empty(int(_lib.lib().crh_bpr_plan_heavy_workspace_bytes(nb)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().crh_bpr_plan_heavy_lists(_lib.ptr(plans), nb, L, _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream()), "crh_bpr_plan_heavy_lists")
     return plans
 
 

@@ -139,6 +139,11 @@ int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, in
 size_t crh_bpr_workspace_bytes(int64_t batch);
 int64_t crh_bpr_plan_ints(int64_t batch);
 int crh_bpr_heavy_threshold(void);   /* a row with more entries than this is on the plan's heavy list */
+/* (re)build the heavy-row lists of n_batches device plans whose header and row lists are in place (plans built
+ * outside crh_bpr_plan_build, e.g. batches beyond its LDS sort) */
+size_t crh_bpr_plan_heavy_workspace_bytes(int64_t n_batches);
+int crh_bpr_plan_heavy_lists(int32_t* plans, int64_t n_batches, int64_t layout_batch, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx_host,
                             const int32_t* neg_idx_host, int64_t batch, int64_t layout_batch,
                             int32_t* plan_out_host);   /* crh_bpr_plan_ints(layout_batch) ints */
