@@ -122,7 +122,7 @@ def measured_traffic(kernel_prefix, grid_threads):
         except (OSError, ValueError):
             continue
         for name, v in rec.items():
-            if kernel_prefix in name and v.get("_Grid_Size") == grid_threads and "hbm_read_bytes_corrected" in v:
+            if kernel_prefix in name and grid_threads in (None, v.get("_Grid_Size")) and "hbm_read_bytes_corrected" in v:
                 best = (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0), os.path.basename(f))
     return best
 
@@ -172,6 +172,7 @@ def train_legs(dev, with_cpu):
         tu, ti, tj = (torch.from_numpy(x).to(dev) for x in (u, i, j))
         steps = [(lo, min(lo + B, n)) for lo in range(0, n, B)]
         from coldrec_amd.train import EpochRunner
+        from coldrec_amd.ops import mf_step_parts as ops_parts
         runner = EpochRunner(eng, n, B)
         runner.run(tu, ti, tj)            # eager warm-up epoch
         runner.run(tu, ti, tj)            # captured into a hipGraph
@@ -198,6 +199,18 @@ def train_legs(dev, with_cpu):
                "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                             "traffic": None, "note": "whole step (all kernels of one optimiser step)"}}
+        # fabric-side bytes per launch of the step's dominant kernel from the committed PMC record (same kernel, same grid)
+        if layers:
+            tr = measured_traffic("spmm_csr_kernel<8>", None)
+            if tr:
+                leg["roofline"].update({"traffic": tr[0], "traffic_note": "spmm_csr_kernel<8> (FETCH_SIZE x2 + WRITE_SIZE) per "
+                                        "launch from %s; a step has %d such launches" % (tr[1], 2 * layers)})
+        elif getattr(eng, "fused", False):
+            tr = measured_traffic("mf_step_kernel<32>", float(ops_parts(n_u + n_i, d) * 256))
+            if tr:
+                leg["roofline"].update({"traffic": tr[0], "traffic_note": "mf_step_kernel<32> = the whole step (FETCH_SIZE x2 + "
+                                        "WRITE_SIZE) from %s; it moves 24 B per element of optimiser state, not the 32 of "
+                                        "the formula (no gradient table)" % tr[1]})
         if with_cpu:
             from oracle import ref_port
 
