@@ -27,7 +27,7 @@ import torch
 from .. import ops
 from ..eval import ShardedTopK, shard_bounds
 from ..train import dp_from_env
-from ..util.evaluator import format_measure, ranking_metrics, truth_csr
+from ..util.evaluator import format_measure, ranking_metrics, truth_csr, truth_dense
 
 _STOCK_PREDICT = re.compile(
     r"score=torch\.matmul\(self\.user_emb\[users\],self\.item_emb\.transpose\(0,1\)\)returnscore$")
@@ -125,6 +125,7 @@ class BaseColdStartTrainer(ABC):
             'rated_col': torch.from_numpy(np.ascontiguousarray(col)).to(dev) if rowptr[-1] else None,
             'bitmap': ops.make_bitmap(d.item_num, masked, dev),
             'gt_rowptr': gt_rowptr, 'gt_items': gt_items,
+            'gt_dense': truth_dense(gt_rowptr, gt_items, len(d.item)),
         }
         self._eval_cache[key] = hit
         return hit
@@ -177,7 +178,7 @@ class BaseColdStartTrainer(ABC):
 
     def _metrics(self, data_set: Dict, data_type: str, topn):
         c, _s, i = self._topk_arrays(data_set, data_type)
-        return ranking_metrics(c['gt_rowptr'], c['gt_items'], i, topn)
+        return ranking_metrics(c['gt_rowptr'], c['gt_items'], i, topn, dense=c['gt_dense'])
 
     def full_evaluation(self, rec_list=None, test_type: str = 'warm') -> None:
         """Prints and stores the test metrics.  ``rec_list`` (the dict ``test()`` returns) is accepted

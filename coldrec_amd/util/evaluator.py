@@ -28,9 +28,25 @@ def truth_csr(origin: Dict, item_of=None) -> Tuple[List, np.ndarray, np.ndarray]
     return users, rowptr, items
 
 
-def hit_matrix(gt_rowptr: np.ndarray, gt_items: np.ndarray, pred: np.ndarray) -> np.ndarray:
+def truth_dense(gt_rowptr: np.ndarray, gt_items: np.ndarray, n_items: int, max_cells: int = 1 << 26):
+    """bool (users, n_items) membership table of a ground truth, or None when it would exceed ``max_cells``:
+    the per-epoch validation then tests its (users, k) predictions with one gather instead of a sort."""
+    n_user = len(gt_rowptr) - 1
+    if n_user * max(int(n_items), 1) > max_cells or (len(gt_items) and int(gt_items.max()) >= n_items):
+        return None
+    dense = np.zeros((n_user, int(n_items)), dtype=bool)
+    rows = np.repeat(np.arange(n_user, dtype=np.int64), np.diff(gt_rowptr))
+    dense[rows, np.asarray(gt_items, np.int64)] = True
+    return dense
+
+
+def hit_matrix(gt_rowptr: np.ndarray, gt_items: np.ndarray, pred: np.ndarray, dense=None) -> np.ndarray:
     """bool (users, k): pred[r, q] is in the ground truth of row r."""
     n_user, k = pred.shape
+    if dense is not None:
+        p = np.asarray(pred, np.int64)
+        ok = (p >= 0) & (p < dense.shape[1])
+        return dense[np.arange(n_user)[:, None], np.where(ok, p, 0)] & ok
     base = int(max(gt_items.max(initial=0), pred.max(initial=0))) + 1
     rows = np.repeat(np.arange(n_user, dtype=np.int64), np.diff(gt_rowptr))
     gt_keys = rows * base + gt_items.astype(np.int64)
@@ -38,12 +54,13 @@ def hit_matrix(gt_rowptr: np.ndarray, gt_items: np.ndarray, pred: np.ndarray) ->
     return np.isin(pr_keys, gt_keys)
 
 
-def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int]) -> List[List[float]]:
-    """[[hit ratio, precision, recall, ndcg] for n in topn]; pred is (users, >= max(topn))."""
+def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None) -> List[List[float]]:
+    """[[hit ratio, precision, recall, ndcg] for n in topn]; pred is (users, >= max(topn)); ``dense``: optional
+    ``truth_dense`` table of the same ground truth."""
     gt_rowptr = np.asarray(gt_rowptr, np.int64)
     n_user = gt_rowptr.shape[0] - 1
     tlen = np.diff(gt_rowptr)
-    hit = hit_matrix(gt_rowptr, np.asarray(gt_items), np.asarray(pred))
+    hit = hit_matrix(gt_rowptr, np.asarray(gt_items), np.asarray(pred), dense)
     out = []
     for n in topn:
         h = hit[:, :n]

@@ -205,3 +205,22 @@ def test_sharded_eval_plumbing_world2_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "SHARDED_OK 2" in out.stdout
+
+
+def test_dense_truth_lookup_equals_sorted_membership():
+    """ranking_metrics with the cached (users, items) truth table == the sort-based membership test, including
+    predictions outside the item table (padding ids) and users without ground truth."""
+    from coldrec_amd.util.evaluator import hit_matrix, ranking_metrics, truth_dense
+    rng = np.random.default_rng(3)
+    n_u, n_i, k = 400, 250, 20
+    lens = rng.integers(0, 12, n_u)
+    lens[:5] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    gt = np.concatenate([rng.choice(n_i, l, replace=False) for l in lens])
+    pred = np.stack([rng.choice(n_i + 10, k, replace=False) for _ in range(n_u)])
+    pred[7, :4] = np.iinfo(np.int32).max                      # short lists are padded with INT32_MAX
+    dense = truth_dense(rp, gt, n_i)
+    assert dense is not None and dense.sum() == len(gt)
+    assert np.array_equal(hit_matrix(rp, gt, pred), hit_matrix(rp, gt, pred, dense))
+    assert ranking_metrics(rp, gt, pred, [10, 20]) == ranking_metrics(rp, gt, pred, [10, 20], dense=dense)
+    assert truth_dense(rp, gt, n_i, max_cells=1000) is None    # too large: callers fall back to the sort
