@@ -380,6 +380,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dp-leg-timeout", type=int, default=240, help="N > 1: seconds the data-parallel training leg may take")
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--users", type=int, default=1_000_000, help="rows of the user table")
     ap.add_argument("--users-per-step", type=int, default=131072,
@@ -552,15 +553,35 @@ def main():
             "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
                       "%d threads, 4 reps (~12 s of CPU work)" % (nu, ni, torch.__version__, os.cpu_count())}
     if world > 1 and not args.no_train and args.dtype == "f32":
+        # Secondary leg.  The headline line must survive it: an exception is caught below, and if a rank gets stuck
+        # in a collective (the others would wait for ever) a watchdog on every rank ends the process after the
+        # deadline -- rank 0 prints the line it has first.
+        import threading
+        done = threading.Lock()
+
+        def bail():
+            if not done.acquire(blocking=False):
+                return
+            if rank == 0:
+                result["train_mf_dp"] = {"error": "no result within %d s (watchdog)" % args.dp_leg_timeout}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.dp_leg_timeout, bail)
+        dog.daemon = True
+        dog.start()
         try:                                   # every rank takes part; rank 0 reports
             del V, U, engine
             torch.cuda.empty_cache()
             leg = train_dp_leg(dev, world, rank)
             if rank == 0:
                 result["train_mf_dp"] = leg
-        except Exception as e:                 # the headline line must survive a failure of the secondary leg
+        except Exception as e:
             if rank == 0:
                 result["train_mf_dp"] = {"error": repr(e)[:300]}
+        if not done.acquire(blocking=False):   # the watchdog fired while the leg was finishing: it reports and exits
+            time.sleep(3600)
+        dog.cancel()
     if rank == 0 and world == 1 and not args.no_train and args.dtype == "f32":
         del V, U, engine
         torch.cuda.empty_cache()
