@@ -62,6 +62,9 @@ struct ScoreArgs {
     unsigned* xcd_sync;     // [8 XCD][1 + n_windows] zeroed counters, or NULL: keeps the waves of an XCD within
     int sync_window;        // two windows of `sync_window` tiles of each other (see xcd_window_sync)
     int64_t sync_stride;    // counters per XCD
+    float* dense;           // small catalogues: write the score tiles here (slot-major, `dense_stride` floats per
+    int64_t dense_stride;   // user, a multiple of 32) instead of selecting; crh_mask_topk_f32 ranks the block
+    int64_t user_base;      // first table row of the block when `users` is NULL
 };
 
 // in : lane (i,0) holds k = 8q+0..3 of row i, lane (i,1) holds k = 8q+4..7
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     for (int u = 0; u < UW; ++u) {
         int64_t slot = ug * UPW + 32 * u + i;
         if (slot >= a.n_users) slot = a.n_users - 1;
-        const int64_t row = a.users ? (int64_t)a.users[slot] : slot;
+        const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
         const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
@@ -381,6 +384,22 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             }
             return;
         }
+        if (a.dense) {
+            // small catalogue: the tile goes to memory as it is.  acc[r] = item row (r&3) + 8*(r>>2) + 4h of user
+            // column i: four 16-B pieces per lane, columns 8g + 4h .. +3 of the tile
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const int64_t slot = ug * UPW + 32 * u + i;
+                if (slot < a.n_users) {
+                    float* row = a.dense + slot * a.dense_stride + (t << 5) + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(row + 8 * g) =
+                            f32x4{acc[u][4 * g], acc[u][4 * g + 1], acc[u][4 * g + 2], acc[u][4 * g + 3]};
+                }
+            }
+            return;
+        }
         // selection: one compare per lane and accumulator in the common case
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
@@ -427,6 +446,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     }
 
     if (a.wave_clock && lane == 0) a.wave_clock[2 * vb + 1] = wall_clock64();
+    if (a.dense) return;
     // ---- write this split's lists: [split][slot][k], padded with (-inf, PAD)
     for (int j = 0; j < UPW; ++j) {
         const int64_t slot = ug * UPW + j;
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     for (int u = 0; u < UW; ++u) {
         int64_t slot = ug * UPW + 32 * u + i;
         if (slot >= a.n_users) slot = a.n_users - 1;
-        const int64_t row = a.users ? (int64_t)a.users[slot] : slot;
+        const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
         const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
@@ -745,6 +765,38 @@ int pack_items(int esz, const void* item_emb, int64_t n_items, int d, void* pk, 
     return CRH_OK;
 }
 
+// The per-wave kernel for (element size, d, waves per SIMD).
+int launch_score_per_wave(int esz, int d, int occ, const ScoreArgs& a, hipStream_t st) {
+    if (esz == 4) {
+        switch (d) {
+            case 8: return launch_score<float, 8, 4, 1>(a, st);
+            case 16: return launch_score<float, 16, 4, 1>(a, st);
+            case 32: return launch_score<float, 32, 4, 1>(a, st);
+            case 64: return launch_score<float, 64, 4, 1>(a, st);
+            case 128: return occ == 2 ? launch_score<float, 128, 2, 2>(a, st) : launch_score<float, 128, 2, 1>(a, st);
+            default: return launch_score<float, 256, 1, 1>(a, st);
+        }
+    }
+    switch (d) {
+        case 16: return launch_score<_Float16, 16, 4, 2>(a, st);
+        case 32: return launch_score<_Float16, 32, 4, 2>(a, st);
+        case 64: return launch_score<_Float16, 64, 4, 2>(a, st);
+        case 128: return launch_score<_Float16, 128, 4, 2>(a, st);
+        default: return launch_score<_Float16, 256, 2, 2>(a, st);
+    }
+}
+
+// Catalogues up to this many items are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any)
+constexpr int64_t DENSE_MAX_ITEMS = 65536;
+constexpr size_t DENSE_MAX_BLOCK = (size_t)1 << 30;
+size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
+    if (n_items > DENSE_MAX_ITEMS) return 0;
+    const size_t row = (size_t)((n_items + 31) / 32) * 32 * sizeof(float);
+    const size_t all = (size_t)n_users * row;
+    if (all <= DENSE_MAX_BLOCK) return (all + 255) & ~(size_t)255;
+    return ((DENSE_MAX_BLOCK / (row * 64)) * 64 * row + 255) & ~(size_t)255;       // whole 64-user groups
+}
+
 // esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
 int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
                    int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
@@ -799,11 +851,65 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
     static const int variant = getenv("CRH_SCORE_OCC") ? atoi(getenv("CRH_SCORE_OCC")) : 2;
     const int occ = esz == 2 ? 2 : ((variant == 2 && d == 128) ? 2 : 1);
-    a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items, occ);
+    a.dense = nullptr;
+    a.dense_stride = 0;
+    a.user_base = 0;
     const int64_t T = (n_items + 31) / 32;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    // Small catalogues (the trainers' per-epoch validation: a few thousand users x a few thousand items).  The fused
+    // selection is built for catalogues where a candidate above the running threshold is rare; here every user takes
+    // ~k (1 + ln(N/k)) candidates through the wave-serial slow path (5 - 8 ms for 5 K users x 4 K items, a single
+    // wave of 64 users being the critical path).  Instead: the same MFMA kernel writes its score tiles to a dense
+    // block (bit-identical scores) and crh_mask_topk_f32 -- one wave per user, same masks, same canonical order --
+    // ranks it; users go in chunks if the block would pass 1 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
+    static const int dense_mode = getenv("CRH_SCORE_DENSE") ? atoi(getenv("CRH_SCORE_DENSE")) : 1;
+    const size_t dense_b = dense_block_bytes(n_users, n_items);
+    if (dense_mode && n_splits == 0 && dense_b && workspace && workspace_bytes >= dense_b) {
+        const int64_t stride = T * 32;
+        const int upw_pw = users_per_wave(esz, d);
+        int64_t chunk = (int64_t)(dense_b / ((size_t)stride * sizeof(float)));
+        if (chunk > n_users) chunk = n_users;
+        a.packed = nullptr;
+        if (!no_pack && workspace_bytes >= dense_b + packed_bytes(n_items, d, esz)) {
+            void* pk = reinterpret_cast<char*>(workspace) + dense_b;
+            const int prc = pack_items(esz, item_emb, n_items, d, pk, st);
+            if (prc != CRH_OK) return prc;
+            a.packed = pk;
+        }
+        a.n_splits = 1;
+        a.xcd_sync = nullptr;
+        a.sync_window = 0;
+        a.sync_stride = 0;
+        a.wave_clock = nullptr;
+        a.out_score = out_score;      // not written by the kernel on this route
+        a.out_idx = out_idx;
+        a.dense = reinterpret_cast<float*>(workspace);
+        a.dense_stride = stride;
+        if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
+        for (int64_t u0 = 0; u0 < n_users; u0 += chunk) {
+            const int64_t cu = std::min(chunk, n_users - u0);
+            a.users = users ? users + u0 : nullptr;
+            a.user_base = u0;
+            a.n_users = cu;
+            a.n_ugroups = (cu + upw_pw - 1) / upw_pw;
+            // item-range splits cost nothing here (every wave writes its own columns of the block): as many as
+            // fill the wave slots of the chip once
+            a.n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(T, (1024 * occ) / a.n_ugroups));
+            a.rated_rowptr = rated_rowptr ? rated_rowptr + u0 : nullptr;
+            const int rc1 = launch_score_per_wave(esz, d, occ, a, st);
+            if (rc1 != CRH_OK) return rc1;
+            const int rc2 = crh_mask_topk_f32(a.dense, cu, n_items, stride, a.rated_rowptr, rated_col, cand_bitmap, k,
+                                              item_base, 0, out_score + u0 * k, out_idx + u0 * k, stream);
+            if (rc2 != CRH_OK) return rc2;
+        }
+        if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
+        return CRH_OK;
+    }
+
+    a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items, occ);
     if (a.n_splits > T) a.n_splits = (int)T;
 
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (a.n_splits == 1) {
         a.out_score = out_score;
         a.out_idx = out_idx;
@@ -849,17 +955,6 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
     if (esz == 4 && use_wg) {
         rc = launch_score_wg<float, 128, 2, 8>(a, st);
-    } else if (esz == 4) {
-        switch (d) {
-            case 8: rc = launch_score<float, 8, 4, 1>(a, st); break;
-            case 16: rc = launch_score<float, 16, 4, 1>(a, st); break;
-            case 32: rc = launch_score<float, 32, 4, 1>(a, st); break;
-            case 64: rc = launch_score<float, 64, 4, 1>(a, st); break;
-            case 128:
-                rc = occ == 2 ? launch_score<float, 128, 2, 2>(a, st) : launch_score<float, 128, 2, 1>(a, st);
-                break;
-            default: rc = launch_score<float, 256, 1, 1>(a, st); break;
-        }
     } else if (use_wg) {
         switch (d) {
             case 64: rc = wg_waves == 4 ? launch_score_wg<_Float16, 64, 2, 4>(a, st) : launch_score_wg<_Float16, 64, 2, 8>(a, st); break;
@@ -867,13 +962,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
             default: rc = wg_waves == 4 ? launch_score_wg<_Float16, 256, 2, 4>(a, st) : launch_score_wg<_Float16, 256, 2, 8>(a, st); break;
         }
     } else {
-        switch (d) {
-            case 16: rc = launch_score<_Float16, 16, 4, 2>(a, st); break;
-            case 32: rc = launch_score<_Float16, 32, 4, 2>(a, st); break;
-            case 64: rc = launch_score<_Float16, 64, 4, 2>(a, st); break;
-            case 128: rc = launch_score<_Float16, 128, 4, 2>(a, st); break;
-            default: rc = launch_score<_Float16, 256, 2, 2>(a, st); break;
-        }
+        rc = launch_score_per_wave(esz, d, occ, a, st);
     }
     if (rc != CRH_OK) return rc;
     if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
@@ -907,13 +996,13 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
 // row-major kernel, at ~0.9x the speed.
 extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
     if (n_users <= 0 || k <= 0) return 0;
-    return lists_bytes(n_users, k) +
+    return std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) +
            (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 4) + sync_bytes(n_items) : 0);
 }
 
 extern "C" size_t crh_score_topk_f16_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
     if (n_users <= 0 || k <= 0) return 0;
-    return lists_bytes(n_users, k) +
+    return std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) +
            (crh_score_topk_f16_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 2) + sync_bytes(n_items) : 0);
 }
 
