@@ -789,8 +789,12 @@ int launch_score_per_wave(int esz, int d, int occ, const ScoreArgs& a, hipStream
 // Catalogues up to this many items are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any)
 constexpr int64_t DENSE_MAX_ITEMS = 65536;
 constexpr size_t DENSE_MAX_BLOCK = (size_t)1 << 30;
+// Which shapes: the fused selection is bound by its per-candidate slow path while N is small (k (1 + ln(N/k)) inserts
+// per user against N / 32 tiles of MFMA work) or while there are too few user groups to fill the chip (one wave is
+// the critical path); with many users and N in the tens of thousands it is MFMA-bound again and beats the 8 bytes
+// per pair the dense block costs.
 size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
-    if (n_items > DENSE_MAX_ITEMS) return 0;
+    if (n_items > DENSE_MAX_ITEMS || (n_items > 16384 && n_users > 65536)) return 0;
     const size_t row = (size_t)((n_items + 31) / 32) * 32 * sizeof(float);
     const size_t all = (size_t)n_users * row;
     if (all <= DENSE_MAX_BLOCK) return (all + 255) & ~(size_t)255;
