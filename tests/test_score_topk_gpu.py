@@ -400,3 +400,34 @@ def test_f32_workgroup_kernel_is_bit_exact(n_splits, n_items):
     sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
     ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
+
+
+def test_dense_route_chunks_users_and_equals_fused_route():
+    """Small-catalogue route of crh_score_topk_f32 (score block + wave-per-user ranking) on a shape whose block
+    exceeds 1 GiB, so the users go in chunks: user indirection, rated lists, bitmap and item_base must follow the
+    chunk offsets.  Same bits as the fused selection (forced single split) and, on a sample of rows, as the oracle."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(99)
+    n_rows, n_users, n_items, d, k, base = 21000, 20011, 16384, 8, 20, 1000
+    U = (rng.standard_normal((n_rows, d)) * 0.5).astype(np.float32)
+    V = (rng.standard_normal((n_items, d)) * 0.5).astype(np.float32)
+    users = rng.permutation(n_rows)[:n_users].astype(np.int32)
+    lens = rng.integers(0, 6, n_users)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(n_items, l, replace=False)) + base for l in lens]).astype(np.int32)
+    cold = (np.where(rng.random(n_items) < 0.3)[0] + base).astype(np.int64)
+    DEV = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    tU, tV, tu = t(U), t(V), t(users)
+    rp, rc = t(rowptr), t(col)
+    bm = ops.make_bitmap(base + n_items, cold, DEV)
+    assert n_users * n_items * 4 > (1 << 30)                       # more than one chunk
+    s0, i0 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base)             # dispatcher: dense route
+    s1, i1 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base, n_splits=1)  # fused selection
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    rows = np.concatenate([np.arange(5), [16383, 16384, 16385, n_users - 1]])       # around the chunk boundary
+    sub_ptr = np.concatenate([[0], np.cumsum(lens[rows])]).astype(np.int64)
+    sub_col = np.concatenate([col[rowptr[r]:rowptr[r + 1]] for r in rows]).astype(np.int64)
+    ws, wi = orc.score_topk(U, users[rows], V, k, sub_ptr, sub_col, orc.make_bitmap(base + n_items, cold), item_base=base)
+    assert np.array_equal(i0.cpu().numpy()[rows], wi)
+    assert np.array_equal(s0.cpu().numpy()[rows].view(np.uint32), ws.view(np.uint32))
