@@ -140,6 +140,35 @@ def _time_steps(fn, n_steps, warm):
     return e0.elapsed_time(e1) * 1e-3 / n_steps
 
 
+def validation_eval_leg(dev):
+    """The ranking the trainers run after every epoch, at the reference's own dataset sizes (configs[1] / [2]:
+    MovieLens- and CiteULike-shaped validation: every user against the whole catalogue, rated lists + cold-item bitmap,
+    k=20, fp32 d=128).  At these sizes the library scores into a dense block and ranks it with one wave per user
+    (DESIGN.md 4.1); the fused selection of the headline kernel (forced single item range) is timed beside it."""
+    from coldrec_amd import ops
+    out = {}
+    rng = np.random.default_rng(11)
+    for name, n_users, n_items, mean_rated in (("movielens", 6040, 3706, 108), ("citeulike", 5551, 16980, 23)):
+        U = xavier_(n_users, 128, 21, dev, n_items)
+        V = xavier_(n_items, 128, 22, dev, n_users)
+        rated = [np.unique(rng.integers(0, n_items, mean_rated)) for _ in range(n_users)]
+        rp, rc = ops.rated_csr(rated, dev)
+        bm = ops.make_bitmap(n_items, np.where(rng.random(n_items) < 0.2)[0], dev)
+        ms = {}
+        for tag, ns in (("library", 0), ("fused_selection", 1)):
+            for _ in range(2):
+                ops.score_topk(U, None, V, 20, rp, rc, bm, n_splits=ns)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ops.score_topk(U, None, V, 20, rp, rc, bm, n_splits=ns)
+            torch.cuda.synchronize()
+            ms[tag] = (time.perf_counter() - t0) / 10 * 1e3
+        out[name] = {"users": n_users, "items": n_items, "ms": ms["library"], "items_per_s": n_users * n_items / ms["library"] * 1e3,
+                     "ms_fused_selection": ms["fused_selection"]}
+    return {"eval_validation": out}
+
+
 def train_legs(dev, with_cpu):
     """Secondary metric of BASELINE.json: BPR triples/s (train), configs[1] (BPR-MF, MovieLens shape,
     d=128) and configs[2] (LightGCN L=3, CiteULike shape, d=128), one epoch each, triples pre-sampled
@@ -437,7 +466,9 @@ def main():
         print(json.dumps(train_xl(dev, args.steps, args.warmup, lazy=args.lazy_adam)), flush=True)
         return
     if args.train_only:
-        print(json.dumps(train_legs(dev, not args.no_cpu_baseline)), flush=True)
+        legs = train_legs(dev, not args.no_cpu_baseline)
+        legs.update(validation_eval_leg(dev))
+        print(json.dumps(legs), flush=True)
         return
 
     I, d, k, Bu = args.items, args.dim, args.k, args.users_per_step
@@ -586,6 +617,7 @@ def main():
         del V, U, engine
         torch.cuda.empty_cache()
         result.update(train_legs(dev, not args.no_cpu_baseline))
+        result.update(validation_eval_leg(dev))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
