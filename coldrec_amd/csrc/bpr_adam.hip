@@ -1233,10 +1233,17 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
         if (!(phases & 2)) return CRH_OK;
         const unsigned bwd_blocks = (grad_user || loss_out) ? (grad_user ? (unsigned)blocks : 1u) : 0u;
         if (plan) {
-            int64_t rb = (3 * batch + per_block - 1) / per_block;      // <= 3B touched rows
-            if (rb > BPR_MAX_BLOCKS) rb = BPR_MAX_BLOCKS;
             int64_t hb = 3 * batch / BPR_HEAVY + 1;                     // worst case; surplus blocks exit at once
             if (hb > 512) hb = 512;
+            // rows per lane group (grid-stride): the smallest count up to 4 that keeps the launch in one resident
+            // round (256 CUs x 5 workgroups at this kernel's ~100 VGPRs); B = 4096: two rows, LightGCN step -4 us
+            static const int force_rows = getenv("CRH_BWD_ROWS") ? atoi(getenv("CRH_BWD_ROWS")) : 0;
+            int64_t rb = 0;
+            for (int r = force_rows > 0 ? force_rows : 1; r <= (force_rows > 0 ? force_rows : 4); ++r) {
+                rb = (3 * batch + per_block * r - 1) / (per_block * r);      // <= 3B touched rows
+                if (rb + hb <= 256 * 5) break;
+            }
+            if (rb > BPR_MAX_BLOCKS) rb = BPR_MAX_BLOCKS;
             hipLaunchKernelGGL(bpr_bwd_rows_kernel<GG>, dim3((unsigned)(rb + hb)), dim3(BPR_THREADS), 0, st, a, (int)rb);
             CRH_HIP(hipGetLastError());
         } else if (bwd_blocks) {

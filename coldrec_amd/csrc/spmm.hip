@@ -153,15 +153,17 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     const bool seg = a.sched.n_seg > 0;
     if (j < a.light_blocks) {
         if (a.skip & 2) return;
-        const int64_t w = j * (256 / G) + threadIdx.x / G;
         const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
-        if (w >= n_work) return;
-        if (seg && a.sched.seg_slot[w] >= 0) return;            // part of a heavy row: done below
-        const int64_t row = seg ? a.sched.seg_row[w] : w;
-        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];   // a light work item is a whole row
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        row_edges<G>(a, e0, e1, c, on, lig, acc);
-        if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
+        // rows_per_group work items per lane group, a whole "grid" apart: with the schedule's descending-length order a
+        // long row is paired with a short one, and fewer, fully resident workgroups replace a second round of them
+        for (int64_t w = j * (256 / G) + threadIdx.x / G; w < n_work; w += a.light_blocks * (256 / G)) {
+            if (seg && a.sched.seg_slot[w] >= 0) continue;        // a heavy row: done below
+            const int64_t row = seg ? a.sched.seg_row[w] : w;
+            const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];   // a light work item is a whole row
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            row_edges<G>(a, e0, e1, c, on, lig, acc);
+            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
+        }
         return;
     }
     // heavy rows: one block per (row, slice); the NGB lane groups of the block split the row's edge list;
@@ -204,10 +206,25 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
 
 template <int G>
 int launch_spmm(SpmmArgs a, hipStream_t st) {
-    const int64_t per_block = 256 / G;
+    // Rows per lane group: the smallest count (up to 4) that makes the whole launch resident at once -- 256 CUs x 7
+    // workgroups at this kernel's 70 VGPRs -- instead of a second, partly filled round of workgroups.  CiteULike
+    // shape (4 slices): 3 rows -> 1612 workgroups, LightGCN step 0.182 -> 0.164 ms (2: 0.176, 4: 0.172, 8: 0.229).
+    // Launches of many rounds (catalogue-scale graphs) keep one row per group.  CRH_SPMM_ROWS forces a count.
+    static const int force_rows = getenv("CRH_SPMM_ROWS") ? atoi(getenv("CRH_SPMM_ROWS")) : 0;
     const int64_t n_work = a.sched.n_seg > 0 ? a.sched.n_seg : a.n_rows;
-    a.light_blocks = (n_work + per_block - 1) / per_block;
     const int64_t heavy_blocks = a.sched.n_seg > 0 ? (int64_t)a.sched.n_multi : 0;
+    int rows_per_group = 1;
+    if (force_rows > 0) {
+        rows_per_group = force_rows;
+    } else {
+        const int64_t resident = 256 * 7;
+        for (int r = 1; r <= 4; ++r) {
+            const int64_t lb = (n_work + (256 / G) * r - 1) / ((256 / G) * r);
+            if ((lb + heavy_blocks) * a.cs <= resident) { rows_per_group = r; break; }
+        }
+    }
+    const int64_t per_block = (256 / G) * rows_per_group;
+    a.light_blocks = (n_work + per_block - 1) / per_block;
     const int64_t per_slice = a.light_blocks + heavy_blocks;
     const int64_t groups8 = (per_slice + (8 / a.cs) - 1) / (8 / a.cs);      // grid in units of 8 blocks
     hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)(groups8 * 8)), dim3(256), 0, st, a);
