@@ -140,7 +140,8 @@ class MFEngine(_TableState):
 
     def can_fuse(self, n_batches: int, batch_size: int) -> bool:
         return (self.k is ops and not self.lazy and self.dp is None and self.d <= 256 and self.E.is_cuda
-                and batch_size <= 8192 and n_batches * self.E.shape[0] * 12 <= self.FUSED_MAX_MAP_BYTES)
+                and batch_size <= 8192 and 1 <= n_batches <= 65535
+                and n_batches * self.E.shape[0] * 12 <= self.FUSED_MAX_MAP_BYTES)
 
     def enable_fused_step(self) -> None:
         """Whole step (gather, loss, backward, dense Adam) in one launch, crh_mf_step_f32: the parameters
