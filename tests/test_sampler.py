@@ -327,3 +327,26 @@ def test_epoch_prefetcher_keeps_the_stream_and_takes_back_unused_epochs():
         for a, b in zip(got, want):
             assert all(np.array_equal(x, y) for x, y in zip(a, b))
         assert np.array_equal(np.random.randint(0, 1 << 30, 4), tail)
+
+
+def test_cgrc_try_limit_and_lara_guard():
+    """next_batch_cgrc stops drawing for a user after 50 x ranking_neg tries (a user that rated everything consumes
+    exactly that many draws, util/utils.py:321-334); next_batch_pairwise_LARA would loop for ever on such a user in
+    the reference -- the C++ sampler reports it instead of hanging the host."""
+    n_u, n_i = 4, 6
+    rec = [(0, i) for i in range(n_i)] + [(1, 0), (2, 3), (3, 5)]          # user 0 rated every item
+    ru, ri = np.array([r[0] for r in rec], np.int32), np.array([r[1] for r in rec], np.int32)
+    s = PairwiseSampler(ru, ri, n_u, n_i)
+    s.set_catalogue(n_u + 1, None)
+    o = orc.OtherSamplers(ru, ri, n_u + 1, n_i, ())
+    _seed_both(3)
+    want = [[sum((b[k] for b in ep), []) for k in range(3)] for ep in (list(o.cgrc_epoch(4, 2)) for _ in range(2))]
+    tail = _tails()
+    _seed_both(3)
+    got = _run_product(s, lambda: s.epoch_cgrc(4, 2))
+    assert _tails() == tail
+    for ep in range(2):
+        gu, gi, _ptr, gb = got[ep]
+        assert gu.tolist() == want[ep][0] and gi.tolist() == want[ep][1] and gb.tolist() == want[ep][2]
+    with pytest.raises(RuntimeError, match="rated every item"):
+        s.epoch_lara(1)

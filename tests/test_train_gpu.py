@@ -593,3 +593,36 @@ def test_lightgcn_adam_in_spmm_epilogue_is_bit_identical(L, monkeypatch):
         assert torch.equal(a.E, b.E) and torch.equal(a.M, b.M) and torch.equal(a.V, b.V), (L, step)
         if L >= 2:
             assert a._dout_clean and not bool(a.dOUT.any())
+
+
+def test_spmm_adam_epilogue_ops_level():
+    """crh_spmm_csr_adam_f32 == crh_spmm_csr_f32 (gradient into a table) + crh_adam_dense_f32, bit for bit, on a
+    NON-symmetric weighted matrix with and without the schedule; zero_acc_in clears the consumed operand; the
+    gradient can still be stored (acc_out)."""
+    from coldrec_amd import ops
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    n, d = 3000, 64
+    deg = np.minimum(rng.zipf(1.6, n), 400)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, rows.shape[0])
+    A = sp.csr_matrix((rng.random(rows.shape[0]).astype(np.float32), (rows, cols)), shape=(n, n))
+    A.sum_duplicates(); A.sort_indices()
+    rp, cl, vl = t(A.indptr.astype(np.int64)), t(A.indices.astype(np.int32)), t(A.data.astype(np.float32))
+    x, z = t(rng.standard_normal((n, d)).astype(np.float32)), t(rng.standard_normal((n, d)).astype(np.float32))
+    p0 = t((rng.standard_normal((n, d)) * 0.1).astype(np.float32))
+    m0 = t((rng.standard_normal((n, d)) * 1e-3).astype(np.float32))
+    v0 = t((rng.random((n, d)) * 1e-5).astype(np.float32))
+    for sched in (None, ops.SpmmSchedule(A.indptr, DEV)):
+        g = torch.empty_like(x)
+        ops.spmm_csr(rp, cl, vl, x, acc_in=z, s_in=0.5, acc_out=g, s_out=0.25, sched=sched)
+        p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+        ops.adam_dense(p1, g.clone(), m1, v1, 7, lr=1e-2, zero_grad=False)
+        p2, m2, v2, z2, g2 = p0.clone(), m0.clone(), v0.clone(), z.clone(), torch.empty_like(x)
+        ops.spmm_csr_adam(rp, cl, vl, x, z2, 0.5, g2, 0.25, sched, p2, m2, v2, 7, lr=1e-2, zero_acc_in=True)
+        assert torch.equal(g, g2) and torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+        assert not bool(z2.any())
+        sc = torch.from_numpy(ops.adam_step_scalars(7, 1, 1e-2)).to(DEV)            # graph-replay form: factors from memory
+        p3, m3, v3 = p0.clone(), m0.clone(), v0.clone()
+        ops.spmm_csr_adam(rp, cl, vl, x, z.clone(), 0.5, None, 0.25, sched, p3, m3, v3, 0, lr=1e-2, step_scalars=sc[0])
+        assert torch.equal(p1, p3) and torch.equal(m1, m3) and torch.equal(v1, v3)
