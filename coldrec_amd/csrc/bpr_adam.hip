@@ -411,19 +411,42 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a, in
 }
 
 // ---------------------------------------------------------------- plan builder (device)
-// One workgroup per batch sorts the batch's (row << 31 | entry) keys in LDS (bitonic, 64-bit keys) and
+// One workgroup per batch sorts the batch's (row | entry) keys in LDS (bitonic; see PlanKey for the two widths) and
 // emits the reverse index in the layout bpr_bwd_rows_kernel reads.  An epoch of S-ML (159 batches of
 // 4096 triples) is one launch of 159 workgroups.
 constexpr int PLAN_THREADS = 1024;
 
-__device__ inline void bitonic_sort_lds(unsigned long long* keys, int P) {
+// Sort key of a plan entry: row id above the payload (entry index in the batch, role bit for the item side).
+// 64 bits in general; 32 bits when every row id of the batch is below 2^17 (MovieLens / CiteULike scale: half the
+// LDS traffic of the sort, 32-bit compares): row << 14 | role << 13 | entry, entry < 8192.
+template <typename K>
+struct PlanKey;
+template <>
+struct PlanKey<unsigned long long> {
+    static constexpr unsigned long long INVALID = ~0ull;
+    __device__ static unsigned long long make(uint32_t row, unsigned e, unsigned role) {
+        return ((unsigned long long)row << 31) | e | (role << 30);
+    }
+    __device__ static int32_t row(unsigned long long k) { return (int32_t)(k >> 31); }
+    __device__ static int32_t entry(unsigned long long k) { return (int32_t)(k & 0x7fffffffull); }   // e | role << 30
+};
+template <>
+struct PlanKey<uint32_t> {
+    static constexpr uint32_t INVALID = ~0u;
+    __device__ static uint32_t make(uint32_t row, unsigned e, unsigned role) { return (row << 14) | (role << 13) | e; }
+    __device__ static int32_t row(uint32_t k) { return (int32_t)(k >> 14); }
+    __device__ static int32_t entry(uint32_t k) { return (int32_t)((k & 0x1fffu) | (((k >> 13) & 1u) << 30)); }
+};
+
+template <typename K>
+__device__ inline void bitonic_sort_lds(K* keys, int P) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < P; i += PLAN_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const bool asc = (i & k) == 0;
-                    const unsigned long long x = keys[i], y = keys[ixj];
+                    const K x = keys[i], y = keys[ixj];
                     if ((x > y) == asc) {
                         keys[i] = y;
                         keys[ixj] = x;
@@ -436,16 +459,16 @@ __device__ inline void bitonic_sort_lds(unsigned long long* keys, int P) {
 }
 
 // keys[0..P) sorted, invalid = ~0.  Writes rows[], ptr[], list[] and returns the segment count.
-__device__ inline int plan_emit(const unsigned long long* keys, int P, int32_t* rows, int32_t* ptr, int32_t* list,
-                                int* scan) {
+template <typename K>
+__device__ inline int plan_emit(const K* keys, int P, int32_t* rows, int32_t* ptr, int32_t* list, int* scan) {
     const int chunk = (P + PLAN_THREADS - 1) / PLAN_THREADS;
     const int e0 = threadIdx.x * chunk, e1 = min(e0 + chunk, P);
     int starts = 0, valid = 0;
     for (int e = e0; e < e1; ++e) {
-        const unsigned long long kx = keys[e];
-        if (kx == ~0ull) break;
+        const K kx = keys[e];
+        if (kx == PlanKey<K>::INVALID) break;
         ++valid;
-        if (e == 0 || (kx >> 31) != (keys[e - 1] >> 31)) ++starts;
+        if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[e - 1])) ++starts;
     }
     scan[threadIdx.x] = starts;
     scan[PLAN_THREADS + threadIdx.x] = valid;
@@ -464,19 +487,42 @@ __device__ inline int plan_emit(const unsigned long long* keys, int P, int32_t* 
     __syncthreads();
     int rank = scan[threadIdx.x];
     for (int e = e0; e < e1; ++e) {
-        const unsigned long long kx = keys[e];
-        if (kx == ~0ull) break;
-        if (e == 0 || (kx >> 31) != (keys[e - 1] >> 31)) {
-            rows[rank] = (int32_t)(kx >> 31);
+        const K kx = keys[e];
+        if (kx == PlanKey<K>::INVALID) break;
+        if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[e - 1])) {
+            rows[rank] = PlanKey<K>::row(kx);
             ptr[rank] = e;
             ++rank;
         }
-        list[e] = (int32_t)(kx & 0x7fffffffull);
+        list[e] = PlanKey<K>::entry(kx);
     }
     const int nseg = scan[2 * PLAN_THREADS], nvalid = scan[2 * PLAN_THREADS + 1];
     if (threadIdx.x == 0) ptr[nseg] = nvalid;
     __syncthreads();
     return nseg;
+}
+
+// Both sides of one batch with keys of type K (LDS: P keys + the scan scratch).
+template <typename K>
+__device__ inline void plan_sides(const int32_t* iu, const int32_t* ip, const int32_t* in_, int64_t lo, int cnt, int P,
+                                  char* smem, int32_t* urow, int32_t* uptr, int32_t* ulist, int32_t* irow, int32_t* iptr,
+                                  int32_t* ilist, int* scan, int& nu, int& ni) {
+    K* keys = reinterpret_cast<K*>(smem);
+    const int Pu = P > 2 ? P >> 1 : P;            // the user side has half as many keys (P covers 2 L item keys)
+    for (int e = threadIdx.x; e < Pu; e += PLAN_THREADS)
+        keys[e] = e < cnt ? PlanKey<K>::make((uint32_t)iu[lo + e], (unsigned)e, 0u) : PlanKey<K>::INVALID;
+    __syncthreads();
+    bitonic_sort_lds(keys, Pu);
+    nu = plan_emit(keys, Pu, urow, uptr, ulist, scan);
+    for (int e = threadIdx.x; e < P; e += PLAN_THREADS) {
+        K kx = PlanKey<K>::INVALID;
+        if (e < cnt) kx = PlanKey<K>::make((uint32_t)ip[lo + e], (unsigned)e, 0u);
+        else if (e < 2 * cnt) kx = PlanKey<K>::make((uint32_t)in_[lo + e - cnt], (unsigned)(e - cnt), 1u);
+        keys[e] = kx;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, P);
+    ni = plan_emit(keys, P, irow, iptr, ilist, scan);
 }
 
 // Heavy rows of one plan, ascending (a fixed order: the one-launch MF step sums per-block partials, and which block
@@ -570,8 +616,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
                                                                 int L, int P, int32_t* __restrict__ plans,
                                                                 int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    int* scan = reinterpret_cast<int*>(keys + P);
+    int* scan = reinterpret_cast<int*>(smem + (size_t)P * 8);      // behind the key area (sized for 64-bit keys)
     const int64_t lo = (int64_t)blockIdx.x * L;
     const int cnt = (int)((n_rec - lo) < L ? (n_rec - lo) : L);
     int32_t* pl = plans + (int64_t)blockIdx.x * stride;
@@ -582,21 +627,22 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
     int32_t* iptr = irow + 2 * L;
     int32_t* ilist = iptr + (2 * L + 1);
 
-    for (int e = threadIdx.x; e < P; e += PLAN_THREADS)
-        keys[e] = e < cnt ? (((unsigned long long)(uint32_t)iu[lo + e] << 31) | (unsigned)e) : ~0ull;
+    // largest row id of the batch decides the key width (block maximum through LDS)
+    int mx = 0;
+    for (int e = threadIdx.x; e < cnt; e += PLAN_THREADS) mx = max(mx, max(iu[lo + e], max(ip[lo + e], in_[lo + e])));
+    scan[threadIdx.x] = mx;
     __syncthreads();
-    bitonic_sort_lds(keys, P);
-    const int nu = plan_emit(keys, P, urow, uptr, ulist, scan);
-
-    for (int e = threadIdx.x; e < P; e += PLAN_THREADS) {
-        unsigned long long kx = ~0ull;
-        if (e < cnt) kx = ((unsigned long long)(uint32_t)ip[lo + e] << 31) | (unsigned)e;
-        else if (e < 2 * cnt) kx = ((unsigned long long)(uint32_t)in_[lo + e - cnt] << 31) | (unsigned)(e - cnt) | (1u << 30);
-        keys[e] = kx;
+    for (int off = PLAN_THREADS / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) scan[threadIdx.x] = max(scan[threadIdx.x], scan[threadIdx.x + off]);
+        __syncthreads();
     }
+    const bool narrow = scan[0] < (1 << 17) && L <= 8192;
     __syncthreads();
-    bitonic_sort_lds(keys, P);
-    const int ni = plan_emit(keys, P, irow, iptr, ilist, scan);
+    int nu, ni;
+    if (narrow)
+        plan_sides<uint32_t>(iu, ip, in_, lo, cnt, P, smem, urow, uptr, ulist, irow, iptr, ilist, scan, nu, ni);
+    else
+        plan_sides<unsigned long long>(iu, ip, in_, lo, cnt, P, smem, urow, uptr, ulist, irow, iptr, ilist, scan, nu, ni);
     plan_emit_heavy(pl, L, nu, ni, uptr, iptr, scan);
 }
 

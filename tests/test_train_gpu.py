@@ -97,11 +97,14 @@ def test_plan_backward_is_deterministic_and_exact(B, L):
     assert (outs[0][1].cpu().numpy()[untouched] == 0).all()
 
 
-def test_plan_kernel_whole_epoch_with_short_last_batch():
+@pytest.mark.parametrize("id_max", [700, 131_071, 131_073, 30_000_000])     # 32-bit sort keys below 2^17 rows, else 64-bit
+def test_plan_kernel_whole_epoch_with_short_last_batch(id_max):
     from coldrec_amd import ops
     rng = np.random.default_rng(5)
     n_rec, L = 10_000, 4096
-    u, p, n = (rng.integers(0, 700, n_rec).astype(np.int32) for _ in range(3))
+    u, p, n = (rng.integers(0, id_max, n_rec).astype(np.int32) for _ in range(3))
+    u[:3], p[:3], n[:3] = id_max - 1, id_max - 1, id_max - 1                   # the boundary ids are present
+    p[100:400] = 5                                                              # a heavy row
     dev = ops.build_plans_device(t(u), t(p), t(n), L).cpu().numpy()
     host = ops.build_plans(u, p, n, L)
     from coldrec_amd import _lib
