@@ -429,11 +429,18 @@ class SpmmSchedule:
     each); they sit at the end of the list with seg_slot >= 0 and the light path skips them.  Rows are independent,
     so the order does not change any result."""
 
-    def __init__(self, rowptr, device):
+    def __init__(self, rowptr, device, seg: Optional[int] = None):
         rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
         rp = rp.astype(np.int64)
-        seg = int(_lib.lib().crh_spmm_segment_edges())
         deg = np.diff(rp)
+        if seg is None:
+            # heavy threshold: crh_spmm_segment_edges() (64) for sparse graphs; for dense ones (MovieLens shape: mean
+            # degree 133, nine rows in ten above 64) a workgroup per row is the costlier path: 256 there
+            # (SpMM 59.0 -> 54.7 us; CiteULike shape, mean 11.5: 20 us at 64, 32 us at 256)
+            seg = int(_lib.lib().crh_spmm_segment_edges())
+            if "CRH_SPMM_SEG" not in os.environ and len(deg) and float(deg.mean()) > 48.0:
+                seg *= 4
+        self.seg = int(seg)
         heavy = deg > seg
         order = np.argsort(-deg, kind="stable") if os.environ.get("CRH_SPMM_SORT", "1") != "0" else np.arange(len(deg))
         order = np.concatenate([order[~heavy[order]], order[heavy[order]]])

@@ -240,11 +240,13 @@ def test_spmm_segment_schedule_on_skewed_graph():
     rowptr, col, val = orc.norm_adj_csr(key // n_i, key % n_i, n_u, n_i)
     deg = np.diff(rowptr)
     sched = ops.SpmmSchedule(rowptr, DEV)
-    assert deg.max() > 1500 and sched.n_seg == len(deg) and sched.n_partial == np.where(deg > 64, -(-deg // 64), 0).sum()
+    T = sched.seg                                                                 # 64, or 256 for dense graphs
+    assert T in (64, 256)
+    assert deg.max() > 1500 and sched.n_seg == len(deg) and sched.n_partial == np.where(deg > T, -(-deg // T), 0).sum()
     order, slot = sched.t[0].cpu().numpy(), sched.t[2].cpu().numpy()
     assert np.array_equal(np.sort(order), np.arange(len(deg)))                   # every row exactly once
-    n_light = int((deg <= 64).sum())
-    assert (slot[:n_light] == -1).all() and (slot[n_light:] >= 0).all() and (deg[order[n_light:]] > 64).all()
+    n_light = int((deg <= T).sum())
+    assert (slot[:n_light] == -1).all() and (slot[n_light:] >= 0).all() and (deg[order[n_light:]] > T).all()
     assert (np.diff(deg[order[:n_light]]) <= 0).all()                            # light rows by descending length
     X = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
     Z = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
@@ -254,8 +256,8 @@ def test_spmm_segment_schedule_on_skewed_graph():
     ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y1, acc_in=tZ, s_in=2.0, acc_out=A1, s_out=0.5, sched=sched)
     want = orc.spmm(rowptr, col, val, X)
     np.testing.assert_array_equal(Y0.cpu().numpy(), want)
-    one = deg <= 64
-    np.testing.assert_array_equal(Y1.cpu().numpy()[one], want[one])                # single segment: same chain
+    one = deg <= T
+    np.testing.assert_array_equal(Y1.cpu().numpy()[one], want[one])                # one lane group: same chain
     np.testing.assert_allclose(Y1.cpu().numpy()[~one], want[~one], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(A1.cpu().numpy(), (Z * 2 + want) * 0.5, rtol=1e-5, atol=1e-6)
     Y2 = torch.empty_like(tX)
@@ -445,7 +447,7 @@ def test_spmm_xcd_column_slices(n_u, n_i, d):
     np.testing.assert_array_equal(Y0.cpu().numpy(), want)
     sched = ops.SpmmSchedule(rowptr, DEV)
     ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y1, sched=sched)
-    one = deg <= 64
+    one = deg <= sched.seg
     np.testing.assert_array_equal(Y1.cpu().numpy()[one], want[one])
     np.testing.assert_allclose(Y1.cpu().numpy()[~one], want[~one], rtol=1e-5, atol=1e-6)
 
