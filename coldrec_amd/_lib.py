@@ -11,12 +11,13 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcoldrec_hip.so")
+# CRH_LIB: the measurement build (make -C coldrec_amd/csrc profile), loaded by tools/profile_*.sh only
+LIB_PATH = os.environ.get("CRH_LIB") or os.path.join(_HERE, "lib", "libcoldrec_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PAD_IDX = 0x7FFFFFFF
 MASKED_SCORE = -1.0e9
-MAX_K = 64
+MAX_K = 128
 
 _lib = None
 
@@ -69,6 +70,21 @@ SIGNATURES = {
     "crh_mf_step_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp,
                                _vp, _i32, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _vp, _vp]),
     "crh_mf_step_finish": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "crh_mf_step_sgd_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                   _i64, _vp, _f64, _vp]),
+    "crh_sgd_dense_f32": (_i32, [_vp, _vp, _i64, _f64, _i32, _vp]),
+    "crh_sgd_rows_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _f64, _vp]),
+    "crh_spmm_csr_sgd_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _f32, _vp, _f32, _vp, _vp, _f64, _i32, _vp]),
+    "crh_l2_workspace_bytes": (_sz, []),
+    "crh_l2_norm_f32": (_i32, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "crh_l2_reg_bwd_f32": (_i32, [_vp, _i64, _i64, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "crh_comm_unique_id": (_i32, [_vp]),
+    "crh_comm_init": (_vp, [_i32, _i32, _vp]),
+    "crh_comm_destroy": (_i32, [_vp]),
+    "crh_comm_rank": (_i32, [_vp]),
+    "crh_comm_world": (_i32, [_vp]),
+    "crh_comm_allreduce_f32": (_i32, [_vp, _vp, _i64, _vp]),
+    "crh_comm_allgather_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "crh_sampler_create": (_vp, [_vp, _vp, _i64, _i32, _i32]),
     "crh_sampler_destroy": (None, [_vp]),
     "crh_sampler_seed": (_i32, [_vp, ctypes.c_uint32]),

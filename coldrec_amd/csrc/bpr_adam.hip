@@ -692,6 +692,23 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(AdamSeg s0, AdamSeg s1,
     }
 }
 
+// ---------------------------------------------------------------- plain SGD (north_star's "BPR loss + SGD update")
+// torch.optim.SGD defaults (no momentum, no weight decay): p <- p + (-lr) * g, ONE fused multiply-add per element
+// (the canonical form of this build: oracle/oracle_np.py sgd_dense; ATen's vectorised add_(g, alpha=-lr) uses
+// an fma as well).  SURVEY.md F3: the reference trains with Adam, SGD is the extra mode the north_star names.
+// A row whose gradient is zero does not move, so the dense pass and the touched-rows pass give the same tables.
+__global__ __launch_bounds__(256) void sgd_dense_kernel(float* __restrict__ p, float* __restrict__ g, int64_t n4,
+                                                        float neg_lr, int zero_grad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4* P = reinterpret_cast<f32x4*>(p) + i;
+        f32x4* G = reinterpret_cast<f32x4*>(g) + i;
+        f32x4 x = *P;
+        sgd_elem4(x, *G, neg_lr);
+        *P = x;
+        if (zero_grad) *G = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // ---------------------------------------------------------------- touched-rows replay of dense Adam
 // torch.optim.Adam moves EVERY row every step: a row whose gradient is zero still decays its
 // moments and drifts by its stale momentum.  At catalogue scale (S-TRAIN-XL: 11 M rows, 196 K touched per
@@ -756,6 +773,29 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(AdamRowsArgs a) {
         }
         // all lanes of the group have read last[row] before anyone overwrites it (same wave, in order)
         if (lig == 0) a.last[row] = (int32_t)(a.mode == 0 ? a.step - 1 : a.step);
+    }
+}
+
+// SGD on the rows of a batch's plan only (users, then items offset by user_rows): p[row] += -lr * g[row], g[row] = 0.
+// Equal to sgd_dense_kernel over the whole table (untouched rows have a zero gradient), at 3 x 16 B per touched
+// element instead of a pass over every row: the update of choice at catalogue scale.
+template <int G>
+__global__ __launch_bounds__(256) void sgd_rows_kernel(float* __restrict__ p, float* __restrict__ g, int d,
+                                                       const int32_t* __restrict__ plan, int64_t user_rows,
+                                                       float neg_lr) {
+    const PlanView pv = plan_view(plan);
+    const int lig = threadIdx.x % G;
+    const int nvec = d >> 2;
+    const int64_t n_work = (int64_t)pv.n_u + pv.n_i;
+    for (int64_t w = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; w < n_work; w += (int64_t)gridDim.x * (256 / G)) {
+        const int64_t row = w < pv.n_u ? (int64_t)pv.urow[w] : user_rows + pv.irow[w - pv.n_u];
+        for (int c = lig; c < nvec; c += G) {
+            const int64_t o = row * d + (int64_t)c * 4;
+            f32x4 x = *reinterpret_cast<f32x4*>(p + o);
+            sgd_elem4(x, *reinterpret_cast<const f32x4*>(g + o), neg_lr);
+            *reinterpret_cast<f32x4*>(p + o) = x;
+            *reinterpret_cast<f32x4*>(g + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -825,6 +865,7 @@ struct MfStepArgs {
     float* loss_now;       // [2] of this step: l2 is written now
     AdamK k;
     const float* step_scalars;
+    float neg_lr;          // SGD variant (OPT = 1): p <- fma(-lr, g, p); m, v, step_scalars unused
     int light_blocks;
     int ablate;            // measurement only (CRH_MF_ABLATE): 1 no entries, 2 no batch sums, 4 no norms, 8 no stores
 };
@@ -915,17 +956,20 @@ __device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoe
 }
 
 // Adam on one row slice + what the updated row contributes to the norms of the next batch.
-template <int G>
+template <int G, int OPT>
 __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, bool on, int lig, f32x4 p, f32x4 m, f32x4 v,
                                               const f32x4& grad, int mult, float bc2_sqrt, float nss, float& su, float& sp,
                                               float& sn) {
     const int64_t o = row * a.d + lig * 4;
     if (on) {
-        adam_elem4(p, m, v, grad, a.k, bc2_sqrt, nss);
-        if (!(a.ablate & 8) || p.x == 123.f) {
+        if constexpr (OPT == 0) adam_elem4(p, m, v, grad, a.k, bc2_sqrt, nss);
+        else sgd_elem4(p, grad, a.neg_lr);
+        if (!(CRH_ABLATE(a.ablate) & 8) || p.x == 123.f) {
             *reinterpret_cast<f32x4*>(a.pout + o) = p;
-            *reinterpret_cast<f32x4*>(a.m + o) = m;
-            *reinterpret_cast<f32x4*>(a.v + o) = v;
+            if constexpr (OPT == 0) {
+                *reinterpret_cast<f32x4*>(a.m + o) = m;
+                *reinterpret_cast<f32x4*>(a.v + o) = v;
+            }
         }
     }
     if (mult == 0) return;                                       // uniform over the lane group
@@ -940,7 +984,9 @@ __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, 
     }
 }
 
-template <int G>
+// OPT = 0: torch.optim.Adam (m, v in place); OPT = 1: plain SGD -- no optimiser state at all, a row costs one read and
+// one write of p (8 B per element instead of 24)
+template <int G, int OPT>
 __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     __shared__ f32x4 red4[4];
     __shared__ float red[4];
@@ -958,20 +1004,22 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     int mult = 0;
     f32x4 own = {0.f, 0.f, 0.f, 0.f}, m0 = own, v0 = own;
     if (light && gid < R) {
-        if (!(a.ablate & 1)) rg = a.range[gid];
-        if (a.mult2 && !(a.ablate & 4)) mult = a.mult2[gid];
+        if (!(CRH_ABLATE(a.ablate) & 1)) rg = a.range[gid];
+        if (a.mult2 && !(CRH_ABLATE(a.ablate) & 4)) mult = a.mult2[gid];
         if (on) {
             const int64_t o = gid * a.d + lig * 4;
             own = *reinterpret_cast<const f32x4*>(a.pin + o);
-            m0 = *reinterpret_cast<const f32x4*>(a.m + o);
-            v0 = *reinterpret_cast<const f32x4*>(a.v + o);
+            if constexpr (OPT == 0) {
+                m0 = *reinterpret_cast<const f32x4*>(a.m + o);
+                v0 = *reinterpret_cast<const f32x4*>(a.v + o);
+            }
         }
     }
     // batch sums: every block reduces the previous launch's partials in the same order (one 16-B load per partial)
     f32x4 tot;
     {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int i = threadIdx.x; i < ((a.ablate & 2) ? 1 : a.n_in); i += BPR_THREADS) {
+        for (int i = threadIdx.x; i < ((CRH_ABLATE(a.ablate) & 2) ? 1 : a.n_in); i += BPR_THREADS) {
             const f32x4 x = reinterpret_cast<const f32x4*>(a.part_in)[i];
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
@@ -1000,7 +1048,11 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
         k.cp = np_ > 0.f ? a.reg * k.invB / np_ : 0.f;
         k.cn = nn > 0.f ? a.reg * k.invB / nn : 0.f;
     }
-    const float bc2_sqrt = a.step_scalars[0], nss = a.step_scalars[1];
+    float bc2_sqrt = 0.f, nss = 0.f;
+    if constexpr (OPT == 0) {
+        bc2_sqrt = a.step_scalars[0];
+        nss = a.step_scalars[1];
+    }
     float su = 0.f, sp = 0.f, sn = 0.f, sl = 0.f;
     if (light) {
         for (int64_t row = gid; row < R; row += gstride) {
@@ -1010,8 +1062,10 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
                 if (on) {
                     const int64_t o = row * a.d + lig * 4;
                     own = *reinterpret_cast<const f32x4*>(a.pin + o);
-                    m0 = *reinterpret_cast<const f32x4*>(a.m + o);
-                    v0 = *reinterpret_cast<const f32x4*>(a.v + o);
+                    if constexpr (OPT == 0) {
+                        m0 = *reinterpret_cast<const f32x4*>(a.m + o);
+                        v0 = *reinterpret_cast<const f32x4*>(a.v + o);
+                    }
                 }
             }
             if (rg.y - rg.x > BPR_HEAVY) continue;                // a heavy block does this row, Adam included
@@ -1019,7 +1073,7 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
             float loss = 0.f;
             if (rg.y > rg.x) mf_row_entries<G>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
             if (lig == 0) sl += loss;
-            mf_row_update<G>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn);
+            mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn);
         }
     } else {
         const PlanView pv = plan_view(a.plan);
@@ -1058,11 +1112,11 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
                 r.z = (t0.z + t1.z) + (t2.z + t3.z);
                 r.w = (t0.w + t1.w) + (t2.w + t3.w);
                 m0 = v0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (on) {
+                if (OPT == 0 && on) {
                     m0 = *reinterpret_cast<const f32x4*>(a.m + row * a.d + lig * 4);
                     v0 = *reinterpret_cast<const f32x4*>(a.v + row * a.d + lig * 4);
                 }
-                mf_row_update<G>(a, row, on, lig, own, m0, v0, r, a.mult2 ? a.mult2[row] : 0, bc2_sqrt, nss, su, sp, sn);
+                mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, r, a.mult2 ? a.mult2[row] : 0, bc2_sqrt, nss, su, sp, sn);
             }
         }
     }
@@ -1363,6 +1417,37 @@ extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, in
 }
 
 
+// torch.optim.SGD(lr) defaults on a dense tensor: p <- fma(-lr, g, p); zero_grad != 0 also clears g.
+extern "C" int crh_sgd_dense_f32(float* p, float* g, int64_t n, double lr, int zero_grad, void* stream) {
+    CRH_CHECK_ARG(p && g && n > 0 && n % 4 == 0, "crh_sgd_dense_f32: NULL tensor / element count not a multiple of 4");
+    CRH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g) & 15) == 0, "crh_sgd_dense_f32: tensors must be 16-byte aligned");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(sgd_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g,
+                       n / 4, (float)(-lr), zero_grad);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+// The same update on the rows of one batch's plan only (bit-identical tables: a zero gradient moves nothing);
+// clears the gradient rows it consumed.  p, g: (n_rows, d) tables, users first, item rows offset by user_rows.
+extern "C" int crh_sgd_rows_f32(float* p, float* g, int d, const int32_t* plan, int64_t batch, int64_t user_rows,
+                                double lr, void* stream) {
+    CRH_CHECK_ARG(p && g && plan && batch > 0, "crh_sgd_rows_f32: NULL pointer / empty batch");
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "crh_sgd_rows_f32: d=%d must be a positive multiple of 4", d);
+    const int G = pick_group(d);
+    int64_t blocks = (3 * batch + (256 / G) - 1) / (256 / G);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dispatch_group(G, [&](auto gc) -> int {
+        constexpr int GG = decltype(gc)::value;
+        hipLaunchKernelGGL(sgd_rows_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, st, p, g, d, plan, user_rows,
+                           (float)(-lr));
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    });
+}
+
 // Touched-rows replay of dense Adam (see adam_rows_kernel).  p, g, m, v: (n_rows, d) fp32 tables, users first;
 // last_step (n_rows) int32, all zero at the start (every row valid for "step 0"); plan: a batch's reverse index
 // (crh_bpr_plan_build*), its item rows are offset by user_rows; scalar_table: device floats [2*(max_step+1)],
@@ -1467,20 +1552,21 @@ extern "C" int crh_mf_step_tables(const int32_t* plans, const int32_t* user_idx,
 // epoch, by crh_bpr_fwd_f32's workspace (crh_bpr_fwd_parts x 4 floats).  loss_out[1] (l2) is written by this call,
 // loss_out[0] (bpr) by the next call through loss_prev_out (batch_prev = that step's batch size) or by
 // crh_mf_step_finish.
-extern "C" int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v, int64_t user_rows,
-                               int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan,
-                               const int32_t* range, const int32_t* entries, const int32_t* mult_next,
-                               const float* part_in, int n_parts_in, float* part_out, float* loss_prev_out,
-                               int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
-                               const float* step_scalars, void* stream) {
-    CRH_CHECK_ARG(table_in && table_out && m && v && table_in != table_out, "crh_mf_step_f32: NULL / aliased tables");
-    CRH_CHECK_ARG(user_rows > 0 && item_rows > 0 && batch > 0, "crh_mf_step_f32: empty table or batch");
-    CRH_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "crh_mf_step_f32: d=%d must be a multiple of 4, at most 256", d);
-    CRH_CHECK_ARG(plan && range && entries, "crh_mf_step_f32: NULL plan / step tables");
-    CRH_CHECK_ARG(part_in && n_parts_in > 0 && part_out && step_scalars, "crh_mf_step_f32: NULL partial sums / step scalars");
-    CRH_CHECK_ARG(!loss_prev_out || batch_prev > 0, "crh_mf_step_f32: loss_prev_out needs batch_prev");
+namespace {
+int mf_step_run(const char* who, int opt, const float* table_in, float* table_out, float* m, float* v, int64_t user_rows,
+                int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan, const int32_t* range,
+                const int32_t* entries, const int32_t* mult_next, const float* part_in, int n_parts_in, float* part_out,
+                float* loss_prev_out, int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
+                const float* step_scalars, double lr, void* stream) {
+    CRH_CHECK_ARG(table_in && table_out && table_in != table_out, "%s: NULL / aliased tables", who);
+    CRH_CHECK_ARG(opt == 1 || (m && v && step_scalars), "%s: NULL optimiser state / step scalars", who);
+    CRH_CHECK_ARG(user_rows > 0 && item_rows > 0 && batch > 0, "%s: empty table or batch", who);
+    CRH_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "%s: d=%d must be a multiple of 4, at most 256", who, d);
+    CRH_CHECK_ARG(plan && range && entries, "%s: NULL plan / step tables", who);
+    CRH_CHECK_ARG(part_in && n_parts_in > 0 && part_out, "%s: NULL partial sums", who);
+    CRH_CHECK_ARG(!loss_prev_out || batch_prev > 0, "%s: loss_prev_out needs batch_prev", who);
     CRH_CHECK_ARG((((uintptr_t)table_in | (uintptr_t)table_out | (uintptr_t)m | (uintptr_t)v | (uintptr_t)part_in) & 15) == 0,
-                  "crh_mf_step_f32: tables and partial sums must be 16-byte aligned");
+                  "%s: tables and partial sums must be 16-byte aligned", who);
     MfStepArgs a;
     a.pin = table_in; a.pout = table_out; a.m = m; a.v = v;
     a.U = user_rows; a.I = item_rows; a.d = d;
@@ -1494,17 +1580,43 @@ extern "C" int crh_mf_step_f32(const float* table_in, float* table_out, float* m
     a.loss_now = loss_out;
     a.k = AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
     a.step_scalars = step_scalars;
+    a.neg_lr = (float)(-lr);
     const int parts = crh_mf_step_parts(user_rows + item_rows, d);
     a.light_blocks = parts - MF_HEAVY_BLOCKS;
-    static const int ablate = getenv("CRH_MF_ABLATE") ? atoi(getenv("CRH_MF_ABLATE")) : 0;
+    static const int ablate = CRH_PROFILE_ENV("CRH_MF_ABLATE");
     a.ablate = ablate;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dispatch_group(pick_group(d), [&](auto gc) -> int {
         constexpr int GG = decltype(gc)::value;
-        hipLaunchKernelGGL(mf_step_kernel<GG>, dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        if (opt == 1) hipLaunchKernelGGL((mf_step_kernel<GG, 1>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((mf_step_kernel<GG, 0>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         CRH_HIP(hipGetLastError());
         return CRH_OK;
     });
+}
+}  // namespace
+
+extern "C" int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v, int64_t user_rows,
+                               int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan,
+                               const int32_t* range, const int32_t* entries, const int32_t* mult_next,
+                               const float* part_in, int n_parts_in, float* part_out, float* loss_prev_out,
+                               int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
+                               const float* step_scalars, void* stream) {
+    return mf_step_run("crh_mf_step_f32", 0, table_in, table_out, m, v, user_rows, item_rows, d, batch, reg, plan, range,
+                       entries, mult_next, part_in, n_parts_in, part_out, loss_prev_out, batch_prev, loss_out, beta1, beta2,
+                       eps, step_scalars, 0.0, stream);
+}
+
+// The same one-launch step with torch.optim.SGD(lr) (no momentum, no weight decay) instead of Adam: no optimiser state,
+// every row is read once and written once to the other buffer (north_star: "BPR loss + SGD update").
+extern "C" int crh_mf_step_sgd_f32(const float* table_in, float* table_out, int64_t user_rows, int64_t item_rows, int d,
+                                   int64_t batch, float reg, const int32_t* plan, const int32_t* range,
+                                   const int32_t* entries, const int32_t* mult_next, const float* part_in,
+                                   int n_parts_in, float* part_out, float* loss_prev_out, int64_t batch_prev,
+                                   float* loss_out, double lr, void* stream) {
+    return mf_step_run("crh_mf_step_sgd_f32", 1, table_in, table_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
+                       plan, range, entries, mult_next, part_in, n_parts_in, part_out, loss_prev_out, batch_prev, loss_out,
+                       0.9, 0.999, 1e-8, nullptr, lr, stream);
 }
 
 // bpr loss of the LAST step of an epoch from its partial sums.

@@ -38,6 +38,16 @@ __device__ __forceinline__ bool crh_better(float sa, int ia, float sb, int ib) {
 
 #define CRH_NEG_INF (-__builtin_inff())
 
+// Measurement hooks (parts of a kernel switched off, per-wave clocks) exist only in the -DCRH_PROFILE build that
+// tools/profile_*.sh load (make profile -> lib/libcoldrec_hip_profile.so); in the shipped library they fold to 0.
+#ifdef CRH_PROFILE
+#define CRH_ABLATE(x) (x)
+#define CRH_PROFILE_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define CRH_ABLATE(x) 0
+#define CRH_PROFILE_ENV(name) 0
+#endif
+
 // One Adam step of one element, op for op what torch/optim/adam.py _single_tensor_adam does.  Shared by the
 // dense kernel, the touched-rows replay, the one-launch MF step and the SpMM epilogue so that all produce the same bits.
 struct AdamK {
@@ -57,4 +67,11 @@ __device__ __forceinline__ void adam_elem4(f32x4& p, f32x4& m, f32x4& v, const f
         m[c] = mc;
         v[c] = vc;
     }
+}
+
+// One plain-SGD step of four elements (torch.optim.SGD defaults): p <- fma(-lr, g, p).  Shared by the dense kernel,
+// the touched-rows kernel, the one-launch MF step and the SpMM epilogue.
+__device__ __forceinline__ void sgd_elem4(f32x4& p, const f32x4& g, float neg_lr) {
+    p.x = fmaf(neg_lr, g.x, p.x); p.y = fmaf(neg_lr, g.y, p.y);
+    p.z = fmaf(neg_lr, g.z, p.z); p.w = fmaf(neg_lr, g.w, p.w);
 }

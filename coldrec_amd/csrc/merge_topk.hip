@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
     float* ss = reinterpret_cast<float*>(smem) + (size_t)wave * per_wave * 2;
     int* si = reinterpret_cast<int*>(ss + per_wave);
 
-    for (int64_t user = (int64_t)blockIdx.x * 4 + wave; user < n_users; user += (int64_t)gridDim.x * 4) {
+    const int wpb = (int)(blockDim.x >> 6);      // waves per block: 4, fewer when the staged lists are large (k > 64)
+    for (int64_t user = (int64_t)blockIdx.x * wpb + wave; user < n_users; user += (int64_t)gridDim.x * wpb) {
         for (int e = lane; e < per_wave; e += 64) {
             const int l = e / k_in, t = e - l * k_in;
             const int64_t g = ((int64_t)l * n_users + user) * k_in + t;
@@ -181,10 +182,7 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ S, i
         }
         if (WPR == 1 || wave == 0) {
             const int n = __builtin_amdgcn_readfirstlane(*cnt);
-            if (lane < K) {
-                out_score[row * K + lane] = lane < n ? ls[lane] : CRH_NEG_INF;
-                out_idx[row * K + lane] = lane < n ? li[lane] : CRH_PAD_IDX;
-            }
+            wave_list_store(ls, li, n, K, out_score + row * K, out_idx + row * K, lane);
             if (write_back && rated_rowptr) {       // the row has been read: now it may be scribbled on
                 for (int64_t e = rated_rowptr[row] + lane; e < rated_rowptr[row + 1]; e += 64) {
                     const int64_t il = (int64_t)rated_col[e] - item_base;
@@ -205,13 +203,16 @@ extern "C" int crh_merge_topk(const float* in_score, const int32_t* in_idx, int 
     CRH_CHECK_ARG(k_in >= 1 && k_in <= CRH_MAX_K && k_out >= 1 && k_out <= CRH_MAX_K,
                   "crh_merge_topk: k_in=%d / k_out=%d outside 1..%d", k_in, k_out, CRH_MAX_K);
     CRH_CHECK_ARG(n_users > 0, "crh_merge_topk: n_users=%lld", (long long)n_users);
-    const size_t lds = (size_t)4 * n_lists * k_in * 8;
+    const size_t per_wave = (size_t)n_lists * k_in * 8;          // <= 64 lists x 128 entries x 8 B = 64 KiB
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 152 * 1024) wpb >>= 1;
+    const size_t lds = per_wave * wpb;
     if (lds > 64 * 1024)
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t blocks = (n_users + 3) / 4;
+    int64_t blocks = (n_users + wpb - 1) / wpb;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)blocks), dim3(256), lds,
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)blocks), dim3(64 * wpb), lds,
                        reinterpret_cast<hipStream_t>(stream), in_score, in_idx, n_lists, n_users, k_in, k_out,
                        out_score, out_idx);
     CRH_HIP(hipGetLastError());

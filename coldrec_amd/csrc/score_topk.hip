@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     if (ug >= a.n_ugroups) return;
     const int K = a.k;
     const int i = lane & 31, h = lane >> 5;
-    if (a.wave_clock && lane == 0) a.wave_clock[2 * vb] = wall_clock64();
+    if (CRH_ABLATE(a.wave_clock != nullptr) && lane == 0) a.wave_clock[2 * vb] = wall_clock64();
     unsigned* sync_cnt = nullptr;
     if (a.xcd_sync) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     const int64_t T_all = (a.n_items + 31) >> 5;
     constexpr int QSTRIDE = PK ? 1024 : 32;    // bytes between this lane's consecutive chunks
     auto tile_ptr = [&](int64_t t) -> const char* {
-        if (a.ablate & 2) t = 0;   // measurement only: every load hits the same (cached) tile
+        if (CRH_ABLATE(a.ablate) & 2) t = 0;   // measurement only: every load hits the same (cached) tile
         if constexpr (PK) {
             if (t >= T_all) t = T_all - 1;
             return reinterpret_cast<const char*>(a.packed) + (t * NCH * 64 + lane) * 16;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (a.ablate & 1) {   // keep the products live, skip selection (roofline ablation, results invalid)
+        if (CRH_ABLATE(a.ablate) & 1) {   // keep the products live, skip selection (roofline ablation, results invalid)
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -445,18 +445,15 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         }
     }
 
-    if (a.wave_clock && lane == 0) a.wave_clock[2 * vb + 1] = wall_clock64();
+    if (CRH_ABLATE(a.wave_clock != nullptr) && lane == 0) a.wave_clock[2 * vb + 1] = wall_clock64();
     if (a.dense) return;
     // ---- write this split's lists: [split][slot][k], padded with (-inf, PAD)
     for (int j = 0; j < UPW; ++j) {
         const int64_t slot = ug * UPW + j;
         if (slot >= a.n_users) break;
         const int n = __builtin_amdgcn_readfirstlane(w.cnt[j]);
-        if (lane < K) {
-            const int64_t o = ((int64_t)split * a.n_users + slot) * K + lane;
-            a.out_score[o] = lane < n ? w.ls[j * K + lane] : CRH_NEG_INF;
-            a.out_idx[o] = lane < n ? w.li[j * K + lane] : CRH_PAD_IDX;
-        }
+        const int64_t o = ((int64_t)split * a.n_users + slot) * K;
+        wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
     }
 }
 
@@ -539,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     // this wave's share of tile t: chunks wave, wave+8, ... (1 KiB each, 16 B per lane)
     auto fetch = [&](f32x4(&st)[CPW], int64_t t) {
         if (t >= NT) t = NT - 1;
-        if (a.ablate & 2) t = 0;   // measurement only: every fetch hits the same (cached) tile
+        if (CRH_ABLATE(a.ablate) & 2) t = 0;   // measurement only: every fetch hits the same (cached) tile
         const char* tp = packed + t * TILE_B + lane * 16;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
@@ -595,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
             for (int j = 0; j < GR; ++j) Elem<T>::template mma<UW>(acc, c[g & 1][j], b[g * GR + j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (a.ablate & 1) {
+        if (CRH_ABLATE(a.ablate) & 1) {
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -644,11 +641,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
             const int64_t slot = ug * UPW + j;
             if (slot >= a.n_users) break;
             const int n = __builtin_amdgcn_readfirstlane(w.cnt[j]);
-            if (lane < K) {
-                const int64_t o = ((int64_t)split * a.n_users + slot) * K + lane;
-                a.out_score[o] = lane < n ? w.ls[j * K + lane] : CRH_NEG_INF;
-                a.out_idx[o] = lane < n ? w.li[j * K + lane] : CRH_PAD_IDX;
-            }
+            const int64_t o = ((int64_t)split * a.n_users + slot) * K;
+            wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
         }
     }
 }
@@ -849,7 +843,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     a.k = k;
     a.item_base = item_base;
     a.n_ugroups = (n_users + upw - 1) / upw;
-    static const int ablate = getenv("CRH_SCORE_ABLATE") ? atoi(getenv("CRH_SCORE_ABLATE")) : 0;
+    static const int ablate = CRH_PROFILE_ENV("CRH_SCORE_ABLATE");
     a.ablate = ablate;
     // two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured at fp32
     // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
@@ -952,10 +946,12 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
             CRH_HIP(hipMemsetAsync(a.xcd_sync, 0, (size_t)a.sync_stride * 8 * sizeof(unsigned), st));
         }
     }
-    static const int timing = getenv("CRH_SCORE_TIMING") ? atoi(getenv("CRH_SCORE_TIMING")) : 0;
     a.wave_clock = nullptr;
+#ifdef CRH_PROFILE
+    static const int timing = CRH_PROFILE_ENV("CRH_SCORE_TIMING");
     const int64_t n_waves = a.n_ugroups * a.n_splits;
-    if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // measurement hook only
+    if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // profile build only
+#endif
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
     if (esz == 4 && use_wg) {
         rc = launch_score_wg<float, 128, 2, 8>(a, st);
@@ -970,6 +966,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     }
     if (rc != CRH_OK) return rc;
     if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
+#ifdef CRH_PROFILE
     if (timing && !use_wg) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
         CRH_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)n_waves * 2);
@@ -989,6 +986,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
                 en_[n_waves / 4] / tot, en_[n_waves / 2] / tot, en_[3 * n_waves / 4] / tot, en_[9 * n_waves / 10] / tot,
                 en_[n_waves - 1] / tot);
     }
+#endif
     if (a.n_splits > 1)
         return crh_merge_topk(a.out_score, a.out_idx, a.n_splits, n_users, k, k, out_score, out_idx, stream);
     return CRH_OK;

@@ -51,6 +51,7 @@ struct SpmmArgs {
     float bc2_sqrt, neg_step_size;
     const float* step_scalars;
     int zero_acc_in;        // clear acc_in's row once it has been consumed (ready for the next step's scatter)
+    int sgd;                // optimiser epilogue is plain SGD: p <- fma(neg_step_size, g, p), no m / v
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -71,7 +72,11 @@ __device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f3
         r.z = (z.z * a.s_in + acc.z) * a.s_out;
         r.w = (z.w * a.s_in + acc.w) * a.s_out;
         if (a.acc_out) *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
-        if (a.adam_p) {
+        if (a.adam_p && a.sgd) {
+            f32x4 p = *reinterpret_cast<const f32x4*>(a.adam_p + o);
+            sgd_elem4(p, r, a.neg_step_size);
+            *reinterpret_cast<f32x4*>(a.adam_p + o) = p;
+        } else if (a.adam_p) {
             f32x4 p = *reinterpret_cast<const f32x4*>(a.adam_p + o), m = *reinterpret_cast<const f32x4*>(a.adam_m + o);
             f32x4 v = *reinterpret_cast<const f32x4*>(a.adam_v + o);
             const float b2s = a.step_scalars ? a.step_scalars[0] : a.bc2_sqrt;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     const bool on = c < (a.d >> 2);                  // d/4 not a power of two: the lane group is padded
     const bool seg = a.sched.n_seg > 0;
     if (j < a.light_blocks) {
-        if (a.skip & 2) return;
+        if (CRH_ABLATE(a.skip) & 2) return;
         const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
         // rows_per_group work items per lane group, a whole "grid" apart: with the schedule's descending-length order a
         // long row is paired with a short one, and fewer, fully resident workgroups replace a second round of them
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     // partial sums meet in a fixed order: shuffle tree inside a wave, then the 4 waves through LDS
     __shared__ f32x4 wsum[4][G];
     const int64_t m = j - a.light_blocks;
-    if (m >= a.sched.n_multi || (a.skip & 1)) return;
+    if (m >= a.sched.n_multi || (CRH_ABLATE(a.skip) & 1)) return;
     constexpr int NGB = 256 / G;
     const int64_t row = a.sched.multi_row[m];
     const int64_t r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
@@ -250,7 +255,7 @@ namespace {
 int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* x,
              int d, float* y, float* acc_in, float s_in, float* acc_out, float s_out, const crh_spmm_sched* sched,
              float* adam_p, float* adam_m, float* adam_v, AdamK k, float bc2_sqrt, float nss, const float* step_scalars,
-             int zero_acc_in, void* stream) {
+             int zero_acc_in, void* stream, int sgd = 0) {
     CRH_CHECK_ARG(rowptr && x && n_rows > 0, "%s: NULL pointer / empty matrix", who);
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "%s: d=%d must be a positive multiple of 4", who, d);
     CRH_CHECK_ARG(y || acc_out || adam_p, "%s: nothing to write (y and acc_out both NULL)", who);
@@ -259,9 +264,9 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
     CRH_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)acc_in | (uintptr_t)acc_out | (uintptr_t)adam_p |
                     (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) == 0,
                   "%s: dense operands must be 16-byte aligned", who);
-    static const int skip = getenv("CRH_SPMM_SKIP") ? atoi(getenv("CRH_SPMM_SKIP")) : 0;
+    static const int skip = CRH_PROFILE_ENV("CRH_SPMM_SKIP");
     SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0, skip,
-               adam_p, adam_m, adam_v, k, bc2_sqrt, nss, step_scalars, zero_acc_in};
+               adam_p, adam_m, adam_v, k, bc2_sqrt, nss, step_scalars, zero_acc_in, sgd};
     if (sched && sched->n_seg > 0) {
         CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "%s: incomplete schedule", who);
         CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "%s: incomplete schedule (heavy rows)", who);
@@ -333,4 +338,13 @@ extern "C" int crh_spmm_csr_adam_f32(const int64_t* rowptr, const int32_t* col, 
     return spmm_run("crh_spmm_csr_adam_f32", rowptr, col, val, n_rows, x, d, nullptr, acc_in, s_in, acc_out, s_out, sched,
                     p, m, v, AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps},
                     (float)sqrt(bc2), (float)(-(lr / bc1)), step_scalars, zero_acc_in, stream);
+}
+
+// The same fused epilogue with torch.optim.SGD(lr) defaults instead of Adam: p <- fma(-lr, g, p), no optimiser state.
+extern "C" int crh_spmm_csr_sgd_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                                    const float* x, int d, float* acc_in, float s_in, float* acc_out, float s_out,
+                                    const crh_spmm_sched* sched, float* p, double lr, int zero_acc_in, void* stream) {
+    CRH_CHECK_ARG(p, "crh_spmm_csr_sgd_f32: NULL parameter table");
+    return spmm_run("crh_spmm_csr_sgd_f32", rowptr, col, val, n_rows, x, d, nullptr, acc_in, s_in, acc_out, s_out, sched,
+                    p, nullptr, nullptr, AdamK{}, 0.f, (float)(-lr), nullptr, zero_acc_in, stream, 1);
 }

@@ -1,31 +1,55 @@
 // Wave-cooperative per-user top-k lists kept in LDS (one wave = 64 lanes owns its lists, so
 // there is no cross-wave synchronisation anywhere).  Lists are sorted best-first by the
-// canonical key; lane t holds entry t during an insertion, hence k <= 64.
+// canonical key; lane t holds entries t and t + 64 during an insertion, hence k <= 128.
 #pragma once
 #include "crh_common.h"
 
 // All 64 lanes call with wave-uniform (sc, gi).  lsu/liu: this user's k-entry list, cntp its fill.
+// Lane t holds entries t and t + 64 during an insertion (k <= CRH_MAX_K = 128); the second half is only touched
+// when K > 64 (wave-uniform branch), so the common k <= 64 case costs what it did with one entry per lane.
 __device__ __forceinline__ void wave_list_insert(float* lsu, int* liu, int* cntp, int K, float sc,
                                                  int gi, int lane) {
     const int n = __builtin_amdgcn_readfirstlane(*cntp);
-    float es = CRH_NEG_INF;
-    int ei = CRH_PAD_IDX;
+    float es = CRH_NEG_INF, es2 = CRH_NEG_INF;
+    int ei = CRH_PAD_IDX, ei2 = CRH_PAD_IDX;
     if (lane < n) {
         es = lsu[lane];
         ei = liu[lane];
     }
     const bool ahead = lane < n && crh_better(es, ei, sc, gi);
-    const int p = __popcll(__ballot(ahead));
+    int p = __popcll(__ballot(ahead));
+    const bool wide = K > 64;
+    if (wide) {
+        if (lane + 64 < n) {
+            es2 = lsu[lane + 64];
+            ei2 = liu[lane + 64];
+        }
+        p += __popcll(__ballot(lane + 64 < n && crh_better(es2, ei2, sc, gi)));
+    }
     if (p < K) {
+        // every shifted entry was read into registers above, so the stores cannot overtake a load
         if (lane >= p && lane < n && lane + 1 < K) {
             lsu[lane + 1] = es;
             liu[lane + 1] = ei;
+        }
+        if (wide && lane + 64 >= p && lane + 64 < n && lane + 65 < K) {
+            lsu[lane + 65] = es2;
+            liu[lane + 65] = ei2;
         }
         if (lane == 0) {
             lsu[p] = sc;
             liu[p] = gi;
             *cntp = n < K ? n + 1 : K;
         }
+    }
+}
+
+// Write a finished list (n valid entries of K) to out[0..K), padded with (-inf, PAD); whole wave.
+__device__ __forceinline__ void wave_list_store(const float* ls, const int* li, int n, int K, float* out_s, int* out_i,
+                                                int lane) {
+    for (int e = lane; e < K; e += 64) {
+        out_s[e] = e < n ? ls[e] : CRH_NEG_INF;
+        out_i[e] = e < n ? li[e] : CRH_PAD_IDX;
     }
 }
 

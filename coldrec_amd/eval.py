@@ -9,7 +9,7 @@ no collective at all.
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional, Tuple
+from typing import Tuple
 
 import torch
 
@@ -27,11 +27,9 @@ class UserShardedTopK:
     all-gather puts the (k scores, k ids) rows back in user order.  No merge, no dependence on G by construction;
     used as the validation mode of the item-sharded path and when the catalogue fits every GPU."""
 
-    def __init__(self, items: torch.Tensor, k: int, world: int = 1, rank: int = 0, group=None,
-                 local_topk: Optional[Callable] = None):
+    def __init__(self, items: torch.Tensor, k: int, world: int = 1, rank: int = 0, group=None):
         self.items, self.k = items, int(k)
         self.world, self.rank, self.group = world, rank, group
-        self._local_topk = local_topk or ops.score_topk
 
     def topk(self, user_emb, users, rated_rowptr=None, rated_col=None, cand_bitmap=None):
         """``users`` must be given (int32 rows of user_emb for the whole block, identical on every rank)."""
@@ -41,7 +39,7 @@ class UserShardedTopK:
         if rated_rowptr is not None:
             rp = (rated_rowptr[lo:hi + 1] - rated_rowptr[lo]).contiguous()
             rc = rated_col[int(rated_rowptr[lo]):int(rated_rowptr[hi])].contiguous()
-        s, i = self._local_topk(user_emb, users[lo:hi].contiguous(), self.items, self.k, rp, rc, cand_bitmap)
+        s, i = ops.score_topk(user_emb, users[lo:hi].contiguous(), self.items, self.k, rp, rc, cand_bitmap)
         if self.world == 1:
             return s, i
         import torch.distributed as dist
@@ -59,16 +57,12 @@ class UserShardedTopK:
 
 class ShardedTopK:
     def __init__(self, item_shard: torch.Tensor, item_base: int, n_items_global: int, k: int,
-                 world: int = 1, rank: int = 0, group=None,
-                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None):
+                 world: int = 1, rank: int = 0, group=None):
         self.items = item_shard
         self.item_base = int(item_base)
         self.n_items_global = int(n_items_global)
         self.k = int(k)
         self.world, self.rank, self.group = world, rank, group
-        # injectable for the CPU (gloo) plumbing tests; the product path is the HIP ops
-        self._local_topk = local_topk or ops.score_topk
-        self._merge = merge or ops.merge_topk
         # test hook: run the all-gather + merge even with one rank (exercises the RCCL path on a 1-GPU box)
         self.force_collective = bool(int(os.environ.get("CRH_FORCE_COLLECTIVE", "0")))
 
@@ -79,8 +73,8 @@ class ShardedTopK:
             kw["kernel_events"] = kernel_events
         if n_splits:
             kw["n_splits"] = n_splits
-        s, i = self._local_topk(user_emb, users, self.items, self.k, rated_rowptr, rated_col, cand_bitmap,
-                                item_base=self.item_base, **kw)
+        s, i = ops.score_topk(user_emb, users, self.items, self.k, rated_rowptr, rated_col, cand_bitmap,
+                              item_base=self.item_base, **kw)
         if self.world == 1 and not self.force_collective:
             return s, i
         import torch.distributed as dist
@@ -91,4 +85,4 @@ class ShardedTopK:
         gathered = flat.view(self.world, packed.shape[0], packed.shape[1])
         gs = gathered[:, :, :self.k].contiguous().view(torch.float32)
         gi = gathered[:, :, self.k:].contiguous()
-        return self._merge(gs, gi, self.k)
+        return ops.merge_topk(gs, gi, self.k)

@@ -82,6 +82,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--lazy_adam', choices=['auto', 'on', 'off'], default='auto',
                    help='(addition) BPR-MF only: replay dense Adam on the rows a batch touches (bit-identical to the '
                         'dense pass, which it replaces when the tables are much larger than a batch)')
+    p.add_argument('--optimizer', choices=['adam', 'sgd'], default='adam',
+                   help='(addition) MF / LightGCN: adam = torch.optim.Adam as the reference (model/MF.py:14); sgd = '
+                        'torch.optim.SGD(lr) defaults, the "BPR loss + SGD update" mode: rows a batch does not touch do '
+                        'not move, 8 instead of 24 bytes of optimiser traffic per element')
     p.add_argument('--score_dtype', choices=['fp32', 'fp16'], default='fp32',
                    help='(addition) table precision of the fused full-catalogue ranking: fp32 = exact, the '
                         'reference\'s arithmetic; fp16 = half tables, fp32 accumulation (16x the MFMA rate)')

@@ -24,7 +24,7 @@ from typing import Any, Dict, List, Tuple
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from ..eval import ShardedTopK, shard_bounds
 from ..train import dp_from_env
 from ..util.evaluator import format_measure, ranking_metrics, truth_csr, truth_dense
@@ -54,6 +54,9 @@ class BaseColdStartTrainer(ABC):
         self.bestPerformance = []
         self.topN = [int(x) for x in a.topN.split(',')]
         self.max_N = max(self.topN)
+        if self.max_N > _lib.MAX_K or min(self.topN) < 1:
+            raise ValueError(f'--topN {a.topN}: the HIP ranking kernels keep lists of 1..{_lib.MAX_K} entries '
+                             f'(CRH_MAX_K in include/coldrec_hip.h)')
         self.model_name, self.dataset_name = a.model, a.dataset
         self.emb_size, self.maxEpoch, self.batch_size = a.emb_size, a.epochs, a.bs
         self.lr, self.reg = a.lr, a.reg
@@ -133,6 +136,8 @@ class BaseColdStartTrainer(ABC):
     def _topk_arrays(self, data_set: Dict, data_type: str):
         """(users, scores (n,k) float32, internal item ids (n,k)) on the host, canonical order."""
         c = self._get_eval_cache(data_set, data_type)
+        if len(c['users']) == 0:        # an empty warm / cold / valid split: the reference reports zeros, no kernel runs
+            return c, np.zeros((0, self.max_N), np.float32), np.zeros((0, self.max_N), np.int32)
         fused = self.fused_eval
         if fused is None:
             fused = _is_stock_batch_predict(type(self).batch_predict)
@@ -180,15 +185,30 @@ class BaseColdStartTrainer(ABC):
         c, _s, i = self._topk_arrays(data_set, data_type)
         return ranking_metrics(c['gt_rowptr'], c['gt_items'], i, topn, dense=c['gt_dense'])
 
+    def _metrics_from_rec_list(self, data_set: Dict, data_type: str, rec_list: Dict, topn):
+        """Metrics of a caller-supplied ``{user: [(item, score), ...]}`` (what ``test()`` returns, possibly
+        post-processed by a plugin) -- the reference's ranking_evaluation(test_set, rec_list, topN) on arrays."""
+        c = self._get_eval_cache(data_set, data_type)
+        item_id = self.data.item
+        pred = np.full((len(c['users']), max(topn)), np.iinfo(np.int32).max, np.int64)
+        for r, u in enumerate(c['users']):
+            row = [item_id.get(it, np.iinfo(np.int32).max) for it, _ in rec_list[u][: max(topn)]]
+            pred[r, : len(row)] = row
+        return ranking_metrics(c['gt_rowptr'], c['gt_items'], pred, topn, dense=c['gt_dense'])
+
     def full_evaluation(self, rec_list=None, test_type: str = 'warm') -> None:
-        """Prints and stores the test metrics.  ``rec_list`` (the dict ``test()`` returns) is accepted
-        for API compatibility; the numbers are computed from the same top-k on arrays."""
+        """Prints and stores the test metrics (model/BaseRecommender.py:230-254).  With a ``rec_list`` (the dict
+        ``test()`` returns, or a plugin's post-processed version of it) the numbers are computed FROM it, as the
+        reference does; ``rec_list=None`` (the built-in ``run()``) ranks once on the GPU and scores the arrays."""
         test_set = self._sets('test', test_type)
         if rec_list is not None and len(rec_list) != len(test_set):
             print(f"ground-truth set size: {len(test_set)}, predicted set size: {len(rec_list)}")
             print('The Lengths of ground-truth set and predicted set do not match!')
             exit(-1)
-        perf = self._metrics(test_set, test_type, self.topN)
+        if rec_list is not None:
+            perf = self._metrics_from_rec_list(test_set, test_type, rec_list, self.topN)
+        else:
+            perf = self._metrics(test_set, test_type, self.topN)
         self.result = format_measure(perf, self.topN)
         setattr(self, {'warm': 'warm_test_results', 'cold': 'cold_test_results',
                        'all': 'overall_test_results'}[test_type], perf)

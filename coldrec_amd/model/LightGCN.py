@@ -35,7 +35,7 @@ class LightGCN(MF):
     def _make_engine(self):
         rowptr, col, val = self.data.norm_adj_csr()
         return LGCNEngine(self.model.user0, self.model.item0, rowptr, col, val, self.n_layers, self.lr,
-                          self.reg, self.device)
+                          self.reg, self.device, optimizer=getattr(self.args, 'optimizer', 'adam'))
 
     def _save_tables(self, as_parameter=False):
         super()._save_tables(as_parameter=False)

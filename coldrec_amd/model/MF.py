@@ -40,7 +40,8 @@ class MF(BaseColdStartTrainer):
         self.engine = None
 
     def _make_engine(self):
-        return MFEngine(self.model.user0, self.model.item0, self.lr, self.reg, self.device)
+        return MFEngine(self.model.user0, self.model.item0, self.lr, self.reg, self.device,
+                        optimizer=getattr(self.args, 'optimizer', 'adam'))
 
     def train(self):
         _require_gpu(self.device)

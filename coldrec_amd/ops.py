@@ -65,7 +65,11 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.type, device.index)
+    """Grow-only scratch, ONE PER (device, stream): calls on different streams never alias, and calls on one stream
+    are ordered by it.  Only the eager ops (scoring, dense ranking) use it; everything that may be captured into a
+    hipGraph (the engines' BPR steps) owns a private buffer (``bpr_workspace``), because a captured graph keeps the raw
+    pointer and a regrown shared buffer would hand that memory back to the caching allocator."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -153,7 +157,7 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k_out: int):
 # ------------------------------------------------------------------------------ training ops
 def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, reg: float,
                 grad_user=None, grad_pos=None, grad_neg=None, loss_out: Optional[torch.Tensor] = None,
-                plan: Optional[torch.Tensor] = None):
+                plan: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
     """bpr_loss + l2_reg_loss and their dense table gradients for one batch of triples
     (util/utils.py:25-29,44-48 + autograd at model/MF.py:22-26).  ``*_idx`` int32 device tensors or
     None (tables are already gathered).  Gradients are ACCUMULATED into ``grad_*`` (all three or
@@ -169,7 +173,9 @@ def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, re
     if loss_out is None:
         loss_out = torch.empty(2, dtype=torch.float32, device=dev)
     L = _lib.lib()
-    ws = _workspace(L.crh_bpr_workspace_bytes(batch), dev)   # same grow-only scratch as score_topk
+    need = L.crh_bpr_workspace_bytes(batch)
+    ws = workspace if workspace is not None else _workspace(need, dev)
+    assert ws.numel() >= need, "bpr_fwd_bwd: private workspace too small for this batch"
     rc = L.crh_bpr_fwd_bwd_f32(_lib.ptr(user_table), _lib.ptr(pos_table), _lib.ptr(neg_table), d,
                                _lib.ptr(user_idx), _lib.ptr(pos_idx), _lib.ptr(neg_idx), batch, float(reg),
                                _lib.ptr(grad_user), _lib.ptr(grad_pos), _lib.ptr(grad_neg), _lib.ptr(loss_out),
@@ -289,15 +295,24 @@ def mf_step_tables(plans: torch.Tensor, user_idx, pos_idx, neg_idx, batch_size: 
 
 def mf_step(table_in, table_out, m, v, user_rows: int, batch: int, reg: float, plan, rng, entries, mult_next,
             part_in, n_parts_in: int, part_out, loss_prev, batch_prev: int, loss_out, step_scalars,
-            beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
-    """One whole optimiser step of model/MF.py:19-27 in one launch (crh_mf_step_f32, see include/coldrec_hip.h)."""
+            beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, sgd_lr: Optional[float] = None) -> None:
+    """One whole optimiser step of model/MF.py:19-27 in one launch (crh_mf_step_f32, see include/coldrec_hip.h);
+    ``sgd_lr`` selects torch.optim.SGD(lr) instead of Adam (crh_mf_step_sgd_f32: m, v, step_scalars unused)."""
     _need_cuda(table_in, table_out, m, v, plan, rng, entries, part_in, part_out, step_scalars)
     R, d = table_in.shape
-    for t in (table_in, table_out, m, v):
+    for t in (table_in, table_out) + (() if sgd_lr is not None else (m, v)):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (R, d)
     for t in (plan, rng, entries):
         assert t.dtype == torch.int32 and t.is_contiguous()
     assert rng.shape == (R, 2) and (mult_next is None or (mult_next.shape == (R,) and mult_next.is_contiguous()))
+    if sgd_lr is not None:
+        rc = _lib.lib().crh_mf_step_sgd_f32(
+            _lib.ptr(table_in), _lib.ptr(table_out), int(user_rows), R - int(user_rows), d, int(batch), float(reg),
+            _lib.ptr(plan), _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(mult_next), _lib.ptr(part_in), int(n_parts_in),
+            _lib.ptr(part_out), _lib.ptr(loss_prev), int(batch_prev), _lib.ptr(loss_out), float(sgd_lr),
+            _lib.current_stream())
+        _lib.check(rc, "crh_mf_step_sgd_f32")
+        return
     rc = _lib.lib().crh_mf_step_f32(
         _lib.ptr(table_in), _lib.ptr(table_out), _lib.ptr(m), _lib.ptr(v), int(user_rows), R - int(user_rows), d,
         int(batch), float(reg), _lib.ptr(plan), _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(mult_next),
@@ -400,6 +415,59 @@ def adam_rows(p, g, m, v, last_step, plan, batch: int, user_rows: int, step: int
                                       _lib.ptr(scalar_table), float(betas[0]), float(betas[1]), float(eps), int(mode),
                                       _lib.current_stream())
     _lib.check(rc, "crh_adam_rows_f32")
+
+
+def sgd_dense(p, g, lr: float, zero_grad: bool = True):
+    """In-place torch.optim.SGD(lr) defaults on a dense tensor: p <- fma(-lr, g, p) (crh_sgd_dense_f32)."""
+    _need_cuda(p, g)
+    assert p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
+    _lib.check(_lib.lib().crh_sgd_dense_f32(_lib.ptr(p), _lib.ptr(g), p.numel(), float(lr), 1 if zero_grad else 0,
+                                            _lib.current_stream()), "crh_sgd_dense_f32")
+
+
+def sgd_rows(p, g, plan, batch: int, user_rows: int, lr: float):
+    """The same update on the rows of one batch's plan only (crh_sgd_rows_f32); clears the consumed gradient rows."""
+    _need_cuda(p, g, plan)
+    assert p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and plan.dtype == torch.int32
+    _lib.check(_lib.lib().crh_sgd_rows_f32(_lib.ptr(p), _lib.ptr(g), p.shape[1], _lib.ptr(plan), int(batch),
+                                           int(user_rows), float(lr), _lib.current_stream()), "crh_sgd_rows_f32")
+
+
+def spmm_csr_sgd(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: float, sched, p, lr: float,
+                 zero_acc_in: bool = False) -> None:
+    """g = (acc_in*s_in + A @ x)*s_out -> p <- fma(-lr, g, p) in the SpMM's epilogue (crh_spmm_csr_sgd_f32)."""
+    _need_cuda(rowptr, col, val, x, acc_in, acc_out, p)
+    n_rows, d = rowptr.shape[0] - 1, x.shape[1]
+    for t in (x, p):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n_rows, d)
+    rc = _lib.lib().crh_spmm_csr_sgd_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
+                                         _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
+                                         ctypes.byref(sched.c) if sched is not None else None, _lib.ptr(p), float(lr),
+                                         int(bool(zero_acc_in)), _lib.current_stream())
+    _lib.check(rc, "crh_spmm_csr_sgd_f32")
+
+
+def l2_norm(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """|x|_F as a device scalar (crh_l2_norm_f32; deterministic two-stage reduction)."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(L.crh_l2_workspace_bytes()), dtype=torch.uint8, device=x.device)
+    _lib.check(L.crh_l2_norm_f32(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+               "crh_l2_norm_f32")
+    return out
+
+
+def l2_reg_bwd(x: torch.Tensor, reg: float, norm: torch.Tensor, grad_out: Optional[torch.Tensor]) -> torch.Tensor:
+    """d(reg * |x|_F / rows)/dx * grad_out (crh_l2_reg_bwd_f32)."""
+    _need_cuda(x, norm, grad_out)
+    gx = torch.empty_like(x)
+    go = None if grad_out is None else grad_out.reshape(1).float().contiguous()
+    _lib.check(_lib.lib().crh_l2_reg_bwd_f32(_lib.ptr(x), x.numel(), x.shape[0], float(reg), _lib.ptr(norm), _lib.ptr(go),
+                                             _lib.ptr(gx), 0, _lib.current_stream()), "crh_l2_reg_bwd_f32")
+    return gx
 
 
 def spmm_csr_adam(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: float, sched, p, m, v, step: int,

@@ -180,12 +180,15 @@ class EpochPrefetcher:
         self.s.pull_numpy_state()
 
         def work():
-            out = self.s.epoch(self.B)
-            key = np.empty(624, dtype=np.uint32)
-            pos = ctypes.c_int(0)
-            _lib.check(self.s._L.crh_sampler_get_state(self.s._h, key.ctypes.data, ctypes.addressof(pos)),
-                       "crh_sampler_get_state")
-            self._result = (out, key, int(pos.value))
+            try:
+                out = self.s.epoch(self.B)
+                key = np.empty(624, dtype=np.uint32)
+                pos = ctypes.c_int(0)
+                _lib.check(self.s._L.crh_sampler_get_state(self.s._h, key.ctypes.data, ctypes.addressof(pos)),
+                           "crh_sampler_get_state")
+                self._result = (out, key, int(pos.value))
+            except BaseException as e:          # re-raised on the calling thread by _finish()
+                self._result = e
 
         if self.enabled:
             self._thread = threading.Thread(target=work, daemon=True)
@@ -199,6 +202,11 @@ class EpochPrefetcher:
             self._thread.join()
             self._thread = None
         res, self._result = self._result, None
+        if isinstance(res, BaseException) or res is None:
+            # the worker failed: put permutation and generator back where the epoch started, then report
+            _lib.check(self.s._L.crh_sampler_restore(self.s._h), "crh_sampler_restore")
+            self._base = None
+            raise RuntimeError("EpochPrefetcher: sampling the epoch failed") from (res if res is not None else None)
         return res
 
     def get(self):

@@ -52,64 +52,98 @@ def dp_from_env() -> Optional[DPContext]:
 class _TableState:
     dp: Optional[DPContext] = None
 
+    optimizer = 'adam'        # 'adam' = torch.optim.Adam as the reference (model/MF.py:14); 'sgd' = torch.optim.SGD(lr)
+
     def enable_data_parallel(self, dp: DPContext) -> None:
         self.dp = dp
         self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self._bpr_ws = None
+        self._dp_ws, self._dp_cap = None, 0
+
+    def _ws(self, batch: int) -> torch.Tensor:
+        """This engine's OWN BPR scratch (grown only outside graph capture): a captured epoch keeps its raw pointer."""
+        if self._bpr_ws is None or self._bpr_cap < batch:
+            if self.E.is_cuda:
+                assert not torch.cuda.is_current_stream_capturing(), "size the BPR workspace before capturing the epoch"
+            self._bpr_cap = max(int(batch), 1)
+            self._bpr_ws = self.k.bpr_workspace(self._bpr_cap, self.device)
+        return self._bpr_ws
 
     def _dp_loss_grad(self, tu, tp, user_idx, pos_idx, neg_idx, gu, gp, loss_out) -> None:
-        """Slice forward -> all-reduce(4 sums) -> slice backward (atomics) into the local gradient."""
+        """Slice forward -> all-reduce(4 sums) -> slice backward into the local gradient.  The backward uses the
+        reverse index of the SLICE (one lane group per touched row, fixed summation order, stores): every rank's
+        gradient is bit-reproducible, as the single-GPU step's is; what remains order-dependent is the all-reduce."""
         B = user_idx.shape[0]
         lo, hi = self.dp.slice(B)
-        if self._bpr_ws is None or self._bpr_cap < hi - lo:
-            self._bpr_cap = max(hi - lo, 1)
-            self._bpr_ws = self.k.bpr_workspace(self._bpr_cap, self.device)
+        if self._dp_ws is None or self._dp_cap < hi - lo:
+            self._dp_cap = max(hi - lo, 1)
+            self._dp_ws = self.k.bpr_workspace(self._dp_cap, self.device)
         u, p, n = user_idx[lo:hi], pos_idx[lo:hi], neg_idx[lo:hi]
         if hi > lo:
-            self.k.bpr_fwd(tu, tp, tp, u, p, n, self.sums, self._bpr_ws)
+            self.k.bpr_fwd(tu, tp, tp, u, p, n, self.sums, self._dp_ws)
         else:
             self.sums.zero_()
         self.dp.all_reduce(self.sums)
         if hi > lo:
-            self.k.bpr_bwd(tu, tp, tp, u, p, n, B, self.reg, self.sums, gu, gp, gp, loss_out, self._bpr_ws)
+            plan = None
+            if hi - lo <= 8192 and hasattr(self.k, 'build_plans_device') and self.d <= 256:
+                plan = self.k.build_plans_device(u, p, n, hi - lo)[0]
+            self.k.bpr_bwd(tu, tp, tp, u, p, n, B, self.reg, self.sums, gu, gp, gp, loss_out, self._dp_ws, plan=plan)
+        elif loss_out is not None:            # a rank without triples still reports the global loss
+            loss_out[0] = self.sums[3] / B
+            loss_out[1] = self.reg * self.sums[:3].sqrt().sum() / B
+
+    def _alloc_state(self, optimizer: str) -> None:
+        assert optimizer in ('adam', 'sgd'), "optimizer must be 'adam' (the reference's) or 'sgd'"
+        self.optimizer = optimizer
+        self.G = torch.zeros_like(self.E)
+        # plain SGD keeps no optimiser state (M, V stay None)
+        self.M, self.V = (torch.zeros_like(self.E), torch.zeros_like(self.E)) if optimizer == 'adam' else (None, None)
+        self.step_count = 0
+        self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._bpr_ws, self._bpr_cap = None, 0
 
     @classmethod
-    def from_table(cls, E: torch.Tensor, user_num: int, lr: float, reg: float):
+    def from_table(cls, E: torch.Tensor, user_num: int, lr: float, reg: float, optimizer: str = 'adam'):
         """Engine over an existing device-resident (user_num + item_num, d) fp32 table (rows of users first);
         no host copy is made -- for tables generated on the GPU (bench.py S-TRAIN-XL)."""
         self = cls.__new__(cls)
         self.k = ops
         assert E.is_cuda and E.dtype == torch.float32 and E.is_contiguous() and E.shape[1] % 4 == 0
         self.user_num, self.item_num, self.d, self.device = int(user_num), E.shape[0] - int(user_num), E.shape[1], E.device
+        self.d_logical = self.d
         self.E = E
-        self.G, self.M, self.V = (torch.zeros_like(E) for _ in range(3))
-        self.lr, self.reg, self.step_count = float(lr), float(reg), 0
-        self.loss = torch.zeros(2, dtype=torch.float32, device=E.device)
+        self.lr, self.reg = float(lr), float(reg)
+        self._alloc_state(optimizer)
         return self
 
-    def __init__(self, user0, item0, lr: float, reg: float, device, kernels=None):
-        # ``kernels``: injectable for the CPU (gloo) plumbing tests only; the product path is coldrec_amd.ops
-        self.k = kernels or ops
+    def __init__(self, user0, item0, lr: float, reg: float, device, optimizer: str = 'adam'):
+        self.k = ops      # the HIP ops; the 2-rank gloo plumbing tests (CPU) substitute the module attribute train.ops
         u = torch.as_tensor(np.asarray(user0, np.float32) if not torch.is_tensor(user0) else user0.detach().float())
         v = torch.as_tensor(np.asarray(item0, np.float32) if not torch.is_tensor(item0) else item0.detach().float())
-        assert u.shape[1] == v.shape[1] and u.shape[1] % 4 == 0, "embedding width must be a multiple of 4"
-        self.user_num, self.item_num, self.d = u.shape[0], v.shape[0], u.shape[1]
+        assert u.shape[1] == v.shape[1], "user and item tables must have one embedding width"
+        self.user_num, self.item_num, self.d_logical = u.shape[0], v.shape[0], u.shape[1]
+        # the reference accepts any --emb_size; the kernels move 16 B per lane, so other widths get zero columns up to
+        # the next multiple of 4: their gradient is 0 (every factor is 0), Adam/SGD leave them at 0, norms and scores
+        # are unchanged -- exact, and invisible through user_emb / item_emb
+        self.d = (self.d_logical + 3) // 4 * 4
         self.device = torch.device(device)
-        self.E = torch.cat([u, v], 0).to(self.device).contiguous()
-        self.G = torch.zeros_like(self.E)
-        self.M = torch.zeros_like(self.E)
-        self.V = torch.zeros_like(self.E)
+        E = torch.zeros((self.user_num + self.item_num, self.d), dtype=torch.float32)
+        E[: self.user_num, : self.d_logical] = u
+        E[self.user_num:, : self.d_logical] = v
+        self.E = E.to(self.device).contiguous()
         self.lr, self.reg = float(lr), float(reg)
-        self.step_count = 0
-        self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._alloc_state(optimizer)
+
+    def _view(self, t):
+        return t if self.d == self.d_logical else t[:, : self.d_logical]
 
     @property
     def user_emb(self):
-        return self.E[: self.user_num]
+        return self._view(self.E[: self.user_num])
 
     @property
     def item_emb(self):
-        return self.E[self.user_num:]
+        return self._view(self.E[self.user_num:])
 
     def last_loss(self) -> float:
         """bpr + l2 of the last step (device -> host sync; the reference prints it every 50 batches)."""
@@ -128,6 +162,8 @@ class MFEngine(_TableState):
 
     def enable_lazy_adam(self) -> None:
         assert self.dp is None, "the touched-rows optimiser is single-GPU"
+        if self.optimizer != 'adam':       # SGD never moves an untouched row: sgd_rows already is the touched-rows form
+            return
         self.lazy = True
         self.last_step = torch.zeros(self.E.shape[0], dtype=torch.int32, device=self.device)
         self._table = None
@@ -139,16 +175,17 @@ class MFEngine(_TableState):
     FUSED_MAX_MAP_BYTES = 1 << 29        # the (batches, rows) per-row tables of an epoch (12 B per row and batch)
 
     def can_fuse(self, n_batches: int, batch_size: int) -> bool:
-        return (self.k is ops and not self.lazy and self.dp is None and self.d <= 256 and self.E.is_cuda
+        return (hasattr(self.k, 'mf_step') and not self.lazy and self.dp is None and self.d <= 256 and self.E.is_cuda
                 and batch_size <= 8192 and 1 <= n_batches <= 65535
                 and n_batches * self.E.shape[0] * 12 <= self.FUSED_MAX_MAP_BYTES)
 
     def enable_fused_step(self) -> None:
         """Whole step (gather, loss, backward, dense Adam) in one launch, crh_mf_step_f32: the parameters
         ping-pong between ``E`` and a second buffer, no gradient table is used.  Driven by ``fused_epoch``."""
-        assert self.k is ops and not self.lazy and self.dp is None and self.d <= 256
+        assert not self.lazy and self.dp is None and self.d <= 256
         self.fused = True
         self.E2 = torch.empty_like(self.E)
+        self._sgd_lr = self.lr if self.optimizer == 'sgd' else None
         self._nparts = ops.mf_step_parts(self.E.shape[0], self.d)
         self._parts = [torch.zeros(self._nparts * 4, dtype=torch.float32, device=self.device) for _ in range(2)]
         self._fws, self._fws_cap = None, 0
@@ -169,7 +206,7 @@ class MFEngine(_TableState):
             part_out = self._parts[s & 1]
             ops.mf_step(src, dst, self.M, self.V, U, hi - lo, self.reg, plans[s], rng[s], ent[s],
                         mult[s + 1] if s + 1 < len(steps) else None, part_in, n_in, part_out,
-                        losses[s - 1] if s else None, prev, losses[s], scalars[s])
+                        losses[s - 1] if s else None, prev, losses[s], scalars[s], sgd_lr=self._sgd_lr)
             part_in, n_in, prev = part_out, self._nparts, hi - lo
             src, dst = dst, src
         ops.mf_step_finish(part_in, n_in, prev, losses[len(steps) - 1])
@@ -200,7 +237,7 @@ class MFEngine(_TableState):
         tab = self._scalar_table(t)
         ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=0)
         self.k.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
-                           self.G[:U], self.G[U:], self.G[U:], loss, plan=plan)
+                           self.G[:U], self.G[U:], self.G[U:], loss, plan=plan, workspace=self._ws(B))
         ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=1)
         self.step_count, self._dirty = t, True
 
@@ -215,10 +252,17 @@ class MFEngine(_TableState):
         if self.dp is not None:
             self._dp_loss_grad(self.E[:U], self.E[U:], user_idx, pos_idx, neg_idx, self.G[:U], self.G[U:], loss)
             self.dp.all_reduce(self.G)
+            plan = None                       # the summed gradient has rows of every rank's slice
         else:
             self.k.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
-                               self.G[:U], self.G[U:], self.G[U:], loss, plan=plan)
+                               self.G[:U], self.G[U:], self.G[U:], loss, plan=plan, workspace=self._ws(user_idx.shape[0]))
         self.step_count += 1
+        if self.optimizer == 'sgd':
+            if plan is not None:              # only the rows the batch touched move (and only their gradient is cleared)
+                self.k.sgd_rows(self.E, self.G, plan, user_idx.shape[0], U, self.lr)
+            else:
+                self.k.sgd_dense(self.E, self.G, self.lr, zero_grad=True)
+            return
         self.k.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=True,
                           step_scalars=step_scalars)
 
@@ -230,8 +274,9 @@ class MFEngine(_TableState):
 class LGCNEngine(_TableState):
     """model/LightGCN.py:14-29,86-96: full-graph L-layer propagation per batch and its backward."""
 
-    def __init__(self, user0, item0, rowptr, col, val, n_layers: int, lr: float, reg: float, device, kernels=None):
-        super().__init__(user0, item0, lr, reg, device, kernels)
+    def __init__(self, user0, item0, rowptr, col, val, n_layers: int, lr: float, reg: float, device,
+                 optimizer: str = 'adam'):
+        super().__init__(user0, item0, lr, reg, device, optimizer)
         assert n_layers >= 1
         self.L = int(n_layers)
         dev = self.device
@@ -245,7 +290,7 @@ class LGCNEngine(_TableState):
         self.dOUT = torch.zeros_like(self.E)
         self._dout_clean = True
         # Adam in the epilogue of the last backward SpMM (CRH_LGCN_FUSED=0: separate gradient table + Adam launch)
-        self.fuse_adam = self.k is ops and os.environ.get("CRH_LGCN_FUSED", "1") != "0"
+        self.fuse_adam = hasattr(self.k, 'spmm_csr_adam') and os.environ.get("CRH_LGCN_FUSED", "1") != "0"
         self.keep_grad = False       # also store dE0 into self.G (tests compare it with the reference's autograd)
 
     def _propagate(self, out: torch.Tensor) -> None:
@@ -260,7 +305,7 @@ class LGCNEngine(_TableState):
 
     def forward(self):
         self._propagate(self.OUT)
-        return self.OUT[: self.user_num], self.OUT[self.user_num:]
+        return self._view(self.OUT[: self.user_num]), self._view(self.OUT[self.user_num:])
 
     def step(self, user_idx, pos_idx, neg_idx, plan: Optional[torch.Tensor] = None, loss_out=None,
              step_scalars=None) -> None:
@@ -277,7 +322,8 @@ class LGCNEngine(_TableState):
             self.dp.all_reduce(self.dOUT)
         else:
             self.k.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
-                               self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], loss, plan=plan)
+                               self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], loss, plan=plan,
+                               workspace=self._ws(user_idx.shape[0]))
         # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
         x = self.dOUT
         self.step_count += 1
@@ -287,6 +333,11 @@ class LGCNEngine(_TableState):
                 # the optimiser runs in the last SpMM's epilogue (no gradient table, no Adam launch); for L >= 2 the
                 # gathered operand is not dOUT, so the same epilogue clears dOUT for the next step's scatter
                 self._dout_clean = self.L >= 2
+                if self.optimizer == 'sgd':
+                    self.k.spmm_csr_sgd(self.rowptr, self.col, self.val, x, self.dOUT, 1.0 if j == 0 else c,
+                                        self.G if self.keep_grad else None, c if j == 0 else 1.0, self.sched, self.E,
+                                        self.lr, zero_acc_in=self._dout_clean)
+                    return
                 self.k.spmm_csr_adam(self.rowptr, self.col, self.val, x, self.dOUT, 1.0 if j == 0 else c,
                                      self.G if self.keep_grad else None, c if j == 0 else 1.0, self.sched, self.E, self.M, self.V, self.step_count,
                                      lr=self.lr, step_scalars=step_scalars, zero_acc_in=self._dout_clean)
@@ -296,6 +347,9 @@ class LGCNEngine(_TableState):
                             s_in=1.0 if j == 0 else c, acc_out=dst, s_out=c if j == 0 else 1.0, sched=self.sched)
             x = dst
         self._dout_clean = False
+        if self.optimizer == 'sgd':
+            self.k.sgd_dense(self.E, self.G, self.lr, zero_grad=False)
+            return
         self.k.adam_dense(self.E, self.G, self.M, self.V, self.step_count, lr=self.lr, zero_grad=False,
                           step_scalars=step_scalars)
 

@@ -104,21 +104,56 @@ def next_batch_cgrc(data, batch_size, ranking_neg_per_user=32):
         yield u[lo:hi].tolist(), i[lo:hi].tolist(), bset[ptr[b]:ptr[b + 1]].tolist()
 
 
+def _pad4(t):
+    """Zero columns up to the next multiple of 4 (the kernels move 16 B per lane): exact for dots and norms."""
+    t = t.contiguous().float()
+    r = (-t.shape[1]) % 4
+    return t if r == 0 else torch.nn.functional.pad(t, (0, r))
+
+
 class _BprFn(torch.autograd.Function):
-    """mean(-log(1e-5 + sigmoid(u.p - u.n))) on gathered (B, d) tensors."""
+    """mean(-log(1e-5 + sigmoid(u.p - u.n))) on gathered (B, d) tensors (util/utils.py:25-29).  The forward
+    (crh_bpr_fwd_f32) leaves the per-triple score differences in a private workspace that the backward
+    (crh_bpr_bwd_f32) reads: the forward pass is not repeated."""
 
     @staticmethod
     def forward(ctx, u, p, n):
-        u, p, n = (t.contiguous().float() for t in (u, p, n))
-        ctx.save_for_backward(u, p, n)
-        return ops.bpr_fwd_bwd(u, p, n, None, None, None, 0.0)[0].clone()
+        d = u.shape[1]
+        u, p, n = _pad4(u), _pad4(p), _pad4(n)
+        B = u.shape[0]
+        ws = ops.bpr_workspace(B, u.device)
+        sums = torch.empty(4, dtype=torch.float32, device=u.device)
+        ops.bpr_fwd(u, p, n, None, None, None, sums, ws)
+        ctx.save_for_backward(u, p, n, sums, ws)
+        ctx.d = d
+        return sums[3] / B
 
     @staticmethod
     def backward(ctx, grad_out):
-        u, p, n = ctx.saved_tensors
+        u, p, n, sums, ws = ctx.saved_tensors
         gu, gp, gn = torch.zeros_like(u), torch.zeros_like(p), torch.zeros_like(n)
-        ops.bpr_fwd_bwd(u, p, n, None, None, None, 0.0, gu, gp, gn)
-        return gu * grad_out, gp * grad_out, gn * grad_out
+        # reg = 0: only the BPR term; identity indices -> every gradient row is written by exactly one triple
+        ops.bpr_bwd(u, p, n, None, None, None, u.shape[0], 0.0, sums, gu, gp, gn, None, ws)
+        d = ctx.d
+        return (gu[:, :d] * grad_out, gp[:, :d] * grad_out, gn[:, :d] * grad_out)
+
+
+class _L2Fn(torch.autograd.Function):
+    """reg * |x|_F / rows(x) for ONE embedding tensor (a term of util/utils.py:44-48) over crh_l2_norm_f32 /
+    crh_l2_reg_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, x, reg):
+        xc = x.contiguous().float()
+        norm = ops.l2_norm(xc)
+        ctx.save_for_backward(xc, norm)
+        ctx.reg = float(reg)
+        return norm[0] * (ctx.reg / xc.shape[0])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xc, norm = ctx.saved_tensors
+        return ops.l2_reg_bwd(xc, ctx.reg, norm, grad_out), None
 
 
 def _check_gpu(*ts):
@@ -129,15 +164,15 @@ def _check_gpu(*ts):
 
 def bpr_loss(user_emb, pos_item_emb, neg_item_emb):
     _check_gpu(user_emb, pos_item_emb, neg_item_emb)
-    if user_emb.shape[1] % 4:
-        raise RuntimeError("bpr_loss: embedding width must be a multiple of 4 for the HIP kernel")
     return _BprFn.apply(user_emb, pos_item_emb, neg_item_emb)
 
 
 def l2_reg_loss(reg, *args):
-    """reg * sum_e |e|_F / rows(e).  Any number of embeddings (other models pass 2..6)."""
+    """reg * sum_e |e|_F / rows(e).  Any number of embeddings (other models pass 2..6), any shapes; every term runs
+    forward and backward in the HIP library.  Same association as the reference: the norms are summed first, the
+    product with reg comes last."""
     _check_gpu(*args)
     emb_loss = 0
     for emb in args:
-        emb_loss = emb_loss + torch.norm(emb, p=2) / emb.shape[0]
+        emb_loss = emb_loss + _L2Fn.apply(emb.reshape(emb.shape[0], -1) if emb.dim() != 2 else emb, 1.0)
     return emb_loss * reg

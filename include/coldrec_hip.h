@@ -32,7 +32,7 @@ extern "C" {
 #define CRH_ERR_WS (-3)      /* workspace too small */
 #define CRH_PAD_IDX 0x7fffffff
 #define CRH_MASKED_SCORE (-1.0e9f) /* -10e8, model/BaseRecommender.py:177,180 */
-#define CRH_MAX_K 64
+#define CRH_MAX_K 128
 
 const char* crh_last_error(void);
 int crh_version(void);
@@ -118,7 +118,8 @@ int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items, int64_t r
 /*
  * Canonical merge of n_lists partial top-k lists per user, layout [list][user][k_in]
  * (item-range splits inside one GPU; shards after the all-gather).
- * n_lists <= 64, k_out <= CRH_MAX_K.
+ * n_lists <= 64, k_in, k_out <= CRH_MAX_K (the reference takes any --topN, model/BaseRecommender.py:27-29; lists of
+ * up to 128 entries are kept two per lane).
  */
 int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, int64_t n_users,
                    int k_in, int k_out, float* out_score, int32_t* out_idx, void* stream);
@@ -307,6 +308,60 @@ int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v,
                     int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
                     const float* step_scalars, void* stream);
 int crh_mf_step_finish(const float* part_in, int n_parts_in, int64_t batch, float* loss_out, void* stream);
+
+/*
+ * north_star's "BPR loss + SGD update": torch.optim.SGD(lr) defaults (no momentum, no weight decay) in place of
+ * torch.optim.Adam.  The reference itself trains with Adam (model/MF.py:14, model/LightGCN.py:16), so
+ * these are the extra mode; canonical arithmetic p <- fma(-lr, g, p) (oracle/oracle_np.py sgd_dense, pinned to
+ * torch.optim.SGD within fp32 rounding).  A zero gradient moves nothing, so the dense pass (crh_sgd_dense_f32, n % 4
+ * == 0, zero_grad clears g), the pass over the rows of a batch's plan (crh_sgd_rows_f32: tables (rows, d), users
+ * first, item rows of the plan offset by user_rows; clears the gradient rows it consumed) and the fused forms give
+ * the same tables:
+ *   crh_mf_step_sgd_f32   crh_mf_step_f32 without m / v / step_scalars: a row is read once and written once
+ *   crh_spmm_csr_sgd_f32  crh_spmm_csr_adam_f32 with the SGD update in the epilogue
+ */
+int crh_sgd_dense_f32(float* p, float* g, int64_t n, double lr, int zero_grad, void* stream);
+int crh_sgd_rows_f32(float* p, float* g, int d, const int32_t* plan, int64_t batch, int64_t user_rows, double lr,
+                     void* stream);
+int crh_mf_step_sgd_f32(const float* table_in, float* table_out, int64_t user_rows, int64_t item_rows, int d,
+                        int64_t batch, float reg, const int32_t* plan, const int32_t* range, const int32_t* entries,
+                        const int32_t* mult_next, const float* part_in, int n_parts_in, float* part_out,
+                        float* loss_prev_out, int64_t batch_prev, float* loss_out, double lr, void* stream);
+int crh_spmm_csr_sgd_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* x,
+                         int d, float* acc_in, float s_in, float* acc_out, float s_out, const crh_spmm_sched* sched,
+                         float* p, double lr, int zero_acc_in, void* stream);
+
+/*
+ * l2_reg_loss(reg, *embeddings) of util/utils.py:44-48 = reg * sum_e |e|_F / rows(e), for plugins that call it with
+ * their own tensors (2..6 of them, any shapes): crh_l2_norm_f32 leaves |x|_F of n contiguous floats in norm_out
+ * (device scalar; deterministic two-stage reduction through `workspace`, crh_l2_workspace_bytes() bytes);
+ * crh_l2_reg_bwd_f32 is the backward of one term: gx (+)= x * reg * grad_out / (rows * norm), 0 where norm == 0
+ * (grad_out: device scalar or NULL = 1; accumulate != 0 adds to gx).
+ */
+size_t crh_l2_workspace_bytes(void);
+int crh_l2_norm_f32(const float* x, int64_t n, float* norm_out, void* workspace, size_t workspace_bytes, void* stream);
+int crh_l2_reg_bwd_f32(const float* x, int64_t n, int64_t rows, float reg, const float* norm, const float* grad_out,
+                       float* gx, int accumulate, void* stream);
+
+/*
+ * Multi-GPU exchange steps over RCCL (the reference is single-process, nothing to cite): one
+ * communicator per process / GPU.  crh_comm_unique_id (rank 0; 128 bytes, hand them to the other ranks out of band)
+ * -> crh_comm_init on every rank (collective) -> the two collectives below, asynchronous on `stream` -> destroy.
+ *   crh_comm_allgather_topk  every rank's (n_users, k) shard lists -> gathered_* laid out [rank][user][k], which is
+ *                            crh_merge_topk's input with n_lists = world (eval over a row-sharded item table)
+ *   crh_comm_allreduce_f32   in-place sum of n floats: the 4 batch sums of crh_bpr_fwd_f32, the dense gradient table
+ * librccl.so is dlopen'ed on first use (an already loaded copy is reused); single-GPU callers never load it.
+ * coldrec_amd's Python host layer issues the same collectives through torch.distributed ("nccl" = RCCL).
+ */
+typedef struct crh_comm crh_comm;
+int crh_comm_unique_id(void* id128_host);
+crh_comm* crh_comm_init(int rank, int world, const void* id128_host);
+int crh_comm_destroy(crh_comm* c);
+int crh_comm_rank(const crh_comm* c);
+int crh_comm_world(const crh_comm* c);
+int crh_comm_allreduce_f32(crh_comm* c, float* buf, int64_t n, void* stream);
+int crh_comm_allgather_topk(crh_comm* c, const float* score, const int32_t* idx, int64_t n_users, int k,
+                            float* gathered_score, int32_t* gathered_idx, void* stream);
 
 /*
  * HOST-side negative sampler reproducing util/utils.py:123-157 (next_batch_pairwise) and NumPy's

@@ -315,6 +315,29 @@ def adam_dense(p, g, m, v, step: int, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     return p, m, v
 
 
+def sgd_dense(p, g, lr=1e-3):
+    """torch.optim.SGD(lr) defaults (no momentum, no weight decay): p <- p + (-lr) * g.  Canonical form of this
+    build: ONE fused multiply-add per element, fma(-lr, g, p), evaluated here in float64 and rounded once (the
+    product of two fp32 values is exact in float64, so this is the correctly rounded fma).  ATen's CPU kernel for
+    param.add_(grad, alpha=-lr) uses a vector fma too; tests/test_oracle_golden.py pins this function to
+    torch.optim.SGD within one fp32 ulp.  (north_star: "BPR loss + SGD update"; SURVEY.md F3: the reference's own
+    trainers use Adam -- this is the extra mode.)"""
+    p64 = np.asarray(p, np.float32).astype(np.float64)
+    g64 = np.asarray(g, np.float32).astype(np.float64)
+    return (p64 + np.float64(np.float32(-lr)) * g64).astype(np.float32)
+
+
+def l2_reg(reg, *embs):
+    """util/utils.py:44-48: reg * sum_e |e|_F / rows(e) and d/de = reg * e / (rows * |e|_F), in float64."""
+    loss, grads = 0.0, []
+    for e in embs:
+        e64 = np.asarray(e, np.float64)
+        nrm = np.sqrt((e64 * e64).sum())
+        loss += nrm / e64.shape[0]
+        grads.append(reg * e64 / (e64.shape[0] * nrm) if nrm > 0 else np.zeros_like(e64))
+    return reg * loss, grads
+
+
 # ----------------------------------------------------------------------------- A5
 def norm_adj_csr(rec_u, rec_i, user_num: int, item_num: int):
     """util/databuilder.py:220-254: A=[[0,R],[R^T,0]], A_hat = D^-1/2 A D^-1/2 in fp32 with

@@ -47,10 +47,11 @@ def l2_reg_loss(reg, *embs):
 class MFPort:
     """model/MF.py:12-29,66-82: two tables, gather by index lists, BPR + L2, dense Adam."""
 
-    def __init__(self, U0: np.ndarray, V0: np.ndarray, lr: float, reg: float):
+    def __init__(self, U0: np.ndarray, V0: np.ndarray, lr: float, reg: float, optimizer: str = "adam"):
         self.U = torch.nn.Parameter(torch.from_numpy(np.array(U0, np.float32)))
         self.V = torch.nn.Parameter(torch.from_numpy(np.array(V0, np.float32)))
-        self.opt = torch.optim.Adam([self.U, self.V], lr=lr)             # MF.py:14
+        # MF.py:14 uses Adam; "sgd" = the north_star's extra mode with the stock optimiser of that name
+        self.opt = (torch.optim.Adam if optimizer == "adam" else torch.optim.SGD)([self.U, self.V], lr=lr)
         self.reg = reg
 
     def step(self, ui, pi, ni) -> float:
@@ -75,11 +76,11 @@ class LGCNPort:
     """model/LightGCN.py:14-29,86-96: full-graph L-layer propagation per batch via
     torch.sparse.mm on the COO adjacency, mean of layer outputs, BPR + L2, dense Adam."""
 
-    def __init__(self, U0, V0, adj: torch.Tensor, n_layers: int, lr: float, reg: float):
+    def __init__(self, U0, V0, adj: torch.Tensor, n_layers: int, lr: float, reg: float, optimizer: str = "adam"):
         self.U = torch.nn.Parameter(torch.from_numpy(np.array(U0, np.float32)))
         self.V = torch.nn.Parameter(torch.from_numpy(np.array(V0, np.float32)))
         self.adj, self.L, self.reg = adj, n_layers, reg
-        self.opt = torch.optim.Adam([self.U, self.V], lr=lr)
+        self.opt = (torch.optim.Adam if optimizer == "adam" else torch.optim.SGD)([self.U, self.V], lr=lr)
 
     def forward(self):
         ego = torch.cat([self.U, self.V], 0)

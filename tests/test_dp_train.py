@@ -15,13 +15,14 @@ import os, sys
 sys.path.insert(0, os.environ["CR_ROOT"])
 import numpy as np, torch
 import torch.distributed as dist
+import coldrec_amd.train as train
 from coldrec_amd.train import DPContext, MFEngine, LGCNEngine
 from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
 from oracle import oracle_np as orc, ref_port
 
 
 class NpKernels:
-    """CPU stand-ins with the signatures of coldrec_amd.ops (tests only)."""
+    """CPU stand-ins with the signatures of coldrec_amd.ops (tests only), assigned to coldrec_amd.train.ops below."""
 
     class SpmmSchedule:
         def __init__(self, rowptr, device):
@@ -61,7 +62,7 @@ class NpKernels:
         return loss_out
 
     @staticmethod
-    def bpr_fwd_bwd(tu, tp, tn, u, p, n, reg, gu, gp, gn, loss_out, plan=None):
+    def bpr_fwd_bwd(tu, tp, tn, u, p, n, reg, gu, gp, gn, loss_out, plan=None, workspace=None):
         ws, sums = {}, torch.zeros(4)
         NpKernels.bpr_fwd(tu, tp, tn, u, p, n, sums, ws)
         return NpKernels.bpr_bwd(tu, tp, tn, u, p, n, u.shape[0], reg, sums, gu, gp, gn, loss_out, ws)
@@ -83,6 +84,7 @@ class NpKernels:
             acc_out.copy_((base + P) * s_out)
 
 
+train.ops = NpKernels                                # the seam: the engines call whatever train.ops is (tests only)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 rng = np.random.default_rng(7)                      # same stream on every rank: replicated sampler
@@ -97,10 +99,10 @@ torch.set_num_threads(1)
 
 for name in ("mf", "lgcn"):
     if name == "mf":
-        eng = MFEngine(U0, V0, 1e-2, 1e-3, "cpu", kernels=NpKernels)
+        eng = MFEngine(U0, V0, 1e-2, 1e-3, "cpu")
         port = ref_port.MFPort(U0, V0, 1e-2, 1e-3)
     else:
-        eng = LGCNEngine(U0, V0, rowptr, col, val, 2, 1e-2, 1e-3, "cpu", kernels=NpKernels)
+        eng = LGCNEngine(U0, V0, rowptr, col, val, 2, 1e-2, 1e-3, "cpu")
         port = ref_port.LGCNPort(U0, V0, ref_port.coo_adj(rowptr, col, val), 2, 1e-2, 1e-3)
     eng.enable_data_parallel(DPContext(world, rank))
     for (u, i, j) in tri:

@@ -153,6 +153,7 @@ _GLOO_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["CR_ROOT"])
+import coldrec_amd.eval as ev
 from coldrec_amd.eval import ShardedTopK, shard_bounds
 from oracle import oracle_np as orc
 
@@ -166,6 +167,10 @@ def merge(gs, gi, k):
     s, i = orc.merge_topk(gs.numpy(), gi.numpy(), k)
     return torch.from_numpy(s), torch.from_numpy(i)
 
+class OracleOps:                 # the seam: eval.py calls whatever eval.ops is (tests only)
+    score_topk = staticmethod(local_topk)
+    merge_topk = staticmethod(merge)
+ev.ops = OracleOps
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 rng = np.random.default_rng(0)
@@ -177,13 +182,13 @@ rp = torch.from_numpy(np.concatenate([[0], np.cumsum([len(r) for r in rated])]).
 rc = torch.from_numpy(np.concatenate(rated).astype(np.int32))
 bm = torch.from_numpy(orc.make_bitmap(n_items, np.where(rng.random(n_items) < 0.2)[0]).view(np.int32))
 lo, hi = shard_bounds(n_items, world, rank)
-eng = ShardedTopK(V[lo:hi], lo, n_items, k, world, rank, local_topk=local_topk, merge=merge)
+eng = ShardedTopK(V[lo:hi], lo, n_items, k, world, rank)
 s, i = eng.topk(U, None, rp, rc, bm)
 ws, wi = local_topk(U, None, V, k, rp, rc, bm)
 assert torch.equal(i, wi) and torch.equal(s.view(torch.int32), ws.view(torch.int32)), rank
 # user-sharded alternative: replicated items, users cut across the ranks (uneven: 37 users on 2 ranks)
 from coldrec_amd.eval import UserShardedTopK
-ueng = UserShardedTopK(V, k, world, rank, local_topk=local_topk)
+ueng = UserShardedTopK(V, k, world, rank)
 users_all = torch.arange(37, dtype=torch.int32)
 s2, i2 = ueng.topk(U, users_all, rp, rc, bm)
 assert torch.equal(i2, wi) and torch.equal(s2.view(torch.int32), ws.view(torch.int32)), ("user-sharded", rank)
