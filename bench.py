@@ -12,6 +12,13 @@ at 8 GPUs").  Inputs are resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 4 --warmup 1
 
+The default N=1 run also carries every other leg the design claims, in the same JSON line (each with its own
+``roofline``): ``eval_f16`` (configs[4] shape, fp16 MFMA), ``mask_topk`` (dense-block ranking, HBM-bound), ``train_xl``
+(S-TRAIN-XL dense Adam, HBM-bound), ``train_mf`` / ``train_mf_sgd`` / ``train_lightgcn`` (configs[1] / [2], with
+``value_end_to_end`` = triples per wall second over whole epochs WITH the sampler running) and the per-epoch validation
+ranking; after the timed region 8 users of the last headline step are re-ranked by the CPU oracle and must match bit
+for bit (``verified_users``; a mismatch ends the run with a non-zero exit code).
+
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (score_topk_kernel):
 achieved = 2*d flop per (user,item) pair x pairs per launch / average kernel time measured with
 HIP events recorded around that kernel on its stream.  ``cpu_baseline`` is the reference path
@@ -87,23 +94,59 @@ def rated_lists(n_users, n_items, mean_len, seed):
     return rowptr, (key & 0xFFFFFFFF).astype(np.int32)
 
 
-def cpu_baseline(U_cpu, V_cpu, rowptr, col, cold_ids, k, reps):
-    """oracle/ref_port.eval_block (the reference's own library calls) on the host cores."""
+def cpu_baseline(U_cpu, V_cpu, rowptr, col, cold_ids, k, block=256, budget_s=75.0):
+    """oracle/ref_port.eval_block (the reference's own library calls: torch.matmul -> masks -> torch.topk) on the host
+    cores: user blocks of ``block`` (the reference's 4096 would need a 164 GB score block at 10 M items, SURVEY.md
+    8(d)) against the WHOLE item table, until every sampled user is ranked or the time budget is spent.
+    Returns (items/s, users ranked, seconds)."""
     from oracle import ref_port
     torch.set_num_threads(os.cpu_count())
-    users = torch.arange(U_cpu.shape[0])
-    rated = []
-    for r in range(U_cpu.shape[0]):
-        ids = col[rowptr[r]:rowptr[r + 1]]
-        ids = ids[ids < V_cpu.shape[0]]
-        rated.append(torch.from_numpy(ids.astype(np.int64)) if len(ids) else None)
     cand = torch.from_numpy(cold_ids[cold_ids < V_cpu.shape[0]].astype(np.int64))
-    ref_port.eval_block(U_cpu[:8], V_cpu, users[:8], rated[:8], cand, k)   # touch pages / warm MKL
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ref_port.eval_block(U_cpu, V_cpu, users, rated, cand, k)
-    dt = (time.perf_counter() - t0) / reps
-    return U_cpu.shape[0] * V_cpu.shape[0] / dt
+
+    def rated_of(lo, hi):
+        out = []
+        for r in range(lo, hi):
+            ids = col[rowptr[r]:rowptr[r + 1]]
+            ids = ids[ids < V_cpu.shape[0]]
+            out.append(torch.from_numpy(ids.astype(np.int64)) if len(ids) else None)
+        return out
+
+    ref_port.eval_block(U_cpu[:8], V_cpu, torch.arange(8), rated_of(0, 8), cand, k)   # touch pages / warm MKL
+    done, t0 = 0, time.perf_counter()
+    while done < U_cpu.shape[0]:
+        hi = min(done + block, U_cpu.shape[0])
+        ref_port.eval_block(U_cpu, V_cpu, torch.arange(done, hi), rated_of(done, hi), cand, k)
+        done = hi
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done * V_cpu.shape[0] / dt, done, dt
+
+
+def verify_users(tag, got_s, got_i, users_rows, U_cpu, V_cpu, rowptr_blk, col_blk, cold_ids, k, n_check=8, seed=123):
+    """Self-check of a timed step: ``n_check`` users of the block re-ranked by the CPU oracle (oracle/topk_oracle.c,
+    the canonical fma chain and order) must equal what the kernel returned, scores and indices, bit for bit.
+    got_s / got_i: (block, k) host arrays; users_rows: table rows of the block's slots; rowptr_blk / col_blk: the
+    block's rated CSR.  Raises SystemExit(3) on a mismatch -- a fast wrong kernel must not produce a number."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_np as orc
+    rng = np.random.default_rng(seed)
+    slots = np.sort(rng.choice(got_i.shape[0], size=min(n_check, got_i.shape[0]), replace=False))
+    bm = orc.make_bitmap(V_cpu.shape[0], cold_ids) if cold_ids is not None and len(cold_ids) else None
+
+    def one(sl):
+        lo, hi = int(rowptr_blk[sl]), int(rowptr_blk[sl + 1])
+        rp = np.array([0, hi - lo], np.int64)
+        return orc.score_topk(U_cpu[users_rows[sl]:users_rows[sl] + 1], None, V_cpu, k, rp, col_blk[lo:hi], bm)
+
+    with ThreadPoolExecutor(max_workers=min(len(slots), os.cpu_count() or 1)) as ex:       # ctypes releases the GIL
+        want = list(ex.map(one, slots.tolist()))
+    for sl, (ws, wi) in zip(slots.tolist(), want):
+        if not (np.array_equal(got_i[sl], wi[0]) and np.array_equal(got_s[sl].view(np.uint32), ws[0].view(np.uint32))):
+            print(json.dumps({"error": "%s: kernel result differs from the oracle for block slot %d" % (tag, sl),
+                              "got_idx": got_i[sl].tolist(), "want_idx": wi[0].tolist()}), flush=True)
+            raise SystemExit(3)
+    return len(slots)
 
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -169,39 +212,50 @@ def validation_eval_leg(dev):
     return {"eval_validation": out}
 
 
-def train_legs(dev, with_cpu):
-    """Secondary metric of BASELINE.json: BPR triples/s (train), configs[1] (BPR-MF, MovieLens shape,
-    d=128) and configs[2] (LightGCN L=3, CiteULike shape, d=128), one epoch each, triples pre-sampled
-    by the host sampler and resident in HBM; Adam dense as in the reference."""
+def train_legs(dev, with_cpu, e2e_epochs=5):
+    """Secondary metric of BASELINE.json: BPR triples/s (train): configs[1] (BPR-MF, MovieLens shape, d=128) with
+    Adam as the reference and with plain SGD (the north_star's "BPR loss + SGD update"), configs[2] (LightGCN L=3,
+    CiteULike shape, d=128).  Two numbers per leg:
+      value             one epoch of optimiser steps with the triples already in HBM (kernel-side rate; the roofline
+                        refers to it)
+      value_end_to_end  whole epochs as the trainers run them -- NumPy-stream-exact sampler (A1)
+                        producing epoch e+1 while epoch e trains, upload, reverse index, optimiser steps -- triples
+                        per wall second over ``e2e_epochs`` epochs (the reference's timing point, main.py:179-187,
+                        without the validation pass)."""
     from coldrec_amd.data.synth import make_dataset
-    from coldrec_amd.sampler import PairwiseSampler
-    from coldrec_amd.train import LGCNEngine, MFEngine
+    from coldrec_amd.sampler import EpochPrefetcher, PairwiseSampler
+    from coldrec_amd.train import EpochRunner, LGCNEngine, MFEngine
+    from coldrec_amd.ops import mf_step_parts as ops_parts
+    from coldrec_amd import ops as _ops
     from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
     out = {}
     B, d = 4096, 128
-    for name, shape, layers in (("train_mf", "movielens", 0), ("train_lightgcn", "citeulike", 3)):
-        split = make_dataset(shape, "item", seed=1 if layers == 0 else 2, with_content=False)
-        tr = split.warm_train
-        ukeys, ru = np.unique(tr[:, 0], return_inverse=True)
-        ikeys, ri = np.unique(tr[:, 1], return_inverse=True)
-        n_u, n_i, n = split.user_num, split.item_num, tr.shape[0]
-        t0 = time.perf_counter()
+    data_cache = {}
+    for name, shape, layers, optim in (("train_mf", "movielens", 0, "adam"), ("train_mf_sgd", "movielens", 0, "sgd"),
+                                       ("train_lightgcn", "citeulike", 3, "adam")):
+        if shape not in data_cache:
+            split = make_dataset(shape, "item", seed=1 if layers == 0 else 2, with_content=False)
+            tr = split.warm_train
+            _, ru = np.unique(tr[:, 0], return_inverse=True)
+            _, ri = np.unique(tr[:, 1], return_inverse=True)
+            data_cache[shape] = (split.user_num, split.item_num, tr.shape[0], ru, ri)
+        n_u, n_i, n, ru, ri = data_cache[shape]
         smp = PairwiseSampler(ru, ri, n_u, n_i)
         smp.seed(2024)
         u, i, j = smp.epoch(B)
-        t_sample = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        smp.epoch(B)
+        t_sample = time.perf_counter() - t0                        # one epoch of triples, one host call, on its own
         g = torch.Generator().manual_seed(2024)
         U0 = torch.nn.init.xavier_uniform_(torch.empty(n_u, d), generator=g)
         V0 = torch.nn.init.xavier_uniform_(torch.empty(n_i, d), generator=g)
         if layers:
             rowptr, col, val = bipartite_norm_adj_csr(ru, ri, n_u, n_i)
-            eng = LGCNEngine(U0, V0, rowptr, col, val, layers, 1e-3, 1e-4, dev)
+            eng = LGCNEngine(U0, V0, rowptr, col, val, layers, 1e-3, 1e-4, dev, optimizer=optim)
         else:
-            eng = MFEngine(U0, V0, 1e-3, 1e-4, dev)
+            eng = MFEngine(U0, V0, 1e-3, 1e-4, dev, optimizer=optim)
         tu, ti, tj = (torch.from_numpy(x).to(dev) for x in (u, i, j))
         steps = [(lo, min(lo + B, n)) for lo in range(0, n, B)]
-        from coldrec_amd.train import EpochRunner
-        from coldrec_amd.ops import mf_step_parts as ops_parts
         runner = EpochRunner(eng, n, B)
         runner.run(tu, ti, tj)            # eager warm-up epoch
         runner.run(tu, ti, tj)            # captured into a hipGraph
@@ -211,42 +265,54 @@ def train_legs(dev, with_cpu):
         torch.cuda.synchronize()
         sec = (time.perf_counter() - t0) / len(steps)
         t0 = time.perf_counter()
-        from coldrec_amd import ops as _ops
         _ops.build_plans_device(tu, ti, tj, B)
         torch.cuda.synchronize()
         t_plans = time.perf_counter() - t0
+        # ---- end to end: sampler + prefetch + upload + plans + steps, as model/MF.py's epoch loop runs them
+        np.random.seed(2024)
+        pref = EpochPrefetcher(smp, B)
+        runner.run(*pref.get())                                       # starts the speculation on the next epoch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(e2e_epochs):
+            runner.run(*pref.get())
+        torch.cuda.synchronize()
+        sec_e2e = (time.perf_counter() - t0) / e2e_epochs
+        pref.close()
         N, nnz = n_u + n_i, (len(val) if layers else 0)
-        bytes_step = 24 * d * B + 32 * N * d                          # MF step
+        opt_bytes = 8 if optim == "sgd" else 32                        # dense Adam moves 32 B per element;
+        bytes_step = 24 * d * B + opt_bytes * N * d                    # plain SGD reads and writes the parameter only
         if layers:                                                     # + 2L SpMM + layer mean fwd/bwd + dOUT zero
             bytes_step += 2 * layers * (nnz * 8 + (N + 1) * 8 + 2 * N * d * 4) + 2 * (layers + 2) * N * d * 4
         leg = {"metric": "BPR triples/sec (train)", "value": B / sec * (n / (len(steps) * B)), "unit": "triples/s",
+               "value_end_to_end": n / sec_e2e, "ms_per_epoch_end_to_end": sec_e2e * 1e3, "end_to_end_epochs": e2e_epochs,
                "ms_per_step": sec * 1e3, "steps_per_epoch": len(steps),
                "config": {"workload": "configs[%d] %s, %s-shaped synthetic (%d users x %d items, %d train triples), "
-                                      "d=%d, B=%d, dense Adam" % (2 if layers else 1, "LightGCN L=3" if layers else "BPR-MF",
-                                                                  shape, n_u, n_i, n, d, B)},
+                                      "d=%d, B=%d, %s" % (2 if layers else 1, "LightGCN L=3" if layers else "BPR-MF",
+                                                          shape, n_u, n_i, n, d, B,
+                                                          "plain SGD (torch.optim.SGD defaults)" if optim == "sgd" else "dense Adam")},
                "host_sampler_s_per_epoch": t_sample, "device_plan_s_per_epoch": t_plans,
                "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                             "traffic": None, "note": "whole step (all kernels of one optimiser step)"}}
         # fabric-side bytes per launch of the step's dominant kernel from the committed PMC record (same kernel, same grid)
+        tr = None
         if layers:
             tr = measured_traffic("spmm_csr_kernel<8>", None)
-            if tr:
-                leg["roofline"].update({"traffic": tr[0], "traffic_note": "spmm_csr_kernel<8> (FETCH_SIZE x2 + WRITE_SIZE) per "
-                                        "launch from %s; a step has %d such launches" % (tr[1], 2 * layers)})
+            what = "spmm_csr_kernel<8> (FETCH_SIZE x2 + WRITE_SIZE) per launch; a step has %d such launches" % (2 * layers)
         elif getattr(eng, "fused", False):
-            tr = measured_traffic("mf_step_kernel<32>", float(ops_parts(n_u + n_i, d) * 256))
-            if tr:
-                leg["roofline"].update({"traffic": tr[0], "traffic_note": "mf_step_kernel<32> = the whole step (FETCH_SIZE x2 + "
-                                        "WRITE_SIZE) from %s; it moves 24 B per element of optimiser state, not the 32 of "
-                                        "the formula (no gradient table)" % tr[1]})
+            tr = measured_traffic("mf_step_kernel<32, %d>" % (1 if optim == "sgd" else 0), float(ops_parts(n_u + n_i, d) * 256))
+            what = "mf_step_kernel<32> = the whole step (FETCH_SIZE x2 + WRITE_SIZE); it keeps no gradient table"
+        if tr:
+            leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1], "traffic_note": what})
         if with_cpu:
             from oracle import ref_port
 
             def make_port():
                 if layers:
-                    return ref_port.LGCNPort(U0.numpy(), V0.numpy(), ref_port.coo_adj(rowptr, col, val), layers, 1e-3, 1e-4)
-                return ref_port.MFPort(U0.numpy(), V0.numpy(), 1e-3, 1e-4)
+                    return ref_port.LGCNPort(U0.numpy(), V0.numpy(), ref_port.coo_adj(rowptr, col, val), layers, 1e-3, 1e-4,
+                                             optimizer=optim)
+                return ref_port.MFPort(U0.numpy(), V0.numpy(), 1e-3, 1e-4, optimizer=optim)
 
             def cpu_steps(port, count):
                 t0 = time.perf_counter()
@@ -267,16 +333,140 @@ def train_legs(dev, with_cpu):
             torch.set_num_threads(best[1])
             port = make_port()
             cpu_steps(port, 1)
-            n_cpu = int(max(2, min(60, 8.0 / best[0])))
+            n_cpu = int(max(2, min(60, 6.0 / best[0])))
             dt = cpu_steps(port, n_cpu)
             torch.set_num_threads(os.cpu_count())
             leg["cpu_baseline"] = {"value": B / dt, "unit": "triples/s", "cores": best[1], "kind": "port",
-                                   "sample": "%d optimiser steps of the same epoch (torch autograd + Adam%s) on %d threads "
-                                             "(best of 8/32/all), sampler excluded"
-                                             % (n_cpu, ", torch.sparse.mm COO" if layers else "", best[1])}
+                                   "sample": "%d optimiser steps of the same epoch (torch autograd + torch.optim.%s%s) on %d "
+                                             "threads (best of 8/32/all), sampler excluded"
+                                             % (n_cpu, "SGD" if optim == "sgd" else "Adam",
+                                                ", torch.sparse.mm COO" if layers else "", best[1])}
         out[name] = leg
-        del eng
+        del eng, runner
     return out
+
+
+def eval_f16_leg(dev, steps=3, warmup=1, n_items=50_000_000, d=256, Bu=131072, k=20):
+    """BASELINE.json configs[4] at its largest single-GPU shape: 131 072 users ranked against 50 M generated-style fp16
+    item embeddings, d=256 (crh_score_topk_f16_ex: v_mfma_f32_32x32x16_f16, fp32 accumulate), masks as in the headline.
+    Roofline vs the dense fp16 MFMA peak (2.5 PF).  Self-check: 4 users re-scored by a plain PyTorch fp32 matmul over
+    the same fp16 tables (the float-kernel reference), scores within 1e-3 relative + 1e-5 and every returned id in the
+    reference list or tied with its k-th score within that tolerance."""
+    from coldrec_amd import ops
+    V = item_shard(n_items, d, 0, n_items, dev, torch.float16)
+    n_blocks = 2
+    U = xavier_(Bu * n_blocks, d, 17, dev, 1_000_000).to(torch.float16)
+    rowptr, col = rated_lists(Bu * n_blocks, n_items, 50, seed=4)
+    cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
+    bitmap = ops.make_bitmap(n_items, cold, dev)
+    blocks = []
+    for b in range(n_blocks):
+        u0 = b * Bu
+        blocks.append((torch.arange(u0, u0 + Bu, dtype=torch.int32, device=dev),
+                       torch.from_numpy(rowptr[u0:u0 + Bu + 1] - rowptr[u0]).to(dev),
+                       torch.from_numpy(col[rowptr[u0]:rowptr[u0 + Bu]]).to(dev)))
+    events = HipEvents(steps)
+    for w in range(warmup):
+        ops.score_topk(U, *blocks[w % n_blocks][:1], V, k, *blocks[w % n_blocks][1:], bitmap)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        users, rp, rc = blocks[(warmup + s_) % n_blocks]
+        out = ops.score_topk(U, users, V, k, rp, rc, bitmap, kernel_events=events.pairs[s_])
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    kern_ms = float(np.mean(events.elapsed_ms()))
+    flops = 2.0 * d * Bu * n_items
+    # ---- self-check on 4 users of the last block against torch fp32 over the same fp16 inputs
+    b_last = (warmup + steps - 1) % n_blocks
+    users, rp, rc = blocks[b_last]
+    rng = np.random.default_rng(9)
+    slots = np.sort(rng.choice(Bu, 4, replace=False))
+    uu = U[users[torch.from_numpy(slots).to(dev)].long()].float()
+    best_s = torch.full((4, k + 8), -float("inf"), device=dev)
+    best_i = torch.zeros((4, k + 8), dtype=torch.int64, device=dev)
+    cold_t = torch.from_numpy(cold).to(dev)
+    rp_h, rc_h = rp.cpu().numpy(), rc.cpu().numpy()
+    for lo in range(0, n_items, 2_500_000):
+        hi = min(lo + 2_500_000, n_items)
+        S = uu @ V[lo:hi].float().T
+        cm = cold_t[(cold_t >= lo) & (cold_t < hi)] - lo
+        S[:, cm] = -1e9
+        for q, sl in enumerate(slots.tolist()):
+            ids = rc_h[rp_h[sl]:rp_h[sl + 1]]
+            ids = ids[(ids >= lo) & (ids < hi)] - lo
+            if len(ids):
+                S[q, torch.from_numpy(ids.astype(np.int64)).to(dev)] = -1e9
+        cs, ci = torch.topk(S, k + 8, dim=1)
+        ms, mi = torch.topk(torch.cat([best_s, cs], 1), k + 8, dim=1)
+        best_i = torch.gather(torch.cat([best_i, ci + lo], 1), 1, mi)
+        best_s = ms
+        del S
+    gs, gi = out[0][torch.from_numpy(slots).to(dev)].cpu().numpy(), out[1][torch.from_numpy(slots).to(dev)].cpu().numpy()
+    rs, ri = best_s.cpu().numpy(), best_i.cpu().numpy()
+    for q in range(4):
+        tol = 1e-3 * np.abs(rs[q, :k]) + 1e-5
+        ref_of = dict(zip(ri[q].tolist(), rs[q].tolist()))
+        ok = all((int(g) in ref_of and abs(ref_of[int(g)] - float(sg)) <= 1e-3 * abs(float(sg)) + 1e-5)
+                 for g, sg in zip(gi[q], gs[q]))
+        ok = ok and np.all(np.abs(np.sort(gs[q])[::-1] - rs[q, :k]) <= tol)
+        if not ok:
+            print(json.dumps({"error": "eval_f16: kernel result outside tolerance of the fp32 reference, slot %d" % slots[q],
+                              "got": gi[q].tolist(), "ref": ri[q, :k].tolist()}), flush=True)
+            raise SystemExit(3)
+    leg = {"metric": "ranked items/sec (full-catalogue eval)", "value": Bu * n_items / sec, "unit": "items/s",
+           "ms_per_step": sec * 1e3, "steps": steps, "dtype": "f16", "verified_users": 4,
+           "config": {"workload": "configs[4] shape on one GPU: %d users x %d items per step, d=%d, k=%d, fp16 tables / fp32 "
+                                  "accumulate, rated CSR + 20%% cold-item bitmap" % (Bu, n_items, d, k)},
+           "roofline": {"bound": "mfma", "kernel": "score_topk_wg_kernel<f16,%d>" % d, "achieved": flops / (kern_ms * 1e-3) / 1e12,
+                        "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, "kernel_ms": kern_ms,
+                        "flops_per_launch": flops, "traffic": None}}
+    del V, U, out
+    return {"eval_f16": leg}
+
+
+def mask_topk_leg(dev, n_users=4096, n_items=1_000_000, k=20, reps=5):
+    """crh_mask_topk_f32 on a dense (4096 x 1 M) fp32 score block: the ranking path of every plugin whose batch_predict is
+    not the stock matmul (model/VBPR.py:68-75, ALDI.py:149-160).  HBM-bound: 4 bytes per pair (one streaming read);
+    with write-back (the reference mutates the block) the masked 16-byte vectors are stored too."""
+    from coldrec_amd import ops
+    from oracle import oracle_np as orc
+    S = torch.randn(n_users, n_items, device=dev)
+    rowptr, col = rated_lists(n_users, n_items, 50, seed=4)
+    rp, rc = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+    cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
+    bm = ops.make_bitmap(n_items, cold, dev)
+    ms = {}
+    for wb in (False, True):
+        for _ in range(2):
+            out = ops.mask_topk(S, k, rp, rc, bm, write_back=wb)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = ops.mask_topk(S, k, rp, rc, bm, write_back=wb)
+        e1.record()
+        torch.cuda.synchronize()
+        ms[wb] = e0.elapsed_time(e1) / reps
+        if not wb:                                           # self-check before the block is mutated: 3 rows vs the oracle
+            rows = [0, n_users // 2, n_users - 1]
+            for r in rows:
+                ws, wi = orc.mask_topk(S[r:r + 1].cpu().numpy(), k, np.array([0, rowptr[r + 1] - rowptr[r]], np.int64),
+                                       col[rowptr[r]:rowptr[r + 1]], orc.make_bitmap(n_items, cold))
+                if not (np.array_equal(out[1][r].cpu().numpy(), wi[0]) and
+                        np.array_equal(out[0][r].cpu().numpy().view(np.uint32), ws[0].view(np.uint32))):
+                    print(json.dumps({"error": "mask_topk: row %d differs from the oracle" % r}), flush=True)
+                    raise SystemExit(3)
+    byts = n_users * n_items * 4.0
+    leg = {"metric": "ranked items/sec (dense score block)", "value": n_users * n_items / (ms[False] * 1e-3), "unit": "items/s",
+           "ms": ms[False], "ms_with_write_back": ms[True], "verified_users": 3,
+           "config": {"workload": "crh_mask_topk_f32: %d x %d fp32 score block, k=%d, rated CSR + 20%% bitmap" % (n_users, n_items, k)},
+           "roofline": {"bound": "hbm", "kernel": "mask_topk_kernel<1>", "achieved": byts / (ms[False] * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / (ms[False] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "bytes_per_launch": byts, "traffic": None}}
+    del S
+    return {"mask_topk": leg}
 
 
 def train_dp_leg(dev, world, rank):
@@ -400,7 +590,8 @@ def train_xl(dev, steps, warm, lazy=False):
         out["roofline"] = {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                            "traffic": tr[0] if tr else None,
-                           "traffic_note": ("adam_dense_kernel FETCH_SIZE x2 + WRITE_SIZE per launch from %s" % tr[1]) if tr else None}
+                           "traffic_source": ("committed profile " + tr[1]) if tr else None,
+                           "traffic_note": "adam_dense_kernel FETCH_SIZE x2 + WRITE_SIZE per launch" if tr else None}
     return out
 
 
@@ -435,8 +626,12 @@ def main():
     ap.add_argument("--train-xl", action="store_true",
                     help="only run the S-TRAIN-XL roofline case of SURVEY.md 8(d) (1M users x 10M items, d=128, "
                          "B=65536 MF steps; 22.5 GB of state) and print its JSON line")
-    ap.add_argument("--cpu-sample-users", type=int, default=256)
-    ap.add_argument("--cpu-sample-items", type=int, default=2_500_000)
+    ap.add_argument("--cpu-sample-users", type=int, default=2048,
+                    help="users of the CPU baseline (blocks of 256 against the WHOLE item table, SURVEY.md 8(d))")
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="the CPU baseline stops after this many seconds")
+    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train,eval_validation",
+                    help="N=1: secondary legs carried in the same JSON line (comma separated; 'none' = headline only)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the last timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -569,24 +764,47 @@ def main():
             tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8>", float(64 * ((groups + 7) // 8) * 8))
         if tr:
             result["roofline"]["traffic"] = tr[0]
+            result["roofline"]["traffic_source"] = "committed profile " + tr[1]
             result["roofline"]["traffic_note"] = ("L2-miss (fabric-side) bytes per launch from %s; mostly served by the "
                                                   "256 MB Infinity Cache, compulsory HBM bytes are %d" % (
                                                       tr[1], (hi - lo) * d * 4 + Bu * d * 4))
 
     if gen_leg is not None and rank == 0:
         result["dropoutnet_generator"] = gen_leg
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        nu, ni = args.cpu_sample_users, min(args.cpu_sample_items, hi - lo)
-        Uc, Vc = U[:nu].float().cpu(), V[:ni].float().cpu()   # the reference scores in fp32 (torch.matmul)
-        rate = cpu_baseline(Uc, Vc, rowptr[:nu + 1], col, cold, k, reps=4)
+    # ---- self-check of the LAST timed step + CPU baseline: both need the tables on the host (rank 0)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_verify = rank == 0 and not args.no_verify and args.shard == "items" and not args.generator
+    U_cpu = V_cpu = None
+    if want_cpu or want_verify:
+        U_cpu = U.float().cpu().numpy()
+        if world == 1:
+            V_cpu = V.float().cpu().numpy()
+        else:   # rank 0 holds one shard: rebuild the whole table chunk by chunk (same seeds as every rank used)
+            V_cpu = np.concatenate([item_shard(I, d, c, min(c + CHUNK_ROWS, I), dev, tdtype).float().cpu().numpy()
+                                    for c in range(0, I, CHUNK_ROWS)])
+    if want_verify and args.dtype == "f32":
+        b_last = args.warmup + args.steps - 1
+        users_last, rp_last, rc_last = blocks[b_last]
+        result["verified_users"] = verify_users(
+            "headline", out[0].cpu().numpy(), out[1].cpu().numpy(), users_last.cpu().numpy().astype(np.int64), U_cpu, V_cpu,
+            rp_last.cpu().numpy() if args.masks != "none" else np.zeros(Bu + 1, np.int64), rc_last.cpu().numpy(),
+            None if args.masks == "none" else cold, k)
+        result["verified_against"] = "oracle/topk_oracle.c (canonical fp32 fma chain, score desc / index asc), bit-exact"
+    if want_cpu:
+        nu = min(args.cpu_sample_users, n_user_rows)
+        rate, done, secs = cpu_baseline(torch.from_numpy(U_cpu[:nu]), torch.from_numpy(V_cpu), rowptr[:nu + 1], col, cold, k,
+                                        block=256, budget_s=args.cpu_budget_s)
         result["cpu_baseline"] = {
             "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d users x first %d items of the same tables, same masks, torch %s matmul+mask+topk, "
-                      "%d threads, 4 reps (~12 s of CPU work)" % (nu, ni, torch.__version__, os.cpu_count())}
+            "sample": "%d users (of %d sampled; blocks of 256, stopped at the %.0f s budget) x the WHOLE %d-item table, same "
+                      "masks, torch %s matmul+mask+topk on %d threads, %.1f s of CPU work"
+                      % (done, nu, args.cpu_budget_s, V_cpu.shape[0], torch.__version__, os.cpu_count(), secs)}
+    del U_cpu, V_cpu
+    legs = [] if args.legs == "none" else [x.strip() for x in args.legs.split(",") if x.strip()]
     if world > 1 and not args.no_train and args.dtype == "f32":
         # Secondary leg.  The headline line must survive it: an exception is caught below, and if a rank gets stuck
-        # in a collective (the others would wait for ever) a watchdog on every rank ends the process after the
-        # deadline -- rank 0 prints the line it has first.
+        # in a collective (the others would wait for ever) a watchdog on every rank prints what it has (rank 0) and
+        # ends the process with a NON-ZERO code, so a stuck RCCL run is never reported as a success.
         import threading
         done = threading.Lock()
 
@@ -594,9 +812,10 @@ def main():
             if not done.acquire(blocking=False):
                 return
             if rank == 0:
-                result["train_mf_dp"] = {"error": "no result within %d s (watchdog)" % args.dp_leg_timeout}
+                result["train_mf_dp"] = {"error": "no result within %d s (watchdog): a rank is stuck in a collective"
+                                                  % args.dp_leg_timeout}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(4)
 
         dog = threading.Timer(args.dp_leg_timeout, bail)
         dog.daemon = True
@@ -611,13 +830,18 @@ def main():
             if rank == 0:
                 result["train_mf_dp"] = {"error": repr(e)[:300]}
         if not done.acquire(blocking=False):   # the watchdog fired while the leg was finishing: it reports and exits
-            time.sleep(3600)
+            os._exit(4)
         dog.cancel()
-    if rank == 0 and world == 1 and not args.no_train and args.dtype == "f32":
-        del V, U, engine
+    if rank == 0 and world == 1 and not args.no_train and args.dtype == "f32" and legs:
+        del V, U, engine, blocks, out
         torch.cuda.empty_cache()
-        result.update(train_legs(dev, not args.no_cpu_baseline))
-        result.update(validation_eval_leg(dev))
+        for leg_name, fn in (("eval_f16", lambda: eval_f16_leg(dev)), ("mask_topk", lambda: mask_topk_leg(dev)),
+                             ("train_xl", lambda: {"train_xl": train_xl(dev, 3, 1)}),
+                             ("train", lambda: train_legs(dev, not args.no_cpu_baseline)),
+                             ("eval_validation", lambda: validation_eval_leg(dev))):
+            if leg_name in legs:
+                result.update(fn())
+                torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
