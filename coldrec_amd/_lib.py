@@ -117,7 +117,7 @@ class SpmmSched(ctypes.Structure):
     """crh_spmm_sched of include/coldrec_hip.h."""
     _fields_ = [("seg_row", _vp), ("seg_ptr", _vp), ("seg_slot", _vp), ("n_seg", _i64),
                 ("multi_row", _vp), ("multi_first", _vp), ("multi_count", _vp), ("n_multi", _i32),
-                ("n_partial", _i64), ("nnz", _i64)]
+                ("n_partial", _i64), ("nnz", _i64), ("seg_desc", _vp)]
 
 
 class DSamplerIO(ctypes.Structure):

@@ -162,9 +162,22 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
         // rows_per_group work items per lane group, a whole "grid" apart: with the schedule's descending-length order a
         // long row is paired with a short one, and fewer, fully resident workgroups replace a second round of them
         for (int64_t w = j * (256 / G) + threadIdx.x / G; w < n_work; w += a.light_blocks * (256 / G)) {
-            if (seg && a.sched.seg_slot[w] >= 0) continue;        // a heavy row: done below
-            const int64_t row = seg ? a.sched.seg_row[w] : w;
-            const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];   // a light work item is a whole row
+            int64_t row, e0, e1;
+            if (seg && a.sched.seg_desc) {
+                // ONE 16-byte descriptor per work item instead of three dependent loads (seg_row / seg_slot, then
+                // rowptr[row], rowptr[row + 1]): tools/probes/spmm_steps_probe.hip prices the schedule indirection at
+                // 2.4 us and the rowptr reads at 1.0 us of a 15 us launch
+                const i32x4 dsc = reinterpret_cast<const i32x4*>(a.sched.seg_desc)[w];
+                if (dsc.w >= 0) continue;                             // a heavy row: done below
+                row = dsc.x;
+                e0 = dsc.y;
+                e1 = e0 + dsc.z;
+            } else {
+                if (seg && a.sched.seg_slot[w] >= 0) continue;        // a heavy row: done below
+                row = seg ? a.sched.seg_row[w] : w;
+                e0 = a.rowptr[row];
+                e1 = a.rowptr[row + 1];                               // a light work item is a whole row
+            }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             row_edges<G>(a, e0, e1, c, on, lig, acc);
             if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
@@ -172,7 +185,9 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
         return;
     }
     // heavy rows: one block per (row, slice); the NGB lane groups of the block split the row's edge list;
-    // partial sums meet in a fixed order: shuffle tree inside a wave, then the 4 waves through LDS
+    // partial sums meet in a fixed order: shuffle tree inside a wave, then the 4 waves through LDS.  (One WAVE per
+    // heavy row of up to 256 / 512 / 1024 edges instead, four rows per block, measured no gain: LightGCN step 158.7 ->
+    // 159.4 / 161.8 / 165.7 us.)
     __shared__ f32x4 wsum[4][G];
     const int64_t m = j - a.light_blocks;
     if (m >= a.sched.n_multi || (CRH_ABLATE(a.skip) & 1)) return;
@@ -271,9 +286,12 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
         CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "%s: incomplete schedule", who);
         CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "%s: incomplete schedule (heavy rows)", who);
         a.sched = *sched;
+        static const int use_desc = getenv("CRH_SPMM_DESC") ? atoi(getenv("CRH_SPMM_DESC")) : 1;
+        if (!use_desc) a.sched.seg_desc = nullptr;
     } else {
         a.sched.n_seg = 0;
         a.sched.n_multi = 0;
+        a.sched.seg_desc = nullptr;
     }
     // column slices: as few as make one slice of the dense operand fit an XCD's L2 (leaving room for the
     // edge stream), at most 4, and only while a slice keeps >= 4 lanes (64 B) per row

@@ -519,14 +519,20 @@ class SpmmSchedule:
         multi_count = (-(-deg[heavy] // seg)).astype(np.int32)
         multi_first = np.zeros(len(multi_row) + 1, np.int64)
         np.cumsum(multi_count, out=multi_first[1:])
+        # one 16-byte descriptor per work item: {row, first edge, edges, slot}
+        desc = None
+        if len(deg) and int(rp[-1]) < (1 << 31):
+            desc = np.stack([seg_row, rp[:-1][order].astype(np.int32), deg[order].astype(np.int32), seg_slot], 1)
+            desc = np.ascontiguousarray(desc.astype(np.int32).reshape(-1))
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.t = (to(seg_row), to(seg_ptr), to(seg_slot), to(multi_row), to(multi_first[:-1].astype(np.int32)),
                   to(multi_count))
+        self.desc = to(desc) if desc is not None else None
         self.c = _lib.SpmmSched(_lib.ptr(self.t[0]), _lib.ptr(self.t[1]), _lib.ptr(self.t[2]), len(seg_row),
                                 _lib.ptr(self.t[3]) if len(multi_row) else None,
                                 _lib.ptr(self.t[4]) if len(multi_row) else None,
                                 _lib.ptr(self.t[5]) if len(multi_row) else None, len(multi_row),
-                                int(multi_first[-1]), int(rp[-1]))
+                                int(multi_first[-1]), int(rp[-1]), _lib.ptr(self.desc))
         self.n_partial = int(multi_first[-1])
         self.n_seg = len(seg_row)
         self._ws = {}

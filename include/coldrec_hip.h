@@ -252,6 +252,9 @@ typedef struct {
     int32_t n_multi;
     int64_t n_partial;
     int64_t nnz;
+    /* optional (NULL = absent): seg_desc[w] = {row, first edge, edges, slot} as four int32 -- the work item, its edge
+     * range and its class in ONE 16-byte load instead of three dependent ones (needs nnz < 2^31) */
+    const int32_t* seg_desc;
 } crh_spmm_sched;
 int crh_spmm_segment_edges(void);
 size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d);
