@@ -1,8 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_train_gpu.py tests/test_e2e_gpu.py -x -q -k "spmm or lgcn or lightgcn or fsgnn or plugin" > gpurun_out/r02_spmm_b.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/r02_spmm_b.log
-tail -5 gpurun_out/r02_spmm_b.log
-python tools/lgcn_sweep.py CRH_SPMM_DESC=0,1 CRH_SPMM_WAVE=0,256,512,1024 2>&1 | tee gpurun_out/r02_lgcn_sweep.log
-python tools/spmm_shape_probe.py 2>&1 | tee -a gpurun_out/r02_lgcn_sweep.log
+python tools/mask_topk_probe2.py 2>&1 | grep -v amdgpu | tee gpurun_out/r02_mask_probe2.log
+python tools/mask_topk_probe.py 2>&1 | grep mask_topk | tee -a gpurun_out/r02_mask_probe2.log
+timeout 900 python -m pytest tests/test_score_topk_gpu.py tests/test_round2_gpu.py tests/test_e2e_gpu.py -x -q 2>&1 | grep -v -i -E "rccl|amdgpu|^$" | tail -5
