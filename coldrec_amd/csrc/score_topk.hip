@@ -239,7 +239,8 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
         }
     }
     const int my = ucol0 + (lane & 31);
-    tau_reg = wave_list_tau(w.ls + my * K, w.cnt[my], K);
+    // a padding column (slot past the block) never takes a candidate: +inf keeps it out of the threshold ballot
+    tau_reg = slot0 + (lane & 31) < a.n_users ? wave_list_tau(w.ls + my * K, w.cnt[my], K) : __builtin_inff();
 }
 
 // Soft lockstep of the waves of one XCD.  Every wave streams the same item tiles, but left alone the waves
@@ -319,6 +320,9 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
         int64_t slot = ug * UPW + 32 * u + i;
+        // padding columns of the last group: duplicate the last user, threshold +inf (with -inf every tile of the
+        // wave would enter the slow path to find nothing: 100 000 users ran 2.2x slower than 131 072)
+        tau[u] = slot < a.n_users ? CRH_NEG_INF : __builtin_inff();
         if (slot >= a.n_users) slot = a.n_users - 1;
         const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
         const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
@@ -327,7 +331,6 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             b[q][u] = load16(up + 32 * q);
             if constexpr (SWAP) chunk_swap(b[q][u]);
         }
-        tau[u] = CRH_NEG_INF;
     }
 
     // ---- item range of this split, in tiles of 32 rows
@@ -467,13 +470,18 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 // it).  Users, thresholds, lists and the slow path are per wave exactly as above, so results are identical.
 constexpr int WG_RING = 3;   // item-tile slots in LDS
 
-template <typename T, int D, int UW, int NW>
+template <typename T, int D, int UW, int NW, int TT>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArgs a) {
+    // TT = item tiles per ring slot and barrier ("step").  The cost of a step that is not MFMA (barrier skew, ring
+    // commit, the drain of the matrix pipe before the threshold test) is the same for every width, so narrow rows
+    // take two tiles per step: d=128 fp16 43 % -> see DESIGN section 5.
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int NCH = ROWB / 32;
     constexpr int UPW = 32 * UW;
     constexpr int TILE_B = NCH * 1024;                 // one packed tile
-    constexpr int CPW = (NCH + NW - 1) / NW;           // chunks of a tile each wave fetches
+    constexpr int SCH = TT * NCH;                      // 1 KiB chunks of a step
+    constexpr int STEP_B = TT * TILE_B;
+    constexpr int CPW = (SCH + NW - 1) / NW;           // chunks of a step each wave fetches
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -486,10 +494,10 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     const int K = a.k;
     const int i = lane & 31, h = lane >> 5;
 
-    char* ring = smem;                                  // [RING][TILE_B]
+    char* ring = smem;                                  // [RING][STEP_B]
     WaveLds<UPW> w;
     {
-        char* base = smem + WG_RING * TILE_B + (size_t)wave * wave_lds_bytes<UPW>(K);
+        char* base = smem + WG_RING * STEP_B + (size_t)wave * wave_lds_bytes<UPW>(K);
         w.ls = reinterpret_cast<float*>(base);
         w.li = reinterpret_cast<int*>(w.ls + UPW * K);
         w.cnt = w.li + UPW * K;
@@ -509,6 +517,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
         int64_t slot = ug * UPW + 32 * u + i;
+        // padding columns of the last group: duplicate the last user, threshold +inf (with -inf every tile of the
+        // wave would enter the slow path to find nothing: 100 000 users ran 2.2x slower than 131 072)
+        tau[u] = slot < a.n_users ? CRH_NEG_INF : __builtin_inff();
         if (slot >= a.n_users) slot = a.n_users - 1;
         const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
         const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
@@ -517,7 +528,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
             b[q][u] = load16(up + 32 * q);
             if constexpr (Elem<T>::kSwap) chunk_swap(b[q][u]);
         }
-        tau[u] = CRH_NEG_INF;
     }
 
     // the user fragments must have LANDED before the loop: otherwise the compiler's vmcnt bookkeeping for them
@@ -532,28 +542,34 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
     const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
     const char* packed = reinterpret_cast<const char*>(a.packed);
+    // step j of this split = tiles t0 + j*TT .. +TT-1 (tiles past the split or the table: computed on clamped
+    // rows, their candidates dropped by the il >= split_end test of the slow path)
+    const int64_t n_steps = (t1 - t0 + TT - 1) / TT;
 
-    // this wave's share of tile t: chunks wave, wave+8, ... (1 KiB each, 16 B per lane)
-    auto fetch = [&](f32x4(&st)[CPW], int64_t t) {
-        if (t >= NT) t = NT - 1;
-        if (CRH_ABLATE(a.ablate) & 2) t = 0;   // measurement only: every fetch hits the same (cached) tile
-        const char* tp = packed + t * TILE_B + lane * 16;
+    // this wave's share of step j: chunks wave, wave+NW, ... (1 KiB each, 16 B per lane)
+    auto fetch = [&](f32x4(&st)[CPW], int64_t j) {
+        if (j >= n_steps) j = n_steps - 1;
+        if (CRH_ABLATE(a.ablate) & 2) j = 0;   // measurement only: every fetch hits the same (cached) tiles
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
-            const int q = wave + c * NW;
-            if (NCH % NW == 0 || q < NCH) st[c] = load16(tp + q * 1024);   // branch-free when 8 | NCH
+            const int qq = wave + c * NW;
+            if (SCH % NW == 0 || qq < SCH) {   // branch-free when NW | SCH
+                int64_t t = t0 + j * TT + qq / NCH;
+                if (t >= NT) t = NT - 1;
+                st[c] = load16(packed + t * TILE_B + (qq % NCH) * 1024 + lane * 16);
+            }
         }
     };
-    // ring of WG_RING = 3 tile slots: tile t lives in slot t % 3.  Tile t+2 is committed during iteration t
-    // (into the slot tile t-1 left before the last barrier), so tile t+1 is already visible while tile t is
-    // multiplied and its first LDS group can be pulled into registers BEFORE the barrier: the next iteration
-    // starts its MFMAs without waiting for LDS.
+    // ring of WG_RING = 3 slots: step j lives in slot j % 3.  Step j+2 is committed during iteration j (into the
+    // slot step j-1 left before the last barrier), so step j+1 is already visible while step j is multiplied and its
+    // first LDS group can be pulled into registers BEFORE the barrier: the next iteration starts its MFMAs without
+    // waiting for LDS.
     auto commit = [&](const f32x4(&st)[CPW], int slot) {
-        char* dst = ring + slot * TILE_B + lane * 16;
+        char* dst = ring + slot * STEP_B + lane * 16;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
-            const int q = wave + c * NW;
-            if (NCH % NW == 0 || q < NCH) *reinterpret_cast<f32x4*>(dst + q * 1024) = st[c];
+            const int qq = wave + c * NW;
+            if (SCH % NW == 0 || qq < SCH) *reinterpret_cast<f32x4*>(dst + qq * 1024) = st[c];
         }
     };
     auto lds_barrier = [&]() {   // LDS traffic of this wave done, then meet; global prefetches keep flying
@@ -562,75 +578,84 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     };
     // A fragments come from LDS in groups of GR chunks, one group ahead of the MFMAs that consume them
     constexpr int GR = NCH >= 16 ? 2 : (NCH >= 8 ? 4 : NCH / 2);
-    f32x4 cfirst[GR];            // first group of the tile about to be multiplied
+    static_assert(NCH % GR == 0, "a group never straddles two tiles");
+    f32x4 cfirst[GR];            // first group of the step about to be multiplied
     auto load_first = [&](int slot) {
-        const char* src = ring + slot * TILE_B + lane * 16;
+        const char* src = ring + slot * STEP_B + lane * 16;
 #pragma unroll
         for (int j = 0; j < GR; ++j) cfirst[j] = *reinterpret_cast<const f32x4*>(src + j * 1024);
     };
-    auto compute = [&](int64_t t, int slot, int slot_next, bool has_next) {
-        const char* src = ring + slot * TILE_B + lane * 16;
-        f32x16 acc[UW];
+    auto compute = [&](int64_t j, int slot, int slot_next, bool has_next) {
+        const char* src = ring + slot * STEP_B + lane * 16;
+        f32x16 acc[TT][UW];
 #pragma unroll
-        for (int u = 0; u < UW; ++u)
+        for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+            for (int u = 0; u < UW; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tt][u][r] = 0.0f;
         f32x4 c[2][GR];
 #pragma unroll
-        for (int j = 0; j < GR; ++j) c[0][j] = cfirst[j];
+        for (int jj = 0; jj < GR; ++jj) c[0][jj] = cfirst[jj];
 #pragma unroll
-        for (int g = 0; g < NCH / GR; ++g) {
-            if (g + 1 < NCH / GR) {
+        for (int g = 0; g < SCH / GR; ++g) {
+            if (g + 1 < SCH / GR) {
 #pragma unroll
-                for (int j = 0; j < GR; ++j)
-                    c[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(src + ((g + 1) * GR + j) * 1024);
+                for (int jj = 0; jj < GR; ++jj)
+                    c[(g + 1) & 1][jj] = *reinterpret_cast<const f32x4*>(src + ((g + 1) * GR + jj) * 1024);
             } else if (has_next) {
                 load_first(slot_next);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < GR; ++j) Elem<T>::template mma<UW>(acc, c[g & 1][j], b[g * GR + j]);
+            for (int jj = 0; jj < GR; ++jj)
+                Elem<T>::template mma<UW>(acc[(g * GR + jj) / NCH], c[g & 1][jj], b[(g * GR + jj) % NCH]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (CRH_ABLATE(a.ablate) & 1) {
 #pragma unroll
-            for (int u = 0; u < UW; ++u) {
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" ::"v"(acc[u]));
+                    asm volatile("" ::"v"(acc[tt][u]));
 #endif
-            }
+                }
             return;
         }
         if (!live) return;
 #pragma unroll
-        for (int u = 0; u < UW; ++u) {
-            const float m = max16(acc[u]);
-            if (__ballot(m > tau[u]) != 0ull)
-                tile_slow_path<UPW>(acc[u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a, t << 5, split_end, lane);
-        }
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const float m = max16(acc[tt][u]);
+                if (__ballot(m > tau[u]) != 0ull)
+                    tile_slow_path<UPW>(acc[tt][u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a,
+                                        (t0 + j * TT + tt) << 5, split_end, lane);
+            }
     };
 
-    if (t0 < t1) {
+    if (n_steps > 0) {
         f32x4 sa[CPW], sb[CPW];
-        fetch(sa, t0);
-        fetch(sb, t0 + 1);
-        commit(sa, 0);                  // tile t0   -> slot 0
-        commit(sb, 1);                  // tile t0+1 -> slot 1
-        fetch(sa, t0 + 2);              // stage A: tile t0+2
-        fetch(sb, t0 + 3);              // stage B: tile t0+3
+        fetch(sa, 0);
+        fetch(sb, 1);
+        commit(sa, 0);                  // step 0 -> slot 0
+        commit(sb, 1);                  // step 1 -> slot 1
+        fetch(sa, 2);                   // stage A: step 2
+        fetch(sb, 3);                   // stage B: step 3
         lds_barrier();
         load_first(0);
-        int s0 = 0;                     // slot of tile t
-        for (int64_t t = t0; t < t1; t += 2) {
+        int s0 = 0;                     // slot of step j
+        for (int64_t j = 0; j < n_steps; j += 2) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-            commit(sa, s2);             // tile t+2 -> the slot tile t-1 left before the last barrier
-            fetch(sa, t + 4);
-            compute(t, s0, s1, t + 1 < t1);
+            commit(sa, s2);             // step j+2 -> the slot step j-1 left before the last barrier
+            fetch(sa, j + 4);
+            compute(j, s0, s1, j + 1 < n_steps);
             lds_barrier();
-            if (t + 1 >= t1) break;
-            commit(sb, s0);             // tile t+3 -> slot of tile t
-            fetch(sb, t + 5);
-            compute(t + 1, s1, s2, t + 2 < t1);
+            if (j + 1 >= n_steps) break;
+            commit(sb, s0);             // step j+3 -> slot of step j
+            fetch(sb, j + 5);
+            compute(j + 1, s1, s2, j + 2 < n_steps);
             lds_barrier();
             s0 = s2;
         }
@@ -647,10 +672,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     }
 }
 
+// item tiles per ring slot of the workgroup kernel: ~32 MFMAs per wave and step whatever the row width
+constexpr int wg_tiles_per_step(int row_bytes) { return row_bytes <= 128 ? 4 : (row_bytes <= 256 ? 2 : 1); }
+
 template <typename T, int D, int UW, int NW>
 int launch_score_wg(const ScoreArgs& a, hipStream_t stream) {
-    const size_t lds = (size_t)WG_RING * (D * sizeof(T) / 32) * 1024 + NW * wave_lds_bytes<32 * UW>(a.k);
-    auto kern = score_topk_wg_kernel<T, D, UW, NW>;
+    constexpr int TT = wg_tiles_per_step(D * (int)sizeof(T));
+    const size_t lds = (size_t)WG_RING * TT * (D * sizeof(T) / 32) * 1024 + NW * wave_lds_bytes<32 * UW>(a.k);
+    auto kern = score_topk_wg_kernel<T, D, UW, NW, TT>;
     CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const int64_t blocks = ((a.n_ugroups + NW - 1) / NW) * a.n_splits;
@@ -705,6 +734,29 @@ int pick_splits(int64_t n_ugroups, int64_t n_items, int occ) {
         const double rounds = ceil(w / cap);
         const double eff = w / (rounds * cap);
         const double cost = (1.0 + 5700.0 * s / (double)T) / eff;
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
+}
+
+// Split count of the workgroup kernel: n_wg workgroups of `slots` per round (one or two per CU).  Measured on the fp16
+// d=256 kernel (tools/f16_probe.py): a round filled to 77 % / 50 % takes 0.85 / 0.76 of a full one (the chip is
+// power-limited: idle CUs are clock headroom for the others), every extra cut costs ~6 % at 10 M items and k=20 (the
+// top-k warm-up of each user repeats per cut; cut_cost = that share x tiles: 18750 fp16, 5700 at the fp32 MFMA rate) and cuts stream different tile ranges through the same L2 (~+10 %).
+int pick_splits_wg(int64_t n_wg, int64_t n_items, int k, int slots, double cut_cost) {
+    const int64_t T = (n_items + 31) / 32;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && T / s < 64) break;
+        const double w = (double)n_wg * s;
+        const double rounds = ceil(w / slots);
+        const double fill = (w - (rounds - 1) * slots) / slots;
+        const double cost = ((rounds - 1) + 0.55 + 0.45 * fill) / s * (1.0 + cut_cost * (k / 20.0) * s / (double)T) *
+                            (s > 1 ? 1.1 : 1.0);
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = s;
@@ -824,7 +876,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     // one 8-wave workgroup per CU when its lists fit the 160 KiB of LDS, else two 4-wave workgroups (large k);
     // measured at k=20 (fp16): 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two 4-wave groups
     // 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
-    const size_t ring_b = (size_t)WG_RING * (d * esz / 32) * 1024;
+    const size_t ring_b = (size_t)WG_RING * wg_tiles_per_step(d * esz) * (d * esz / 32) * 1024;
     const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
     const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
@@ -905,7 +957,10 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
         return CRH_OK;
     }
 
-    a.n_splits = n_splits > 0 ? n_splits : pick_splits(a.n_ugroups, n_items, occ);
+    a.n_splits = n_splits > 0 ? n_splits
+                 : use_wg     ? pick_splits_wg((a.n_ugroups + wg_waves - 1) / wg_waves, n_items, k, wg_waves == 8 ? 256 : 512,
+                                               esz == 2 ? 18750.0 : 5700.0)
+                              : pick_splits(a.n_ugroups, n_items, occ);
     if (a.n_splits > T) a.n_splits = (int)T;
 
     if (a.n_splits == 1) {

@@ -360,7 +360,7 @@ def test_xcd_lockstep_launch_is_exact():
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
 
 
-@pytest.mark.parametrize("d,n_splits", [(256, 1), (128, 0), (64, 3)])
+@pytest.mark.parametrize("d,n_splits", [(256, 1), (128, 0), (128, 1), (128, 3), (64, 1), (64, 3)])
 def test_f16_workgroup_kernel_is_exact(d, n_splits):
     """>= 512 groups of 64 users: fp16 launches use the workgroup-cooperative kernel (8 waves share the item tiles
     through an LDS ring).  The helper demands bit-identity with the per-wave row-major kernel; sampled users are
