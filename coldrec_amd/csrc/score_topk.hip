@@ -177,11 +177,56 @@ struct WaveLds {
     int* cnt;        // [UPW]
     int64_t* rlo;    // [UPW] bounds of each user's rated list (rated_rowptr staged once per wave)
     int64_t* rhi;    // [UPW]
+    unsigned* rfilter;   // [UPW][8] 256-bit membership filter of the user's rated items in this split's range
 };
 
 template <int UPW>
 __host__ __device__ constexpr size_t wave_lds_bytes(int K) {
-    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + (size_t)UPW * 16;
+    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + (size_t)UPW * 16 + (size_t)UPW * 32;
+}
+
+template <int UPW>
+__device__ __forceinline__ void wave_lds_carve(WaveLds<UPW>& w, char* base, int K) {
+    w.ls = reinterpret_cast<float*>(base);
+    w.li = reinterpret_cast<int*>(w.ls + UPW * K);
+    w.cnt = w.li + UPW * K;
+    w.rlo = reinterpret_cast<int64_t*>(w.cnt + UPW);
+    w.rhi = w.rlo + UPW;
+    w.rfilter = reinterpret_cast<unsigned*>(w.rhi + UPW);
+}
+
+__device__ __forceinline__ unsigned rated_hash(int gi) { return ((unsigned)gi * 2654435761u) >> 24; }
+
+// Stage the list bounds of this wave's UPW slots and build their membership filters.  A slow-path candidate is tested
+// against the filter first (one LDS word): only a hit (a rated item, or a false positive: 1 - exp(-len/256)) pays the
+// memory round trip of the exact search.  The lists of consecutive slots are one contiguous run of rated_col, read
+// coalesced; ids outside [id0, id1) (other splits, other shards) are left out.
+template <int UPW>
+__device__ __forceinline__ void wave_lds_init(const WaveLds<UPW>& w, const ScoreArgs& a, int64_t slot0, int id0, int id1,
+                                              bool filter, int lane) {
+    for (int j = lane; j < UPW; j += 64) {
+        w.cnt[j] = 0;
+        const int64_t slot = slot0 + j;
+        const bool has = a.rated_rowptr && slot < a.n_users;
+        w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
+        w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
+    }
+    if (!filter || !a.rated_rowptr) return;
+    for (int j = lane; j < UPW * 8; j += 64) w.rfilter[j] = 0u;
+    const int64_t s1 = slot0 + UPW < a.n_users ? slot0 + UPW : a.n_users;
+    const int64_t e0 = a.rated_rowptr[slot0], e1 = a.rated_rowptr[s1];
+    int u = 0;                                   // this lane's position in the slot sequence (entries ascend)
+    for (int64_t base = e0; base < e1; base += 64) {
+        const int64_t e = base + lane;
+        if (e < e1) {
+            const int v = a.rated_col[e];
+            while (e >= w.rhi[u]) ++u;           // rhi of the last real slot is e1: terminates
+            if (v >= id0 && v < id1) {
+                const unsigned hsh = rated_hash(v);
+                atomicOr(&w.rfilter[u * 8 + (hsh >> 5)], 1u << (hsh & 31));
+            }
+        }
+    }
 }
 
 // maximum of the 16 accumulator registers as a depth-3 tree of 3-input maxima (v_max3_f32): the wave waits
@@ -205,18 +250,39 @@ __device__ __forceinline__ float pick16(const f32x16& v, int r) {
 
 // Slow path for one 32x32 accumulator tile (rare).  acc[r] = score of item row
 // (r&3) + 8*(r>>2) + 4*(lane>>5) for user column lane&31.
+// Cost per event is what bounds mid-size catalogues and the fp16 kernel (each event stalls the wave, in the workgroup
+// kernel the whole CU), so memory round trips are kept off it: the candidate-bitmap bits of the tile's 32 items are ONE
+// wave-uniform 64-bit window requested on entry (it lands while the candidate masks are built), bitmap-masked
+// candidates of users whose list is full are dropped before the serial part, and the rated list is only searched when
+// the user's LDS filter says the item may be in it.
 template <int UPW>
 __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg, const WaveLds<UPW>& w,
                                                int K, int ucol0, int64_t slot0, const ScoreArgs& a,
                                                int64_t item0, int64_t split_end, int lane) {
+    const int64_t g0 = a.item_base + item0;          // global id of the tile's first item
+    unsigned blo = 0u, bhi = 0u;
+    if (a.bitmap) {
+        const int64_t last = (a.item_base + a.n_items - 1) >> 5;
+        const int64_t w0 = (g0 >> 5) < last ? (g0 >> 5) : last, w1 = w0 < last ? w0 + 1 : last;
+        blo = a.bitmap[w0];
+        bhi = a.bitmap[w1];
+    }
     unsigned cm = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
+    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
+    const unsigned tb = (unsigned)(((((unsigned long long)bhi) << 32) | blo) >> (g0 & 31));
+    const unsigned x = tb >> (4 * (lane >> 5));
+    const unsigned m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
+    // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
+    if (tau_reg > CRH_NEG_INF) cm &= ~m16;
+    const unsigned bm = cm & m16;
     unsigned long long lanes = __ballot(cm != 0u);
     while (lanes) {
         const int L = __builtin_ctzll(lanes);
         lanes &= lanes - 1;
         unsigned cmL = __builtin_amdgcn_readlane(cm, L);
+        const unsigned bmL = __builtin_amdgcn_readlane(bm, L);
         const int jl = L & 31, hh = L >> 5;
         const int64_t slot = slot0 + jl;
         if (slot >= a.n_users) continue;
@@ -232,9 +298,22 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
             // then read lane L
             float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
             const int gi = (int)(a.item_base + il);
-            const int n = __builtin_amdgcn_readfirstlane(w.cnt[ul]);
-            if (wave_list_rejects(lsu, liu, n, K, sc, gi)) continue;
-            if (wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, a.bitmap, lane)) sc = CRH_MASKED_SCORE;
+            // one batch of LDS reads: fill, tail entry, filter word
+            const unsigned hsh = rated_hash(gi);
+            const int n_raw = w.cnt[ul];
+            const float ks_raw = lsu[K - 1];
+            const int ki_raw = liu[K - 1];
+            const unsigned fw_raw = a.rated_rowptr ? w.rfilter[ul * 8 + (hsh >> 5)] : 0u;
+            const int n = __builtin_amdgcn_readfirstlane(n_raw);
+            if (n >= K) {
+                const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ks_raw)));
+                const int ki = __builtin_amdgcn_readfirstlane(ki_raw);
+                if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;   // cannot enter a full list
+            }
+            bool masked = (bmL >> r) & 1u;
+            if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u))
+                masked = wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, nullptr, lane);
+            if (masked) sc = CRH_MASKED_SCORE;
             wave_list_insert(lsu, liu, w.cnt + ul, K, sc, gi, lane);
         }
     }
@@ -297,22 +376,14 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    // ---- item range of this split, in tiles of 32 rows
+    const int64_t NT = (a.n_items + 31) >> 5;
+    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
+    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
+
     WaveLds<UPW> w;
-    {
-        char* base = smem + (size_t)wave * wave_lds_bytes<UPW>(K);
-        w.ls = reinterpret_cast<float*>(base);
-        w.li = reinterpret_cast<int*>(w.ls + UPW * K);
-        w.cnt = w.li + UPW * K;
-        w.rlo = reinterpret_cast<int64_t*>(w.cnt + UPW);
-        w.rhi = w.rlo + UPW;
-    }
-    for (int j = lane; j < UPW; j += 64) {
-        w.cnt[j] = 0;
-        const int64_t slot = ug * UPW + j;
-        const bool has = a.rated_rowptr && slot < a.n_users;
-        w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
-        w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
-    }
+    wave_lds_carve<UPW>(w, smem + (size_t)wave * wave_lds_bytes<UPW>(K), K);
+    wave_lds_init<UPW>(w, a, ug * UPW, (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end), a.dense == nullptr, lane);
 
     // ---- hot user block -> registers (B fragments, already pair-swapped)
     f32x4 b[NCH][UW];
@@ -332,11 +403,6 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             if constexpr (SWAP) chunk_swap(b[q][u]);
         }
     }
-
-    // ---- item range of this split, in tiles of 32 rows
-    const int64_t NT = (a.n_items + 31) >> 5;
-    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
-    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
 
     // Two register tiles: while tile t is multiplied out of one, tile t+1 lands in the other
     // (issued a whole tile = NCH*4*UW MFMAs ahead, pinned there by sched_barrier; left to
@@ -495,22 +561,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     const int i = lane & 31, h = lane >> 5;
 
     char* ring = smem;                                  // [RING][STEP_B]
+    const int64_t NT = (a.n_items + 31) >> 5;
+    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
+    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
+
     WaveLds<UPW> w;
-    {
-        char* base = smem + WG_RING * STEP_B + (size_t)wave * wave_lds_bytes<UPW>(K);
-        w.ls = reinterpret_cast<float*>(base);
-        w.li = reinterpret_cast<int*>(w.ls + UPW * K);
-        w.cnt = w.li + UPW * K;
-        w.rlo = reinterpret_cast<int64_t*>(w.cnt + UPW);
-        w.rhi = w.rlo + UPW;
-    }
-    for (int j = lane; j < UPW; j += 64) {
-        w.cnt[j] = 0;
-        const int64_t slot = ug * UPW + j;
-        const bool has = a.rated_rowptr && slot < a.n_users;
-        w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
-        w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
-    }
+    wave_lds_carve<UPW>(w, smem + WG_RING * STEP_B + (size_t)wave * wave_lds_bytes<UPW>(K), K);
+    wave_lds_init<UPW>(w, a, ug * UPW, (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end), live, lane);
 
     f32x4 b[NCH][UW];
     float tau[UW];
@@ -538,9 +595,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
 #pragma unroll
         for (int u = 0; u < UW; ++u) asm volatile("" : "+v"(b[q][u]));
 #endif
-    const int64_t NT = (a.n_items + 31) >> 5;
-    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
-    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
     const char* packed = reinterpret_cast<const char*>(a.packed);
     // step j of this split = tiles t0 + j*TT .. +TT-1 (tiles past the split or the table: computed on clamped
     // rows, their candidates dropped by the il >= split_end test of the slow path)
@@ -832,15 +886,22 @@ int launch_score_per_wave(int esz, int d, int occ, const ScoreArgs& a, hipStream
     }
 }
 
-// Catalogues up to this many items are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any)
-constexpr int64_t DENSE_MAX_ITEMS = 65536;
+// Small and mid-size blocks are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any).
+constexpr int64_t DENSE_MAX_ITEMS = 262144;
 constexpr size_t DENSE_MAX_BLOCK = (size_t)1 << 30;
-// Which shapes: the fused selection is bound by its per-candidate slow path while N is small (k (1 + ln(N/k)) inserts
-// per user against N / 32 tiles of MFMA work) or while there are too few user groups to fill the chip (one wave is
-// the critical path); with many users and N in the tens of thousands it is MFMA-bound again and beats the 8 bytes
-// per pair the dense block costs.
+// Which shapes.  The dense route costs 8 bytes of HBM traffic per (user, item) pair whatever the shape: 0.38 - 0.44 of
+// the fp32 MFMA peak at d=128.  The fused selection pays k (1 + ln(N/k)) slow-path events of ~1.6 us per user (and that
+// again per item-range cut when there are too few user groups to fill the chip), against N/32 tiles of MFMA work.
+// Measured crossover on one MI355X, d=128, masks on (tools/midsize_probe.py, gpurun_out -> profiles/r02_midsize_probe.log):
+//   users x items   dense    fused (per-wave kernel)
+//    8192 x 262144   8.8 ms  15.1 ms        16384 x 131072   9.2 ms  15.0 ms       16384 x 524288  43.8 ms  29.6 ms
+//   32768 x 131072  18.3 ms  20.5 ms        32768 x 262144  36.1 ms  29.7 ms       65536 x  65536  15.9 ms  20.3 ms
+//   65536 x 131072  36.2 ms  29.7 ms       131072 x 131072  72.1 ms  46.3 ms
+// i.e. dense up to ~5e9 pairs per call; any user count below 16 385 items (the trainers' validation shapes).
 size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
-    if (n_items > DENSE_MAX_ITEMS || (n_items > 16384 && n_users > 65536)) return 0;
+    static const int64_t max_items = getenv("CRH_SCORE_DENSE_MAX_ITEMS") ? atoll(getenv("CRH_SCORE_DENSE_MAX_ITEMS")) : DENSE_MAX_ITEMS;
+    static const double max_pairs = getenv("CRH_SCORE_DENSE_MAX_PAIRS") ? atof(getenv("CRH_SCORE_DENSE_MAX_PAIRS")) : 5e9;
+    if (n_items > max_items || (n_items > 16384 && (double)n_users * (double)n_items > max_pairs)) return 0;
     const size_t row = (size_t)((n_items + 31) / 32) * 32 * sizeof(float);
     const size_t all = (size_t)n_users * row;
     if (all <= DENSE_MAX_BLOCK) return (all + 255) & ~(size_t)255;
@@ -870,7 +931,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     // user groups to fill the CUs and the workspace holds the packed copy.  fp16: d = 64/128/256, 64 users per
     // wave.  fp32: d = 128 (64 users per wave; +1.5 % over the per-wave kernel and 1/8 of its L2 -> CU traffic).
     static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
-    static const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;
+    const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;   // per call: tests force 2
     const bool can_pack = !no_pack && workspace &&
                           workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz);
     // one 8-wave workgroup per CU when its lists fit the 160 KiB of LDS, else two 4-wave workgroups (large k);
@@ -880,8 +941,14 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
     const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
+    // fp32: the lockstep of 8 waves makes every slow-path event a stall of the whole CU, so the workgroup kernel only
+    // pays on long streams (>= 2 M items: 0.852 vs 0.845 of peak at 2 M, 0.912 vs 0.891 at 10 M; at 262 144 items the
+    // per-wave kernel is 0.705 vs 0.655) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
+    // at 0.33 against 0.60 per wave)
+    const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
+    const bool fp32_wg_ok = n_items >= 2000000 && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
     const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
-                        (n_users + 63) / 64 >= 512;
+                        (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
     const int upw = use_wg ? 64 : users_per_wave(esz, d);
     ScoreArgs a;
     a.user_emb = user_emb;

@@ -382,10 +382,12 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
 
 
 @pytest.mark.parametrize("n_splits,n_items", [(1, 5003), (0, 5003), (1, 200_003)])
-def test_f32_workgroup_kernel_is_bit_exact(n_splits, n_items):
-    """fp32 d=128 launches with >= 512 user groups also run the workgroup-cooperative kernel (packed tiles through
-    LDS); its k-ordered MFMA chain must still be the oracle's fma chain bit for bit.  The helper checks bit-identity
-    with the per-wave row-major kernel; sampled users go against the C oracle."""
+def test_f32_workgroup_kernel_is_bit_exact(n_splits, n_items, monkeypatch):
+    """fp32 d=128 launches with >= 512 user groups and >= 2 M items run the workgroup-cooperative kernel (packed tiles
+    through LDS; CRH_SCORE_WG=2 forces it on these smaller catalogues); its k-ordered MFMA chain must still be the
+    oracle's fma chain bit for bit.  The helper checks bit-identity with the per-wave row-major kernel; sampled users
+    go against the C oracle."""
+    monkeypatch.setenv("CRH_SCORE_WG", "2")
     rng = np.random.default_rng(128 + n_splits + n_items)
     n_users, d, k = 32768 + 77, 128, 20
     U = (rng.standard_normal((n_users, d)) * 0.3).astype(np.float32)
