@@ -427,7 +427,14 @@ def eval_f16_leg(dev, steps=3, warmup=1, n_items=50_000_000, d=256, Bu=131072, k
            "roofline": {"bound": "mfma", "kernel": "score_topk_wg_kernel<f16,%d>" % d, "achieved": flops / (kern_ms * 1e-3) / 1e12,
                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, "kernel_ms": kern_ms,
-                        "flops_per_launch": flops, "traffic": None}}
+                        "flops_per_launch": flops, "traffic": None,
+                        "note": "peak is the nominal dense fp16 figure; a bare v_mfma_f32_32x32x16_f16 stream with random "
+                                "operands sustains 0.65-0.68 of it on this chip (power-limited, ~1.57 GHz; 0.60 once the A "
+                                "fragments come from LDS at one read per two MFMAs): tools/probes/mfma_energy_probe.hip, "
+                                "profiles/r02_mfma_energy_probe.log"}}
+    tr = measured_traffic("score_topk_wg_kernel<_Float16, %d" % d, None)
+    if tr:
+        leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1]})
     del V, U, out
     return {"eval_f16": leg}
 
@@ -471,6 +478,11 @@ def mask_topk_leg(dev, n_users=4096, n_items=1_000_000, k=20, reps=5):
            "roofline": {"bound": "hbm", "kernel": "mask_topk_kernel<1>", "achieved": byts / (ms[False] * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / (ms[False] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": byts, "traffic": None}}
+    tr = measured_traffic("mask_topk_kernel<1", None)
+    if tr:
+        leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1],
+                                "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE per launch, mean over the launches of the "
+                                                "profiled run (with and without write-back)"})
     del S
     return {"mask_topk": leg}
 

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-2 profile: rocprofv3 kernel stats of the DEFAULT bench command (all legs) + separate PMC passes for the
+# scoring kernel (headline), the fp16 / mask_topk legs and the training legs.
+# Usage (on the GPU box, from the repo root): bash tools/profile_round2.sh <tag>
+set -u
+TAG=${1:-r02_a}
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+T="timeout 900"
+$T rocprofv3 --kernel-trace --stats -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_stats.json" 2> "$OUT/stats.err"
+EV="--no-cpu-baseline --no-verify --legs none --steps 2 --warmup 1"
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_sq.err"
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_fetch.err"
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_write.err"
+$T rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum -d "$OUT/pmc_l2" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_l2.err"
+python3 tools/prof_summary.py "${TAG}_eval" "$OUT/stats" "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_l2" > "$OUT/summary_eval.txt" 2>&1
+# fp16 scoring + dense-block ranking legs (the headline runs once beside them)
+LG="--no-cpu-baseline --no-verify --steps 1 --warmup 0 --legs eval_f16,mask_topk"
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_lg_sq" -- python3 bench.py $LG > /dev/null 2> "$OUT/pmc_lg_sq.err"
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_lg_fetch" -- python3 bench.py $LG > /dev/null 2> "$OUT/pmc_lg_fetch.err"
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_lg_write" -- python3 bench.py $LG > /dev/null 2> "$OUT/pmc_lg_write.err"
+python3 tools/prof_summary.py "${TAG}_legs" "$OUT/pmc_lg_sq" "$OUT/pmc_lg_sq" "$OUT/pmc_lg_fetch" "$OUT/pmc_lg_write" > "$OUT/summary_legs.txt" 2>&1
+# training legs
+TR="--train-only --no-cpu-baseline"
+$T rocprofv3 --kernel-trace --stats -d "$OUT/tr_stats" -- python3 bench.py $TR > "$OUT/train_under_stats.json" 2> "$OUT/tr_stats.err"
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/tr_fetch" -- python3 bench.py $TR > /dev/null 2> "$OUT/tr_fetch.err"
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/tr_write" -- python3 bench.py $TR > /dev/null 2> "$OUT/tr_write.err"
+$T rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/tr_l2" -- python3 bench.py $TR > /dev/null 2> "$OUT/tr_l2.err"
+python3 tools/prof_summary.py "${TAG}_train" "$OUT/tr_stats" "$OUT/tr_fetch" "$OUT/tr_write" "$OUT/tr_l2" > "$OUT/summary_train.txt" 2>&1
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null
+cp "$OUT/bench_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_eval_bench_under_rocprof.json
+cp "$OUT/train_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_train_bench_under_rocprof.json
+tail -3 "$OUT"/*.err | tail -40; ls -la gpurun_out/profiles_$TAG
