@@ -40,6 +40,24 @@ class DPContext:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
+    def check_replicated(self, t: torch.Tensor, what: str) -> None:
+        """Every rank must hold the same `t` (the epoch's triples: replica consistency rests on all ranks drawing the
+        same NumPy stream).  Position-weighted int64 checksum, all-reduced as max and min."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        v = t.reshape(-1).to(torch.int64)
+        w = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64) % 1000003
+        c = (v * w).sum().reshape(1)
+        hi, lo = c.clone(), c.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        if int(hi.item()) != int(lo.item()):
+            raise RuntimeError("data-parallel training: %s differs between ranks (rank %d has checksum %d, the ranks "
+                               "span %d..%d): the ranks' samplers have diverged -- seed every rank identically"
+                               % (what, self.rank, int(c.item()), int(lo.item()), int(hi.item())))
+
+
 def dp_from_env() -> Optional[DPContext]:
     """The DPContext of this process when it was launched one-rank-per-GPU (torch.distributed initialised,
     world size > 1), else None."""
@@ -393,6 +411,8 @@ class EpochRunner:
         eng = self.eng
         for dst, src in ((self.u, u), (self.i, i), (self.j, j)):
             dst.copy_(torch.as_tensor(src), non_blocking=True)
+        if self.epochs_done == 0 and getattr(eng, "dp", None) is not None:   # once per run: same triples on every rank?
+            eng.dp.check_replicated(torch.stack([self.u, self.i, self.j]), "the first epoch's (user, pos, neg) triples")
         plans = ops.build_plans_device(self.u, self.i, self.j, self.B)
         if self.plans is None:
             self.plans = plans

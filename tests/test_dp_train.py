@@ -119,6 +119,17 @@ for name in ("mf", "lgcn"):
     assert all(torch.equal(gathered[0], t) for t in gathered), name
     lo, hi = eng.dp.slice(B)
     assert 0 <= lo < hi <= B and hi - lo in (B // world, B // world + 1)
+# replica-consistency check of the epoch's triples: identical on every rank passes, one differing element raises
+ctx = DPContext(world, rank)
+t = torch.from_numpy(np.stack(tri[0]))
+ctx.check_replicated(t, "triples")
+t2 = t.clone()
+t2[1, 3] += rank                                    # rank 0 unchanged, rank 1 off by one
+try:
+    ctx.check_replicated(t2, "triples")
+    raise SystemExit("diverged triples were not detected")
+except RuntimeError as e:
+    assert "differs between ranks" in str(e)
 dist.barrier()
 if rank == 0:
     print("DP_TRAIN_OK", world)

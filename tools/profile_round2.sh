@@ -16,12 +16,16 @@ $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- python3 benc
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_write.err"
 $T rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum -d "$OUT/pmc_l2" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_l2.err"
 python3 tools/prof_summary.py "${TAG}_eval" "$OUT/stats" "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_l2" > "$OUT/summary_eval.txt" 2>&1
+rm -rf "$OUT/stats" "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_l2"   # raw rocpd databases: only the summaries travel back (64 MiB cap)
+echo "eval passes done after $SECONDS s"
 # fp16 scoring + dense-block ranking legs (the headline runs once beside them)
 LG="--no-cpu-baseline --no-verify --steps 1 --warmup 0 --legs eval_f16,mask_topk"
 $T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_lg_sq" -- python3 bench.py $LG > /dev/null 2> "$OUT/pmc_lg_sq.err"
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_lg_fetch" -- python3 bench.py $LG > /dev/null 2> "$OUT/pmc_lg_fetch.err"
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_lg_write" -- python3 bench.py $LG > /dev/null 2> "$OUT/pmc_lg_write.err"
 python3 tools/prof_summary.py "${TAG}_legs" "$OUT/pmc_lg_sq" "$OUT/pmc_lg_sq" "$OUT/pmc_lg_fetch" "$OUT/pmc_lg_write" > "$OUT/summary_legs.txt" 2>&1
+rm -rf "$OUT/pmc_lg_sq" "$OUT/pmc_lg_fetch" "$OUT/pmc_lg_write"
+echo "leg passes done after $SECONDS s"
 # training legs
 TR="--train-only --no-cpu-baseline"
 $T rocprofv3 --kernel-trace --stats -d "$OUT/tr_stats" -- python3 bench.py $TR > "$OUT/train_under_stats.json" 2> "$OUT/tr_stats.err"
@@ -29,7 +33,9 @@ $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/tr_fetch" -- python3 bench
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/tr_write" -- python3 bench.py $TR > /dev/null 2> "$OUT/tr_write.err"
 $T rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/tr_l2" -- python3 bench.py $TR > /dev/null 2> "$OUT/tr_l2.err"
 python3 tools/prof_summary.py "${TAG}_train" "$OUT/tr_stats" "$OUT/tr_fetch" "$OUT/tr_write" "$OUT/tr_l2" > "$OUT/summary_train.txt" 2>&1
+rm -rf "$OUT/tr_stats" "$OUT/tr_fetch" "$OUT/tr_write" "$OUT/tr_l2"
+echo "train passes done after $SECONDS s"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null
 cp "$OUT/bench_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_eval_bench_under_rocprof.json
 cp "$OUT/train_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_train_bench_under_rocprof.json
-tail -3 "$OUT"/*.err | tail -40; ls -la gpurun_out/profiles_$TAG
+for f in "$OUT"/*.err; do echo "== $f"; grep -v -E "simple_timer|generateRocpd|tool.cpp|amdgpu.ids" "$f" | tail -n 4; done; du -sh gpurun_out; ls -la gpurun_out/profiles_$TAG
