@@ -48,6 +48,8 @@ SIGNATURES = {
     "crh_bpr_plan_heavy_lists": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
     "crh_bpr_plan_build_host": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "crh_bpr_plan_build": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "crh_bpr_plan_build_large_workspace_bytes": (_sz, [_i64, _i64]),
+    "crh_bpr_plan_build_large": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "crh_bpr_fwd_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _sz, _vp]),
     "crh_bpr_fwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),

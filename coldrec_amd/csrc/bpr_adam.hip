@@ -646,6 +646,138 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
     plan_emit_heavy(pl, L, nu, ni, uptr, iptr, scan);
 }
 
+// ---------------------------------------------------------------- plan builder for batches beyond the LDS sort
+// Batches above 8 192 triples (S-TRAIN-XL: 65 536) do not fit one workgroup's LDS.  Same result, several workgroups
+// per batch: (1) chunks of LP_CHUNK keys are sorted in LDS (bitonic, 64-bit keys row << 31 | role << 30 | entry);
+// (2) log2(chunks) merge passes in global memory, every thread producing LP_VT consecutive outputs of one merged pair
+// from its merge-path split (keys are unique, so there are no ties to order); (3) segment starts are counted per block,
+// each block sums the counts of the blocks before it, and rows / offsets / lists are written in place; (4) the heavy
+// lists by plan_heavy_pass_kernel.  grid.y = batch, so an epoch's plans are a handful of launches.
+constexpr int LP_CHUNK = 8192, LP_VT = 8, LP_EMIT = 4096, LP_MAX_EBLOCKS = 256;
+typedef unsigned long long lpkey;
+
+struct LargePlanSide {       // one side (users / items) of every batch of the call
+    int width_per_L;         // 1 = user side (L keys per batch), 2 = item side (2 L keys)
+    int64_t P;               // padded keys per batch: LP_CHUNK * power of two
+};
+
+__device__ __forceinline__ lpkey lp_key(const int32_t* iu, const int32_t* ip, const int32_t* in_, int64_t lo, int cnt,
+                                        int item_side, int64_t e) {
+    if (!item_side) return e < cnt ? PlanKey<lpkey>::make((uint32_t)iu[lo + e], (unsigned)e, 0u) : PlanKey<lpkey>::INVALID;
+    if (e < cnt) return PlanKey<lpkey>::make((uint32_t)ip[lo + e], (unsigned)e, 0u);
+    if (e < 2 * (int64_t)cnt) return PlanKey<lpkey>::make((uint32_t)in_[lo + e - cnt], (unsigned)(e - cnt), 1u);
+    return PlanKey<lpkey>::INVALID;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void plan_chunk_sort_kernel(const int32_t* __restrict__ iu,
+                                                                        const int32_t* __restrict__ ip,
+                                                                        const int32_t* __restrict__ in_, int64_t n_rec,
+                                                                        int64_t L, int item_side, int64_t P,
+                                                                        lpkey* __restrict__ keys) {
+    __shared__ lpkey sk[LP_CHUNK];
+    const int64_t lo = (int64_t)blockIdx.y * L;
+    const int cnt = (int)((n_rec - lo) < L ? (n_rec - lo) : L);
+    const int64_t c0 = (int64_t)blockIdx.x * LP_CHUNK;
+    for (int e = threadIdx.x; e < LP_CHUNK; e += PLAN_THREADS) sk[e] = lp_key(iu, ip, in_, lo, cnt, item_side, c0 + e);
+    __syncthreads();
+    bitonic_sort_lds(sk, LP_CHUNK);
+    lpkey* out = keys + (int64_t)blockIdx.y * P + c0;
+    for (int e = threadIdx.x; e < LP_CHUNK; e += PLAN_THREADS) out[e] = sk[e];
+}
+
+__global__ __launch_bounds__(256) void plan_merge_pass_kernel(const lpkey* __restrict__ src, lpkey* __restrict__ dst,
+                                                              int64_t P, int64_t run) {
+    const int64_t o0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * LP_VT;
+    if (o0 >= P) return;
+    const lpkey* a = src + (int64_t)blockIdx.y * P + (o0 / (2 * run)) * (2 * run);
+    const lpkey* b = a + run;
+    const int64_t d = o0 % (2 * run);
+    int64_t lo = d > run ? d - run : 0, hi = d < run ? d : run;
+    while (lo < hi) {                       // merge path: the first i with a[i] >= b[d - 1 - i]
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < b[d - 1 - mid]) lo = mid + 1;
+        else hi = mid;
+    }
+    int64_t i = lo, j = d - lo;
+    lpkey* out = dst + (int64_t)blockIdx.y * P + o0;
+    lpkey av = i < run ? a[i] : PlanKey<lpkey>::INVALID, bv = j < run ? b[j] : PlanKey<lpkey>::INVALID;
+#pragma unroll
+    for (int k = 0; k < LP_VT; ++k) {
+        const bool take_a = j >= run || (i < run && av < bv);
+        out[k] = take_a ? av : bv;
+        if (take_a) { ++i; av = i < run ? a[i] : PlanKey<lpkey>::INVALID; }
+        else { ++j; bv = j < run ? b[j] : PlanKey<lpkey>::INVALID; }
+    }
+}
+
+// write = 0: counts[batch][block] = segment starts of the block's LP_EMIT keys; write = 1: rows / offsets / list.
+__global__ __launch_bounds__(PLAN_THREADS) void plan_emit_large_kernel(const lpkey* __restrict__ keys, int64_t P,
+                                                                        int64_t n_rec, int64_t L, int item_side,
+                                                                        int32_t* __restrict__ plans, int64_t stride,
+                                                                        int32_t* __restrict__ counts, int n_eblocks,
+                                                                        int write) {
+    __shared__ int scan[PLAN_THREADS];
+    __shared__ int base_s, total_s;
+    const int64_t lo = (int64_t)blockIdx.y * L;
+    const int cnt = (int)((n_rec - lo) < L ? (n_rec - lo) : L);
+    const int64_t nvalid = item_side ? 2 * (int64_t)cnt : cnt;
+    const lpkey* k = keys + (int64_t)blockIdx.y * P;
+    int32_t* pl = plans + (int64_t)blockIdx.y * stride;
+    const int64_t width = item_side ? 2 * L : L;
+    int32_t* rows = item_side ? pl + 3 + (3 * L + 1) : pl + 3;
+    int32_t* ptr = rows + width;
+    int32_t* list = ptr + (width + 1);
+    constexpr int PER = LP_EMIT / PLAN_THREADS;
+    const int64_t e0 = (int64_t)blockIdx.x * LP_EMIT + (int64_t)threadIdx.x * PER;
+    int starts = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int64_t e = e0 + q;
+        if (e < nvalid && (e == 0 || PlanKey<lpkey>::row(k[e]) != PlanKey<lpkey>::row(k[e - 1]))) ++starts;
+    }
+    scan[threadIdx.x] = starts;
+    __syncthreads();
+    for (int off = 1; off < PLAN_THREADS; off <<= 1) {      // inclusive scan of the per-thread counts
+        const int v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t* cb = counts + (int64_t)blockIdx.y * LP_MAX_EBLOCKS;
+    if (!write) {
+        if (threadIdx.x == PLAN_THREADS - 1) cb[blockIdx.x] = scan[PLAN_THREADS - 1];
+        return;
+    }
+    if (threadIdx.x == 0) {
+        int base = 0, total = 0;
+        for (int b = 0; b < n_eblocks; ++b) {
+            if (b < (int)blockIdx.x) base += cb[b];
+            total += cb[b];
+        }
+        base_s = base;
+        total_s = total;
+    }
+    __syncthreads();
+    int rank = base_s + scan[threadIdx.x] - starts;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int64_t e = e0 + q;
+        if (e >= nvalid) break;
+        const lpkey kx = k[e];
+        if (e == 0 || PlanKey<lpkey>::row(kx) != PlanKey<lpkey>::row(k[e - 1])) {
+            rows[rank] = PlanKey<lpkey>::row(kx);
+            ptr[rank] = (int32_t)e;
+            ++rank;
+        }
+        list[e] = PlanKey<lpkey>::entry(kx);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ptr[total_s] = (int32_t)nvalid;
+        pl[item_side ? 1 : 0] = total_s;
+        pl[2] = (int32_t)L;
+    }
+}
+
 // ---------------------------------------------------------------- dense Adam (+ zero the gradient)
 struct AdamSeg {
     float* p;
@@ -1256,7 +1388,7 @@ extern "C" int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_id
                                   int64_t n_records, int64_t batch_size, int32_t* plans_out, void* stream) {
     CRH_CHECK_ARG(user_idx && pos_idx && neg_idx && plans_out && n_records > 0, "crh_bpr_plan_build: bad arguments");
     CRH_CHECK_ARG(batch_size >= 1 && batch_size <= 8192, "crh_bpr_plan_build: batch_size=%lld outside 1..8192 "
-                  "(build larger plans with crh_bpr_plan_build_host)", (long long)batch_size);
+                  "(larger batches: crh_bpr_plan_build_large)", (long long)batch_size);
     int P = 2;
     while (P < 2 * batch_size) P <<= 1;
     const size_t lds = (size_t)P * 8 + (2 * PLAN_THREADS + 2) * sizeof(int);
@@ -1269,6 +1401,71 @@ extern "C" int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_id
                        P, plans_out, plan_ints(batch_size));
     CRH_HIP(hipGetLastError());
     return CRH_OK;
+}
+
+namespace {
+int64_t lp_padded(int64_t width) {
+    const int64_t c = (width + LP_CHUNK - 1) / LP_CHUNK;
+    int64_t p = 1;
+    while (p < c) p <<= 1;
+    return p * LP_CHUNK;
+}
+size_t lp_align(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+// Workspace of crh_bpr_plan_build_large: two key buffers of the (padded) item side per batch, the per-block segment
+// counts, the heavy-list counts.
+extern "C" size_t crh_bpr_plan_build_large_workspace_bytes(int64_t n_records, int64_t batch_size) {
+    if (n_records <= 0 || batch_size <= 0) return 0;
+    const int64_t nb = (n_records + batch_size - 1) / batch_size;
+    return 2 * lp_align((size_t)nb * lp_padded(2 * batch_size) * sizeof(lpkey)) +
+           lp_align((size_t)nb * LP_MAX_EBLOCKS * sizeof(int32_t)) + lp_align(crh_bpr_plan_heavy_workspace_bytes(nb));
+}
+
+// Device: plans of every batch of an epoch for ANY batch size up to 524 288 (several workgroups per batch: chunk sorts in
+// LDS, merge passes in global memory; see plan_chunk_sort_kernel).  Same layout and contents as crh_bpr_plan_build.
+extern "C" int crh_bpr_plan_build_large(const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                                        int64_t n_records, int64_t batch_size, int32_t* plans_out, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    CRH_CHECK_ARG(user_idx && pos_idx && neg_idx && plans_out && n_records > 0, "crh_bpr_plan_build_large: bad arguments");
+    CRH_CHECK_ARG(batch_size >= 1 && lp_padded(2 * batch_size) <= (int64_t)LP_EMIT * LP_MAX_EBLOCKS,
+                  "crh_bpr_plan_build_large: batch_size=%lld outside 1..%lld", (long long)batch_size,
+                  (long long)LP_EMIT * LP_MAX_EBLOCKS / 2);
+    const int64_t L = batch_size, nb = (n_records + L - 1) / L;
+    CRH_CHECK_ARG(nb <= 65535, "crh_bpr_plan_build_large: %lld batches in one call (at most 65535)", (long long)nb);
+    const size_t need = crh_bpr_plan_build_large_workspace_bytes(n_records, batch_size);
+    if (!workspace || workspace_bytes < need) {
+        crh_set_error("crh_bpr_plan_build_large: workspace %zu < %zu bytes", workspace_bytes, need);
+        return CRH_ERR_WS;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t key_b = lp_align((size_t)nb * lp_padded(2 * L) * sizeof(lpkey));
+    char* wsp = reinterpret_cast<char*>(workspace);
+    lpkey* buf[2] = {reinterpret_cast<lpkey*>(wsp), reinterpret_cast<lpkey*>(wsp + key_b)};
+    int32_t* counts = reinterpret_cast<int32_t*>(wsp + 2 * key_b);
+    void* heavy_ws = wsp + 2 * key_b + lp_align((size_t)nb * LP_MAX_EBLOCKS * sizeof(int32_t));
+    const int64_t stride = plan_ints(L);
+    CRH_HIP(hipMemsetAsync(plans_out, 0, (size_t)nb * stride * sizeof(int32_t), st));
+    for (int side = 0; side < 2; ++side) {
+        const int64_t P = lp_padded(side ? 2 * L : L);
+        hipLaunchKernelGGL(plan_chunk_sort_kernel, dim3((unsigned)(P / LP_CHUNK), (unsigned)nb), dim3(PLAN_THREADS), 0, st,
+                           user_idx, pos_idx, neg_idx, n_records, L, side, P, buf[0]);
+        CRH_HIP(hipGetLastError());
+        int cur = 0;
+        for (int64_t run = LP_CHUNK; run < P; run <<= 1) {
+            hipLaunchKernelGGL(plan_merge_pass_kernel, dim3((unsigned)((P / LP_VT + 255) / 256), (unsigned)nb), dim3(256), 0,
+                               st, buf[cur], buf[cur ^ 1], P, run);
+            CRH_HIP(hipGetLastError());
+            cur ^= 1;
+        }
+        const int n_eblocks = (int)((P + LP_EMIT - 1) / LP_EMIT);
+        for (int write = 0; write < 2; ++write) {
+            hipLaunchKernelGGL(plan_emit_large_kernel, dim3((unsigned)n_eblocks, (unsigned)nb), dim3(PLAN_THREADS), 0, st,
+                               buf[cur], P, n_records, L, side, plans_out, stride, counts, n_eblocks, write);
+            CRH_HIP(hipGetLastError());
+        }
+    }
+    return crh_bpr_plan_heavy_lists(plans_out, nb, L, heavy_ws, crh_bpr_plan_heavy_workspace_bytes(nb), stream);
 }
 
 extern "C" size_t crh_bpr_workspace_bytes(int64_t batch) {

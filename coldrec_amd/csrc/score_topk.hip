@@ -700,7 +700,32 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
         lds_barrier();
         load_first(0);
         int s0 = 0;                     // slot of step j
+        // XCD soft lockstep (see xcd_window_sync): wave 0 reports / waits for the workgroup, the others meet it at the
+        // step's barrier.  Without it the 32 workgroups of an XCD drift apart until their tiles no longer share the L2:
+        // 4.5 TB of fabric-side reads per launch at the S-DN shape against a 25.6 GB table (profiles/r02_a_legs_pmc.json).
+        unsigned* sync_cnt = nullptr;
+        int64_t win_steps = 0, next_sync = n_steps + 2;
+        if (a.xcd_sync && wave == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
+            sync_cnt = a.xcd_sync + (int64_t)xcc * a.sync_stride;
+            if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            win_steps = (a.sync_window / TT) & ~(int64_t)1;      // whole loop trips (two steps each)
+            if (win_steps < 2) win_steps = 2;
+            next_sync = 0;
+        }
         for (int64_t j = 0; j < n_steps; j += 2) {
+            if (j >= next_sync) {       // wave 0 only (next_sync stays beyond the range elsewhere)
+                const int64_t win = j / win_steps;
+                if (xcd_window_sync(sync_cnt, win, lane)) {
+                    next_sync += win_steps;
+                } else {                // timed out: run free, and count this workgroup into every window it will not report
+                    next_sync = n_steps + 2;
+                    const int64_t n_win = (n_steps + win_steps - 1) / win_steps;
+                    if (lane == 0)
+                        for (int64_t wdw = win; wdw < n_win; ++wdw)
+                            __hip_atomic_fetch_add(sync_cnt + 1 + wdw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
             commit(sa, s2);             // step j+2 -> the slot step j-1 left before the last barrier
             fetch(sa, j + 4);
@@ -1058,8 +1083,11 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     a.xcd_sync = nullptr;
     a.sync_window = sync_win;
     a.sync_stride = 0;
-    if (sync_win > 0 && !use_wg && occ == 2 && a.n_splits == 1 && a.n_ugroups <= 2048 && a.n_ugroups > 256 && a.packed) {
-        const int64_t n_win = (T + sync_win - 1) / sync_win;
+    const int64_t n_wg_launch = (a.n_ugroups + wg_waves - 1) / wg_waves;
+    const bool sync_pw = !use_wg && occ == 2 && a.n_ugroups <= 2048 && a.n_ugroups > 256;
+    const bool sync_wg = use_wg && n_wg_launch <= (wg_waves == 8 ? 256 : 512) && n_wg_launch > 8;   // one resident round
+    if (sync_win > 0 && (sync_pw || sync_wg) && a.n_splits == 1 && a.packed) {
+        const int64_t n_win = (T + sync_win - 1) / sync_win + 1;
         const size_t need = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);
         if (workspace_bytes >= need && (size_t)(n_win + 1) * 8 * sizeof(unsigned) <= sync_bytes(n_items)) {
             a.sync_stride = n_win + 1;

@@ -250,20 +250,32 @@ def build_plans(user_idx, pos_idx, neg_idx, batch_size: int) -> np.ndarray:
 
 
 def build_plans_device(user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
-                       batch_size: int) -> torch.Tensor:
-    """Plans of every batch of an epoch, (n_batches, stride) int32 on the GPU: one launch of
-    crh_bpr_plan_build (LDS sort per batch) for batch_size <= 8192, torch index plumbing above that."""
+                       batch_size: int, lds_max_batch: int = 8192) -> torch.Tensor:
+    """Plans of every batch of an epoch, (n_batches, stride) int32 on the GPU: one launch of crh_bpr_plan_build (LDS
+    sort per batch) for batch_size <= 8192, crh_bpr_plan_build_large (several workgroups per batch) above that.
+    ``lds_max_batch`` below 8192 sends smaller batches through the large builder too (tests)."""
     _need_cuda(user_idx, pos_idx, neg_idx)
-    if batch_size <= 8192:
-        L = _lib.lib()
-        n_rec = user_idx.numel()
-        nb = (n_rec + batch_size - 1) // batch_size
-        plans = torch.empty((nb, int(L.crh_bpr_plan_ints(batch_size))), dtype=torch.int32, device=user_idx.device)
-        u, p, n = (x.to(torch.int32).contiguous() for x in (user_idx, pos_idx, neg_idx))
+    L = _lib.lib()
+    n_rec = user_idx.numel()
+    nb = (n_rec + batch_size - 1) // batch_size
+    stride = int(L.crh_bpr_plan_ints(batch_size))
+    u, p, n = (x.to(torch.int32).contiguous() for x in (user_idx, pos_idx, neg_idx))
+    if batch_size <= min(8192, lds_max_batch):
+        plans = torch.empty((nb, stride), dtype=torch.int32, device=user_idx.device)
         _lib.check(L.crh_bpr_plan_build(_lib.ptr(u), _lib.ptr(p), _lib.ptr(n), n_rec, int(batch_size),
                                         _lib.ptr(plans), _lib.current_stream()), "crh_bpr_plan_build")
         return plans
-    return _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size)
+    plans = torch.empty((nb, stride), dtype=torch.int32, device=user_idx.device)
+    group = max(1, min(nb, (256 << 20) // (48 * int(batch_size) + 4096)))     # batches per call: workspace <= ~256 MB
+    for b0 in range(0, nb, group):
+        b1 = min(nb, b0 + group)
+        lo, hi = b0 * batch_size, min(n_rec, b1 * batch_size)
+        ws_bytes = int(L.crh_bpr_plan_build_large_workspace_bytes(hi - lo, int(batch_size)))
+        ws = _workspace(ws_bytes, user_idx.device)
+        _lib.check(L.crh_bpr_plan_build_large(_lib.ptr(u[lo:hi]), _lib.ptr(p[lo:hi]), _lib.ptr(n[lo:hi]), hi - lo,
+                                              int(batch_size), _lib.ptr(plans[b0:b1]), _lib.ptr(ws), ws_bytes,
+                                              _lib.current_stream()), "crh_bpr_plan_build_large")
+    return plans
 
 
 # ----------------------------------------------------------------------------- MF step in one launch

@@ -158,6 +158,13 @@ int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx
  * (LDS bitonic sort per batch; batch_size <= 8192).  plans_out: n_batches * crh_bpr_plan_ints(batch_size). */
 int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
                        int64_t n_records, int64_t batch_size, int32_t* plans_out, void* stream);
+/* Same plans for ANY batch size up to 524 288 (S-TRAIN-XL: 65 536): several workgroups per batch -- chunk sorts in LDS,
+ * merge-path passes in global memory, segment emission, heavy lists -- a handful of launches for all batches of the
+ * call.  Bit-identical to crh_bpr_plan_build where both apply.  Workspace: crh_bpr_plan_build_large_workspace_bytes. */
+size_t crh_bpr_plan_build_large_workspace_bytes(int64_t n_records, int64_t batch_size);
+int crh_bpr_plan_build_large(const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
+                             int64_t n_records, int64_t batch_size, int32_t* plans_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int crh_bpr_fwd_bwd_f32(const float* user_table, const float* pos_table, const float* neg_table, int d,
                         const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx,
                         int64_t batch, float reg, float* grad_user, float* grad_pos, float* grad_neg,

@@ -97,6 +97,36 @@ def test_plan_backward_is_deterministic_and_exact(B, L):
     assert (outs[0][1].cpu().numpy()[untouched] == 0).all()
 
 
+@pytest.mark.parametrize("n_rec,L,id_max,forced", [(10_000, 4096, 700, True), (20_000, 8193, 5_000, False),
+                                                   (150_000, 65_536, 11_000_000, False), (70_000, 20_000, 300, False),
+                                                   (9, 4, 50, True)])
+def test_large_plan_builder_equals_host_builder(n_rec, L, id_max, forced):
+    """crh_bpr_plan_build_large (batches beyond one workgroup's LDS: chunk sorts + merge-path passes + segment emission,
+    several workgroups per batch) against crh_bpr_plan_build_host on whole epochs with a short last batch: every view of
+    every plan equal, heavy lists included; `forced` sends LDS-sized batches through it as well; two runs bit-identical;
+    the plan backward built on it equals the atomics-free oracle gradients."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(n_rec + L)
+    u, p, n = (rng.integers(0, id_max, n_rec).astype(np.int32) for _ in range(3))
+    u[:3], p[:3], n[:3] = id_max - 1, id_max - 1, id_max - 1
+    p[100:min(400, n_rec)] = 5                                                  # a heavy row
+    dev = ops.build_plans_device(t(u), t(p), t(n), L, lds_max_batch=1 if forced else 8192)
+    dev2 = ops.build_plans_device(t(u), t(p), t(n), L, lds_max_batch=1 if forced else 8192)
+    assert torch.equal(dev, dev2)
+    dev = dev.cpu().numpy()
+    host = ops.build_plans(u, p, n, L)
+    assert dev.shape == host.shape
+    for b in range(host.shape[0]):
+        hv, dv = _plan_views(host[b]), _plan_views(dev[b])
+        for k, v in hv.items():
+            assert np.array_equal(v, dv[k]), (b, k)
+    if L <= 8192:                                                               # same bits as the LDS builder where both apply
+        lds = ops.build_plans_device(t(u), t(p), t(n), L).cpu().numpy()
+        for b in range(host.shape[0]):
+            for k, v in _plan_views(lds[b]).items():
+                assert np.array_equal(v, _plan_views(dev[b])[k]), (b, k)
+
+
 @pytest.mark.parametrize("id_max", [700, 131_071, 131_073, 30_000_000])     # 32-bit sort keys below 2^17 rows, else 64-bit
 def test_plan_kernel_whole_epoch_with_short_last_batch(id_max):
     from coldrec_amd import ops
