@@ -557,8 +557,8 @@ __device__ inline void plan_emit_heavy(int32_t* pl, int64_t L, int nu, int ni, c
         if ((r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY) hv[1 + w++] = r;
 }
 
-// Heavy lists for plans whose row lists were built elsewhere (ops._build_plans_torch, batches beyond the LDS sort:
-// up to 3 x 65536 rows per plan).  Two passes over HV_BLOCKS chunks per plan: count, then ordered write.
+// Heavy lists for plans whose row lists were built elsewhere (crh_bpr_plan_build_large, or a caller's own builder:
+// up to 3 x 524288 rows per plan).  Two passes over HV_BLOCKS chunks per plan: count, then ordered write.
 constexpr int HV_BLOCKS = 64, HV_THREADS = 256;
 
 __device__ __forceinline__ int plan_row_heavy(const int32_t* uptr, const int32_t* iptr, int nu, int r) {

@@ -339,58 +339,6 @@ def mf_step_finish(part_in, n_parts_in: int, batch: int, loss_out) -> None:
                                              _lib.current_stream()), "crh_mf_step_finish")
 
 
-def _build_plans_torch(user_idx, pos_idx, neg_idx, batch_size: int) -> torch.Tensor:
-    dev, L = user_idx.device, int(batch_size)
-    n_rec = user_idx.numel()
-    nb = (n_rec + L - 1) // L
-    stride = int(_lib.lib().crh_bpr_plan_ints(L))
-    plans = torch.zeros((nb, stride), dtype=torch.int32, device=dev)
-    big = torch.iinfo(torch.int64).max
-    pad = nb * L - n_rec
-    bl = torch.arange(L, dtype=torch.int64, device=dev).repeat(nb)[: n_rec]
-
-    def side(rows_list, ents_list, width, off_rows):
-        rows = torch.cat([r.to(torch.int64) for r in rows_list])
-        ents = torch.cat(ents_list)
-        key = rows * (1 << 31) + ents
-        if pad:
-            # keep each batch contiguous: (batch, width) layout with the short last batch padded
-            parts = []
-            per = width // L
-            for q in range(per):
-                k = key[q * n_rec:(q + 1) * n_rec]
-                parts.append(torch.cat([k, torch.full((pad,), big, dtype=torch.int64, device=dev)]).view(nb, L))
-            key2 = torch.cat(parts, dim=1)
-        else:
-            per = width // L
-            key2 = torch.cat([key[q * n_rec:(q + 1) * n_rec].view(nb, L) for q in range(per)], dim=1)
-        key2, _ = torch.sort(key2, dim=1)
-        valid = key2 != big
-        srow = (key2 >> 31)
-        start = valid.clone()
-        start[:, 1:] &= srow[:, 1:] != srow[:, :-1]
-        rank = torch.cumsum(start, dim=1) - 1
-        t_idx, e_idx = torch.nonzero(start, as_tuple=True)
-        r_idx = rank[t_idx, e_idx]
-        plans[t_idx, off_rows + r_idx] = srow[t_idx, e_idx].to(torch.int32)
-        plans[t_idx, off_rows + width + r_idx] = e_idx.to(torch.int32)
-        nseg = start.sum(1)
-        plans[torch.arange(nb, device=dev), off_rows + width + nseg] = valid.sum(1).to(torch.int32)
-        plans[:, off_rows + 2 * width + 1: off_rows + 3 * width + 1] = (key2 & 0x7FFFFFFF).to(torch.int32)
-        return nseg.to(torch.int32)
-
-    plans[:, 2] = L
-    nu = side([user_idx], [bl], L, 3)
-    ni = side([pos_idx, neg_idx], [bl, bl + (1 << 30)], 2 * L, 3 + 3 * L + 1)
-    plans[:, 0], plans[:, 1] = nu, ni
-    # heavy rows (more than crh_bpr_heavy_threshold() entries): [count, slots ascending...] behind the item lists,
-    # one small launch over the finished row lists (a torch formulation costs ~20 launches per call)
-    ws = torch.empty(int(_lib.lib().crh_bpr_plan_heavy_workspace_bytes(nb)), dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().crh_bpr_plan_heavy_lists(_lib.ptr(plans), nb, L, _lib.ptr(ws), ws.numel(),
-                                                   _lib.current_stream()), "crh_bpr_plan_heavy_lists")
-    return plans
-
-
 def adam_step_scalars(first_step: int, n_steps: int, lr: float = 1e-3, betas=(0.9, 0.999)) -> np.ndarray:
     """(n_steps, 2) float32 host array of the step-dependent Adam factors for steps first_step.."""
     out = np.empty((n_steps, 2), np.float32)

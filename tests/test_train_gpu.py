@@ -75,7 +75,7 @@ def test_plan_backward_is_deterministic_and_exact(B, L):
     ni = rng.integers(0, rows + 50, B).astype(np.int32)
     host = ops.build_plans(ui, pi, ni, L)[0]
     devp = ops.build_plans_device(t(ui), t(pi), t(ni), L)
-    devt = ops._build_plans_torch(t(ui), t(pi), t(ni), L)
+    devt = ops.build_plans_device(t(ui), t(pi), t(ni), L, lds_max_batch=1)      # the multi-block builder on the same batch
     for k, v in _plan_views(host).items():
         assert np.array_equal(v, _plan_views(devp[0].cpu().numpy())[k]), k
         assert np.array_equal(v, _plan_views(devt[0].cpu().numpy())[k]), k

@@ -31,7 +31,7 @@ def main():
     while time.time() < t_end:
         half = rng.random() < 0.35
         d = int(rng.choice([16, 32, 64, 128, 256] if half else [8, 16, 32, 64, 128, 256, 24, 100]))
-        k = int(rng.choice([1, 5, 10, 20, 20, 20, 33, 64]))
+        k = int(rng.choice([1, 5, 10, 20, 20, 20, 33, 64, 100, 128]))
         big = rng.random() < 0.15                       # workgroup-kernel territory
         n_users = int(rng.integers(32768, 34000)) if big else int(rng.integers(1, 700))
         n_items = int(rng.integers(1, 3000)) if big else int(rng.integers(1, 40000))
@@ -55,6 +55,11 @@ def main():
         use_idx = rng.random() < 0.5 and not big
         users = rng.permutation(n_users)[: max(1, n_users // 2)].astype(np.int64) if use_idx else None
         splits = int(rng.choice([0, 0, 1, 2, 7]))
+        # fp32 launches take the workgroup kernel from 2 M items only; CRH_SCORE_WG=2 (read per call) forces it here
+        if big and rng.random() < 0.6:
+            os.environ["CRH_SCORE_WG"] = "2"
+        else:
+            os.environ.pop("CRH_SCORE_WG", None)
         pack = bool(rng.random() < 0.7)
         sel = slice(None) if users is None else users
         nq = n_users if users is None else len(users)
