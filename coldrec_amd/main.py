@@ -86,6 +86,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help='(addition) MF / LightGCN: adam = torch.optim.Adam as the reference (model/MF.py:14); sgd = '
                         'torch.optim.SGD(lr) defaults, the "BPR loss + SGD update" mode: rows a batch does not touch do '
                         'not move, 8 instead of 24 bytes of optimiser traffic per element')
+    p.add_argument('--shard_graph', action='store_true',
+                   help='(addition) LightGCN under torch.distributed.run: row-shard the adjacency and every layer state '
+                        'over the ranks (one all-gather per layer and direction) instead of replaying all SpMMs on every '
+                        'rank; for graphs beyond one GPU')
     p.add_argument('--score_dtype', choices=['fp32', 'fp16'], default='fp32',
                    help='(addition) table precision of the fused full-catalogue ranking: fp32 = exact, the '
                         'reference\'s arithmetic; fp16 = half tables, fp32 accumulation (16x the MFMA rate)')

@@ -51,6 +51,11 @@ class MF(BaseColdStartTrainer):
         dp = dp_from_env()            # one rank per GPU: shard every batch, all-reduce sums + gradient
         if dp is not None:
             eng.enable_data_parallel(dp)
+            # LightGCN, graphs beyond one GPU's comfort: row-shard the propagation too (--shard_graph / CRH_LGCN_ROW_SHARD=1;
+            # 2L + 1 all-gathers per step instead of replicated SpMMs: train.LGCNEngine.enable_row_sharding)
+            if hasattr(eng, 'enable_row_sharding') and (getattr(self.args, 'shard_graph', False) or
+                                                        os.environ.get('CRH_LGCN_ROW_SHARD', '0') == '1'):
+                eng.enable_row_sharding(dp)
         else:
             # catalogue-scale tables: replay dense Adam on the touched rows only (bit-identical, see
             # crh_adam_rows_f32); 'auto' = when a batch touches under ~5 % of the rows

@@ -398,8 +398,8 @@ def spmm_csr_sgd(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: float
     """g = (acc_in*s_in + A @ x)*s_out -> p <- fma(-lr, g, p) in the SpMM's epilogue (crh_spmm_csr_sgd_f32)."""
     _need_cuda(rowptr, col, val, x, acc_in, acc_out, p)
     n_rows, d = rowptr.shape[0] - 1, x.shape[1]
-    for t in (x, p):
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n_rows, d)
+    assert x.dtype == torch.float32 and x.is_contiguous()          # x may hold more rows than A (row-sharded propagation)
+    assert p.dtype == torch.float32 and p.is_contiguous() and p.shape == (n_rows, d)
     rc = _lib.lib().crh_spmm_csr_sgd_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                          _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
                                          ctypes.byref(sched.c) if sched is not None else None, _lib.ptr(p), float(lr),
@@ -438,7 +438,8 @@ def spmm_csr_adam(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: floa
     _need_cuda(rowptr, col, val, x, acc_in, acc_out, p, m, v, step_scalars)
     assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
     n_rows, d = rowptr.shape[0] - 1, x.shape[1]
-    for t in (x, p, m, v):
+    assert x.dtype == torch.float32 and x.is_contiguous()          # x may hold more rows than A (row-sharded propagation)
+    for t in (p, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n_rows, d)
     rc = _lib.lib().crh_spmm_csr_adam_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                           _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),

@@ -40,6 +40,19 @@ class DPContext:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
 
+    def all_gather_rows(self, full: torch.Tensor, part: torch.Tensor) -> None:
+        """full (world * rows, d) <- every rank's part (rows, d), in rank order (one RCCL all-gather on the compute
+        stream; the list form is the fallback for backends without the flat collective)."""
+        if self.world == 1:
+            full.copy_(part)
+            return
+        import torch.distributed as dist
+        assert full.is_contiguous() and part.is_contiguous() and full.shape[0] == self.world * part.shape[0]
+        try:
+            dist.all_gather_into_tensor(full, part, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(full.view(self.world, part.shape[0], -1).unbind(0)), part, group=self.group)
+
     def check_replicated(self, t: torch.Tensor, what: str) -> None:
         """Every rank must hold the same `t` (the epoch's triples: replica consistency rests on all ranks drawing the
         same NumPy stream).  Position-weighted int64 checksum, all-reduced as max and min."""
@@ -311,7 +324,101 @@ class LGCNEngine(_TableState):
         self.fuse_adam = hasattr(self.k, 'spmm_csr_adam') and os.environ.get("CRH_LGCN_FUSED", "1") != "0"
         self.keep_grad = False       # also store dE0 into self.G (tests compare it with the reference's autograd)
 
+    def enable_row_sharding(self, dp: DPContext) -> None:
+        """SURVEY.md 8(e), "scalable variant": the propagation itself is sharded.  Rank r owns the contiguous row block
+        [r0, r1) of the adjacency and of every layer state: per layer it multiplies ITS rows (1/G of the SpMM work) and
+        the layer outputs are exchanged by one all-gather each (N*d*4 bytes), forward and backward -- the adjacency
+        D^-1/2 A D^-1/2 is symmetric, so the backward `A^T dY` is the same row-block product over the gathered dY and no
+        transposed blocks or reduce-scatter are needed.  The batch is sharded as in plain data parallelism (all-reduce of
+        the 4 sums and of dOUT); Adam / SGD runs on the owned rows only, in the epilogue of the last backward SpMM, and
+        one all-gather republishes E.  m and v of rows a rank does not own are never read there and stay stale.
+        Per row the arithmetic is that of the replicated engine (same edge order, same heavy-row split), so the tables
+        are bit-identical to it.  2L + 1 all-gathers + 1 all-reduce per step: worth it when a row block's SpMM costs more
+        than an all-gather of the table, i.e. for graphs far beyond the reference's datasets."""
+        if self.dp is None:
+            self.enable_data_parallel(dp)
+        N, d = self.E.shape
+        G = dp.world
+        rows = (N + G - 1) // G
+        r0 = min(N, dp.rank * rows)
+        r1 = min(N, r0 + rows)
+        dev = self.device
+        e0, e1 = int(self.rowptr[r0]), int(self.rowptr[r1])
+        self.rs_rowptr = (self.rowptr[r0:r1 + 1] - e0).contiguous()
+        self.rs_col, self.rs_val = self.col[e0:e1].contiguous(), self.val[e0:e1].contiguous()
+        self.rs_sched = self.k.SpmmSchedule(self.rs_rowptr.cpu().numpy(), dev) if r1 > r0 else None
+        self.rs = (rows, r0, r1)
+        pad = G * rows
+        E_pad = torch.zeros((pad, d), dtype=torch.float32, device=dev)     # E becomes a view of the gather target
+        E_pad[:N] = self.E
+        self.rs_E, self.E = E_pad, E_pad[:N]
+        self.rs_X = [torch.zeros((pad, d), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.rs_OUT = torch.zeros((pad, d), dtype=torch.float32, device=dev)
+        self.rs_own = torch.zeros((rows, d), dtype=torch.float32, device=dev)   # send buffer (tail rows stay zero)
+        self.rs_acc = torch.zeros((rows, d), dtype=torch.float32, device=dev)   # layer sum / Horner state of the own rows
+        self.OUT = self.rs_OUT[:N]
+
+    def _propagate_sharded(self) -> None:
+        c = 1.0 / (self.L + 1)
+        rows, r0, r1 = self.rs
+        own = r1 - r0
+        x = self.rs_E
+        for k in range(self.L):
+            last = k == self.L - 1
+            if own:
+                self.k.spmm_csr(self.rs_rowptr, self.rs_col, self.rs_val, x, y=None if last else self.rs_own[:own],
+                                acc_in=self.E[r0:r1] if k == 0 else self.rs_acc[:own], s_in=1.0,
+                                acc_out=self.rs_acc[:own], s_out=c if last else 1.0, sched=self.rs_sched)
+            if not last:
+                self.dp.all_gather_rows(self.rs_X[k & 1], self.rs_own)
+                x = self.rs_X[k & 1]
+        self.dp.all_gather_rows(self.rs_OUT, self.rs_acc)
+
+    def _step_sharded(self, user_idx, pos_idx, neg_idx, loss, step_scalars) -> None:
+        U, c = self.user_num, 1.0 / (self.L + 1)
+        rows, r0, r1 = self.rs
+        own = r1 - r0
+        self._propagate_sharded()
+        self.dOUT.zero_()
+        self._dp_loss_grad(self.OUT[:U], self.OUT[U:], user_idx, pos_idx, neg_idx, self.dOUT[:U], self.dOUT[U:], loss)
+        self.dp.all_reduce(self.dOUT)
+        x = self.dOUT
+        self.step_count += 1
+        Eo, Go = self.E[r0:r1], self.G[r0:r1]
+        Mo, Vo = (self.M[r0:r1], self.V[r0:r1]) if self.M is not None else (None, None)
+        for j in range(self.L):
+            last = j == self.L - 1
+            s_in, s_out = (1.0 if j == 0 else c), (c if j == 0 else 1.0)
+            if not own:
+                pass
+            elif last and self.fuse_adam and self.optimizer == 'sgd':
+                self.k.spmm_csr_sgd(self.rs_rowptr, self.rs_col, self.rs_val, x, self.dOUT[r0:r1], s_in,
+                                    Go if self.keep_grad else None, s_out, self.rs_sched, Eo, self.lr)
+            elif last and self.fuse_adam:
+                self.k.spmm_csr_adam(self.rs_rowptr, self.rs_col, self.rs_val, x, self.dOUT[r0:r1], s_in,
+                                     Go if self.keep_grad else None, s_out, self.rs_sched, Eo, Mo, Vo, self.step_count,
+                                     lr=self.lr, step_scalars=step_scalars)
+            else:
+                self.k.spmm_csr(self.rs_rowptr, self.rs_col, self.rs_val, x, y=None, acc_in=self.dOUT[r0:r1], s_in=s_in,
+                                acc_out=Go if last else self.rs_own[:own], s_out=s_out, sched=self.rs_sched)
+            if not last:
+                self.dp.all_gather_rows(self.rs_X[j & 1], self.rs_own)
+                x = self.rs_X[j & 1]
+        if own and not self.fuse_adam:
+            if self.optimizer == 'sgd':
+                self.k.sgd_dense(Eo, Go, self.lr, zero_grad=False)
+            else:
+                self.k.adam_dense(Eo, Go, Mo, Vo, self.step_count, lr=self.lr, zero_grad=False, step_scalars=step_scalars)
+        if own:
+            self.rs_own[:own].copy_(Eo)
+        self.dp.all_gather_rows(self.rs_E, self.rs_own)      # every rank sees the updated table (rows >= N stay zero)
+
     def _propagate(self, out: torch.Tensor) -> None:
+        if getattr(self, "rs", None) is not None:
+            self._propagate_sharded()
+            if out is not self.OUT:
+                out.copy_(self.OUT)
+            return
         c = 1.0 / (self.L + 1)
         x = self.E
         for k in range(self.L):
@@ -328,10 +435,12 @@ class LGCNEngine(_TableState):
     def step(self, user_idx, pos_idx, neg_idx, plan: Optional[torch.Tensor] = None, loss_out=None,
              step_scalars=None) -> None:
         U, c = self.user_num, 1.0 / (self.L + 1)
+        loss = self.loss if loss_out is None else loss_out
+        if getattr(self, "rs", None) is not None:
+            return self._step_sharded(user_idx, pos_idx, neg_idx, loss, step_scalars)
         self._propagate(self.OUT)
         if not self._dout_clean:
             self.dOUT.zero_()
-        loss = self.loss if loss_out is None else loss_out
         if self.dp is not None:
             # propagation is replicated; only the loss/gradient of the batch is sharded, and the exchange
             # happens on dOUT so the backward SpMMs run on identical inputs everywhere

@@ -119,6 +119,24 @@ for name in ("mf", "lgcn"):
     assert all(torch.equal(gathered[0], t) for t in gathered), name
     lo, hi = eng.dp.slice(B)
     assert 0 <= lo < hi <= B and hi - lo in (B // world, B // world + 1)
+# row-sharded LightGCN propagation (SURVEY.md 8(e), scalable variant): own row block per rank, all-gathered layer states
+for L in (1, 3):
+    eng = LGCNEngine(U0, V0, rowptr, col, val, L, 1e-2, 1e-3, "cpu")
+    eng.enable_row_sharding(DPContext(world, rank))
+    port = ref_port.LGCNPort(U0, V0, ref_port.coo_adj(rowptr, col, val), L, 1e-2, 1e-3)
+    for (u, i, j) in tri:
+        eng.step(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j))
+        want = port.step(u, i, j)
+        got = eng.last_loss()
+        assert abs(got - want) <= 1e-5 * abs(want), ("row-sharded", L, got, want)
+    ref = torch.cat([port.U.detach(), port.V.detach()], 0)
+    err = float((eng.E - ref).norm() / ref.norm())
+    assert err < 1e-5, ("row-sharded", L, err)
+    gathered = [torch.empty_like(eng.E) for _ in range(world)]
+    dist.all_gather(gathered, eng.E.contiguous())
+    assert all(torch.equal(gathered[0], t) for t in gathered), ("row-sharded replicas", L)
+    rows, r0, r1 = eng.rs
+    assert (r0, r1) == (rank * rows, min(n_u + n_i, (rank + 1) * rows))
 # replica-consistency check of the epoch's triples: identical on every rank passes, one differing element raises
 ctx = DPContext(world, rank)
 t = torch.from_numpy(np.stack(tri[0]))
