@@ -212,6 +212,45 @@ def validation_eval_leg(dev):
     return {"eval_validation": out}
 
 
+def midsize_eval_leg(dev):
+    """Mid-size catalogues (65 K - 1 M items, fp32 d=128, masks, k=20): the shapes between the trainers' validation and
+    the headline, where the fused selection's slow path, not MFMA, sets the time.  Whatever route the
+    library picks (dense block + wave-per-user ranking, per-wave kernel, workgroup kernel); 2 users per shape are
+    re-checked against the canonical oracle, bit for bit."""
+    from coldrec_amd import ops
+    from oracle import oracle_np as orc
+    out = {}
+    for n_users, n_items in ((8192, 262144), (65536, 131072), (131072, 262144), (131072, 1048576)):
+        U = xavier_(n_users, 128, 31, dev, n_items)
+        V = item_shard(n_items, 128, 0, n_items, dev)
+        rowptr, col = rated_lists(n_users, n_items, 50, seed=4)
+        cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
+        bm = ops.make_bitmap(n_items, cold, dev)
+        rp, rc = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+        for _ in range(2):
+            res = ops.score_topk(U, None, V, 20, rp, rc, bm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            res = ops.score_topk(U, None, V, 20, rp, rc, bm)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        pick = np.array([0, n_users - 1], np.int64)
+        sub_rp = np.concatenate([[0], np.cumsum([rowptr[u + 1] - rowptr[u] for u in pick])]).astype(np.int64)
+        sub_col = np.concatenate([col[rowptr[u]:rowptr[u + 1]] for u in pick]).astype(np.int64)
+        ws, wi = orc.score_topk(U[torch.from_numpy(pick).to(dev)].cpu().numpy(), np.arange(2, dtype=np.int64), V.cpu().numpy(),
+                                20, sub_rp, sub_col, orc.make_bitmap(n_items, cold))
+        gs, gi = res[0][torch.from_numpy(pick).to(dev)].cpu().numpy(), res[1][torch.from_numpy(pick).to(dev)].cpu().numpy()
+        if not (np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))):
+            print(json.dumps({"error": "eval_midsize %d x %d differs from the oracle" % (n_users, n_items)}), flush=True)
+            raise SystemExit(3)
+        tf = 2.0 * 128 * n_users * n_items / (ms * 1e-3) / 1e12
+        out["%dx%d" % (n_users, n_items)] = {"ms": ms, "items_per_s": n_users * n_items / ms * 1e3,
+                                             "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, "verified_users": 2}
+        del U, V, res
+    return {"eval_midsize": out}
+
+
 def train_legs(dev, with_cpu, e2e_epochs=30):
     """Secondary metric of BASELINE.json: BPR triples/s (train): configs[1] (BPR-MF, MovieLens shape, d=128) with
     Adam as the reference and with plain SGD (the north_star's "BPR loss + SGD update"), configs[2] (LightGCN L=3,
@@ -647,7 +686,7 @@ def main():
     ap.add_argument("--cpu-sample-users", type=int, default=2048,
                     help="users of the CPU baseline (blocks of 256 against the WHOLE item table, SURVEY.md 8(d))")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="the CPU baseline stops after this many seconds")
-    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train,eval_validation",
+    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train,eval_validation,eval_midsize",
                     help="N=1: secondary legs carried in the same JSON line (comma separated; 'none' = headline only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the last timed step")
     args = ap.parse_args()
@@ -856,7 +895,8 @@ def main():
         for leg_name, fn in (("eval_f16", lambda: eval_f16_leg(dev)), ("mask_topk", lambda: mask_topk_leg(dev)),
                              ("train_xl", lambda: {"train_xl": train_xl(dev, 3, 1)}),
                              ("train", lambda: train_legs(dev, not args.no_cpu_baseline)),
-                             ("eval_validation", lambda: validation_eval_leg(dev))):
+                             ("eval_validation", lambda: validation_eval_leg(dev)),
+                             ("eval_midsize", lambda: midsize_eval_leg(dev))):
             if leg_name in legs:
                 result.update(fn())
                 torch.cuda.empty_cache()
