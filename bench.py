@@ -164,8 +164,10 @@ def measured_traffic(kernel_prefix, grid_threads):
             rec = json.load(open(f))
         except (OSError, ValueError):
             continue
+        prefixes = kernel_prefix if isinstance(kernel_prefix, (tuple, list)) else (kernel_prefix,)
         for name, v in rec.items():
-            if kernel_prefix in name and grid_threads in (None, v.get("_Grid_Size")) and "hbm_read_bytes_corrected" in v:
+            if any(p in name for p in prefixes) and grid_threads in (None, v.get("_Grid_Size")) and \
+                    "hbm_read_bytes_corrected" in v:
                 best = (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0), os.path.basename(f))
     return best
 
@@ -471,7 +473,7 @@ def eval_f16_leg(dev, steps=3, warmup=1, n_items=50_000_000, d=256, Bu=131072, k
                                 "operands sustains 0.65-0.68 of it on this chip (power-limited, ~1.57 GHz; 0.60 once the A "
                                 "fragments come from LDS at one read per two MFMAs): tools/probes/mfma_energy_probe.hip, "
                                 "profiles/r02_mfma_energy_probe.log"}}
-    tr = measured_traffic("score_topk_wg_kernel<_Float16, %d" % d, None)
+    tr = measured_traffic(("score_topk_wg_kernel<_Float16, %d" % d, "score_topk_wg_kernelIDF16_Li%dE" % d), float(Bu))
     if tr:
         leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1]})
     del V, U, out
@@ -517,7 +519,7 @@ def mask_topk_leg(dev, n_users=4096, n_items=1_000_000, k=20, reps=5):
            "roofline": {"bound": "hbm", "kernel": "mask_topk_kernel<1>", "achieved": byts / (ms[False] * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / (ms[False] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "bytes_per_launch": byts, "traffic": None}}
-    tr = measured_traffic("mask_topk_kernel<1", None)
+    tr = measured_traffic("mask_topk_kernel<1", float(n_users * 64))
     if tr:
         leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1],
                                 "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE per launch, mean over the launches of the "
@@ -818,7 +820,7 @@ def main():
         groups = (Bu + 63) // 64
         tr = None
         if groups >= 2048:       # the library's choice for this shape: the workgroup-cooperative kernel
-            tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8>", float(64 * ((groups + 7) // 8) * 8))
+            tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8,", float(64 * ((groups + 7) // 8) * 8))
         if tr:
             result["roofline"]["traffic"] = tr[0]
             result["roofline"]["traffic_source"] = "committed profile " + tr[1]

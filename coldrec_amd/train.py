@@ -500,6 +500,7 @@ class EpochRunner:
         self.scalars = torch.empty((len(self.steps), 2), dtype=torch.float32, device=dev)
         self.losses = torch.zeros((len(self.steps), 2), dtype=torch.float32, device=dev)
         self.use_graph, self.graph, self.epochs_done = use_graph and not getattr(engine, "lazy", False), None, 0
+        self._sc_pinned = None
         # BPR-MF with cache-resident tables: the whole step is one launch (CRH_MF_FUSED=0 keeps the three-kernel step)
         self.tables = None
         if fused is None:
@@ -531,7 +532,22 @@ class EpochRunner:
             self.tables = ops.mf_step_tables(self.plans, self.u, self.i, self.j, self.B, eng.user_num, eng.item_num,
                                              out=self.tables)
         sc = ops.adam_step_scalars(eng.step_count + 1, len(self.steps), eng.lr)
-        self.scalars.copy_(torch.from_numpy(sc), non_blocking=True)
+        if self.scalars.is_cuda:
+            # through a pinned slot: a copy from pageable memory is staged synchronously, i.e. the host would wait here
+            # for the previous epoch's graph to drain instead of preparing the next one beside it
+            k = self.epochs_done & 1
+            if self._sc_pinned is None:
+                self._sc_pinned = torch.empty((2,) + tuple(self.scalars.shape), dtype=torch.float32, pin_memory=True)
+                self._sc_event = [None, None]
+            if self._sc_event[k] is not None:
+                self._sc_event[k].synchronize()          # the upload that last read this slot (two epochs ago)
+            self._sc_pinned[k].copy_(torch.from_numpy(sc))
+            self.scalars.copy_(self._sc_pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._sc_event[k] = ev
+        else:
+            self.scalars.copy_(torch.from_numpy(sc))
         if self.graph is not None:
             self.graph.replay()
             eng.step_count += len(self.steps)
