@@ -822,8 +822,12 @@ def main():
         if groups >= 2048:       # the library's choice for this shape: the workgroup-cooperative kernel
             tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8,", float(64 * ((groups + 7) // 8) * 8))
         if tr:
-            result["roofline"]["traffic"] = tr[0]
-            result["roofline"]["traffic_source"] = "committed profile " + tr[1]
+            # the profile is of the one-GPU launch over the whole table; a rank's launch streams its shard only
+            # (the traffic is 8 XCD L2s x the table streamed, so it scales with the shard)
+            frac = (hi - lo) / float(args.items)
+            result["roofline"]["traffic"] = tr[0] * frac
+            result["roofline"]["traffic_source"] = "committed profile " + tr[1] + (
+                "" if world == 1 else " (one-GPU launch) scaled by the shard's share of the table")
             result["roofline"]["traffic_note"] = ("L2-miss (fabric-side) bytes per launch from %s; mostly served by the "
                                                   "256 MB Infinity Cache, compulsory HBM bytes are %d" % (
                                                       tr[1], (hi - lo) * d * 4 + Bu * d * 4))
