@@ -913,7 +913,9 @@ int launch_score_per_wave(int esz, int d, int occ, const ScoreArgs& a, hipStream
 
 // Small and mid-size blocks are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any).
 constexpr int64_t DENSE_MAX_ITEMS = 262144;
-constexpr size_t DENSE_MAX_BLOCK = (size_t)1 << 30;
+// users go in chunks when the block would exceed this: 8 GiB (1 GiB chunks ran the same shapes at 0.37-0.43 of the MFMA peak
+// instead of 0.52: too few rows per ranking launch to fill the CUs; tools/midsize_probe.py d<MB> routes)
+constexpr size_t DENSE_MAX_BLOCK = (size_t)8 << 30;
 // Which shapes.  The dense route costs 8 bytes of HBM traffic per (user, item) pair whatever the shape: 0.38 - 0.44 of
 // the fp32 MFMA peak at d=128.  The fused selection pays k (1 + ln(N/k)) slow-path events of ~1.6 us per user (and that
 // again per item-range cut when there are too few user groups to fill the chip), against N/32 tiles of MFMA work.
@@ -929,8 +931,11 @@ size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
     if (n_items > max_items || (n_items > 16384 && (double)n_users * (double)n_items > max_pairs)) return 0;
     const size_t row = (size_t)((n_items + 31) / 32) * 32 * sizeof(float);
     const size_t all = (size_t)n_users * row;
-    if (all <= DENSE_MAX_BLOCK) return (all + 255) & ~(size_t)255;
-    return ((DENSE_MAX_BLOCK / (row * 64)) * 64 * row + 255) & ~(size_t)255;       // whole 64-user groups
+    static const size_t max_block = getenv("CRH_SCORE_DENSE_BLOCK_MB") ? (size_t)atoll(getenv("CRH_SCORE_DENSE_BLOCK_MB")) << 20
+                                                                        : DENSE_MAX_BLOCK;
+    if (all <= max_block) return (all + 255) & ~(size_t)255;
+    const size_t groups = std::max<size_t>(1, max_block / (row * 64));
+    return (groups * 64 * row + 255) & ~(size_t)255;       // whole 64-user groups
 }
 
 // esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
@@ -1004,7 +1009,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     // ~k (1 + ln(N/k)) candidates through the wave-serial slow path (5 - 8 ms for 5 K users x 4 K items, a single
     // wave of 64 users being the critical path).  Instead: the same MFMA kernel writes its score tiles to a dense
     // block (bit-identical scores) and crh_mask_topk_f32 -- one wave per user, same masks, same canonical order --
-    // ranks it; users go in chunks if the block would pass 1 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
+    // ranks it; users go in chunks if the block would pass 8 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
     static const int dense_mode = getenv("CRH_SCORE_DENSE") ? atoi(getenv("CRH_SCORE_DENSE")) : 1;
     const size_t dense_b = dense_block_bytes(n_users, n_items);
     if (dense_mode && n_splits == 0 && dense_b && workspace && workspace_bytes >= dense_b) {
