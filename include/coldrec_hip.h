@@ -58,7 +58,7 @@ int crh_score_topk_supports_dim(int d);
  *              copy of the shard in MFMA-fragment order (n_items*d*4 bytes, written once per call by a
  *              streaming kernel; removes every cross-lane shuffle from the scoring loop).  With only
  *              crh_score_topk_min_workspace_bytes(...) the row-major kernel runs: identical results.
- *              Calls of up to 5e9 (user, item) pairs and 262144 items -- and any user count below 16385 items: the
+ *              Calls of up to 5e9 (user, item) pairs and 262144 items -- and any user count up to 32768 items: the
  *              trainers' per-epoch validation -- take another route when the
  *              full workspace is given and n_splits is 0: the MFMA kernel writes the score block (n_users x
  *              ceil32(n_items) fp32, at most 8 GiB at a time) into the workspace and the wave-per-user ranking of

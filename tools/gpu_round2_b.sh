@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
-SHAPES=C python tools/midsize_probe.py d2048,d4096,d8192,d32768 2>&1 | grep -E "^(auto|d[0-9]+)" | tee gpurun_out/r02_dense_block_probe.log
+SHAPES=D python tools/midsize_probe.py perwav,dense 2>&1 | grep -E "^(auto|dense|perwav|d[0-9]+)" | tee gpurun_out/r02_dense_boundary_probe.log

@@ -22,7 +22,9 @@ SHAPES_A = [(8192, 65536), (8192, 262144), (65536, 65536), (65536, 131072), (655
 SHAPES_B = [(16384, 131072), (16384, 524288), (32768, 131072), (32768, 262144), (32768, 1048576), (131072, 2097152),
             (131072, 4194304)]
 SHAPES_C = [(8192, 262144), (16384, 131072), (65536, 65536), (32768, 131072), (6040, 3706), (262144, 16384)]
-SHAPES = {"B": SHAPES_B, "C": SHAPES_C}.get(os.environ.get("SHAPES"), SHAPES_A)
+SHAPES_D = [(131072, 65536), (65536, 131072), (32768, 262144), (262144, 32768), (131072, 131072), (524288, 16384),
+            (524288, 32768)]
+SHAPES = {"B": SHAPES_B, "C": SHAPES_C, "D": SHAPES_D}.get(os.environ.get("SHAPES"), SHAPES_A)
 
 
 def child():
@@ -55,7 +57,7 @@ if __name__ == "__main__":
     else:
         routes = (("fused", {"CRH_SCORE_DENSE": "0"}),
                   ("perwav", {"CRH_SCORE_DENSE": "0", "CRH_SCORE_WG": "0"}),
-                  ("dense", {"CRH_SCORE_DENSE_MAX_ITEMS": "2000000", "CRH_SCORE_DENSE_USERS_CUT": "100000000"}),
+                  ("dense", {"CRH_SCORE_DENSE_MAX_ITEMS": "2000000", "CRH_SCORE_DENSE_MAX_PAIRS": "1e18"}),
                   ("auto", {}),
                   ("d128", {"CRH_SCORE_DENSE_BLOCK_MB": "128"}), ("d256", {"CRH_SCORE_DENSE_BLOCK_MB": "256"}),
                   ("d512", {"CRH_SCORE_DENSE_BLOCK_MB": "512"}), ("d2048", {"CRH_SCORE_DENSE_BLOCK_MB": "2048"}),
