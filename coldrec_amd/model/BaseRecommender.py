@@ -135,9 +135,16 @@ class BaseColdStartTrainer(ABC):
 
     def _topk_arrays(self, data_set: Dict, data_type: str):
         """(users, scores (n,k) float32, internal item ids (n,k)) on the host, canonical order."""
+        c, s, i = self._topk_device(data_set, data_type)
+        if s is None:
+            return c, np.zeros((0, self.max_N), np.float32), np.zeros((0, self.max_N), np.int32)
+        return c, s.cpu().numpy(), i.cpu().numpy()
+
+    def _topk_device(self, data_set: Dict, data_type: str):
+        """(cache, scores (n,k), internal item ids (n,k)) as device tensors; (cache, None, None) for an empty split."""
         c = self._get_eval_cache(data_set, data_type)
         if len(c['users']) == 0:        # an empty warm / cold / valid split: the reference reports zeros, no kernel runs
-            return c, np.zeros((0, self.max_N), np.float32), np.zeros((0, self.max_N), np.int32)
+            return c, None, None
         fused = self.fused_eval
         if fused is None:
             fused = _is_stock_batch_predict(type(self).batch_predict)
@@ -168,7 +175,7 @@ class BaseColdStartTrainer(ABC):
                 parts_s.append(s)
                 parts_i.append(i)
             s, i = torch.cat(parts_s), torch.cat(parts_i)
-        return c, s.cpu().numpy(), i.cpu().numpy()
+        return c, s, i
 
     def _evaluate(self, data_set: Dict, data_type: str = 'all') -> Dict[Any, List[Tuple[Any, float]]]:
         c, s, i = self._topk_arrays(data_set, data_type)
@@ -182,8 +189,39 @@ class BaseColdStartTrainer(ABC):
         return self._evaluate(self._sets('test', test_type), test_type)
 
     def _metrics(self, data_set: Dict, data_type: str, topn):
-        c, _s, i = self._topk_arrays(data_set, data_type)
-        return ranking_metrics(c['gt_rowptr'], c['gt_items'], i, topn, dense=c['gt_dense'])
+        c, _s, i = self._topk_device(data_set, data_type)
+        if i is None:
+            return ranking_metrics(c['gt_rowptr'], c['gt_items'], np.zeros((0, self.max_N), np.int32), topn)
+        if c['gt_dense'] is not None:
+            # membership of every prediction in its user's ground truth, tested on the GPU against the device copy of the
+            # dense truth table: one bit per prediction comes back instead of scores + ids and a host gather (the host
+            # part of a MovieLens-size validation was 5-6 ms per epoch, twice the epoch's training time)
+            if c.get('gt_dense_dev') is None:
+                c['gt_dense_dev'] = torch.from_numpy(c['gt_dense']).to(i.device)
+                c['row_ids_dev'] = torch.arange(c['gt_dense'].shape[0], device=i.device).unsqueeze(1)
+            idx = i.long()
+            ok = (idx >= 0) & (idx < c['gt_dense_dev'].shape[1])
+            hit = (c['gt_dense_dev'][c['row_ids_dev'], idx.clamp(0, c['gt_dense_dev'].shape[1] - 1)] & ok).cpu().numpy()
+            return ranking_metrics(c['gt_rowptr'], c['gt_items'], None, topn, hit=hit)
+        # ground truth too large for a dense table: sorted (row, item) keys on the device, one binary search per prediction
+        if c.get('gt_keys_dev') is None:
+            n_items = len(self.data.item)
+            rows = np.repeat(np.arange(len(c['users']), dtype=np.int64), np.diff(c['gt_rowptr']))
+            keys = rows * n_items + np.clip(np.asarray(c['gt_items'], np.int64), 0, n_items - 1)
+            keys = keys[np.asarray(c['gt_items']) < n_items]
+            c['gt_keys_dev'] = torch.sort(torch.from_numpy(keys).to(i.device))[0]
+            c['row_ids_dev'] = torch.arange(len(c['users']), device=i.device).unsqueeze(1)
+            c['gt_base'] = n_items
+        keys, base = c['gt_keys_dev'], c['gt_base']
+        idx = i.long()
+        ok = (idx >= 0) & (idx < base)
+        if keys.numel() == 0:
+            hit = torch.zeros_like(ok)
+        else:
+            pk = (c['row_ids_dev'] * base + idx.clamp(0, base - 1)).reshape(-1)
+            pos = torch.searchsorted(keys, pk).clamp(max=keys.numel() - 1)
+            hit = (keys[pos] == pk).reshape(idx.shape) & ok
+        return ranking_metrics(c['gt_rowptr'], c['gt_items'], None, topn, hit=hit.cpu().numpy())
 
     def _metrics_from_rec_list(self, data_set: Dict, data_type: str, rec_list: Dict, topn):
         """Metrics of a caller-supplied ``{user: [(item, score), ...]}`` (what ``test()`` returns, possibly

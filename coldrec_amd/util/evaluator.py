@@ -54,13 +54,21 @@ def hit_matrix(gt_rowptr: np.ndarray, gt_items: np.ndarray, pred: np.ndarray, de
     return np.isin(pr_keys, gt_keys)
 
 
-def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None) -> List[List[float]]:
+def _seq_sum(x: np.ndarray) -> float:
+    """Left-to-right float64 sum, as Python's sum() over the reference's per-user lists (np.cumsum adds strictly in
+    order; np.sum is pairwise and rounds differently)."""
+    return float(np.cumsum(np.asarray(x, np.float64))[-1]) if len(x) else 0.0
+
+
+def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None, hit=None) -> List[List[float]]:
     """[[hit ratio, precision, recall, ndcg] for n in topn]; pred is (users, >= max(topn)); ``dense``: optional
-    ``truth_dense`` table of the same ground truth."""
+    ``truth_dense`` table of the same ground truth; ``hit``: the bool (users, k) membership matrix when the caller
+    already has it (the trainers test membership on the GPU and bring back one bit per prediction)."""
     gt_rowptr = np.asarray(gt_rowptr, np.int64)
     n_user = gt_rowptr.shape[0] - 1
     tlen = np.diff(gt_rowptr)
-    hit = hit_matrix(gt_rowptr, np.asarray(gt_items), np.asarray(pred), dense)
+    if hit is None:
+        hit = hit_matrix(gt_rowptr, np.asarray(gt_items), np.asarray(pred), dense)
     out = []
     for n in topn:
         h = hit[:, :n]
@@ -69,7 +77,7 @@ def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None) 
         hr = round(int(hits.sum()) / total_truth, 5) if total_truth else 0.0
         prec = round(int(hits.sum()) / (n_user * n), 5) if n_user and n else 0.0
         has = tlen > 0
-        recall = round(float(sum((hits[has] / tlen[has]).tolist())) / int(has.sum()), 5) if has.any() else 0.0
+        recall = round(_seq_sum(hits[has] / tlen[has]) / int(has.sum()), 5) if has.any() else 0.0
         w = np.array([1.0 / math.log(q + 2, 2) for q in range(n)])
         cw = np.concatenate([[0.0], np.cumsum(w)])
         dcg = np.zeros(n_user)
@@ -77,7 +85,7 @@ def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None) 
             dcg = dcg + np.where(h[:, q], w[q], 0.0)
         idcg = cw[np.minimum(tlen, n)]
         ok = idcg > 0
-        ndcg = round(float(sum((dcg[ok] / idcg[ok]).tolist())) / int(ok.sum()), 5) if ok.any() else 0.0
+        ndcg = round(_seq_sum(dcg[ok] / idcg[ok]) / int(ok.sum()), 5) if ok.any() else 0.0
         out.append([hr, prec, recall, ndcg])
     return out
 
