@@ -253,6 +253,93 @@ def midsize_eval_leg(dev):
     return {"eval_midsize": out}
 
 
+def torch_rocm_leg(dev):
+    """The reference's own library calls (model/MF.py:12-29, model/LightGCN.py:14-29,86-96,
+    model/BaseRecommender.py:172-183) on the SAME GPU through stock PyTorch-ROCm -- what a ColdRec checkout does with
+    --use_gpu -- at the shapes of the train legs and on a 1024-user block of the headline.  Context only (plain torch,
+    no oracle): not a target and not the CPU baseline."""
+    from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
+
+    def bpr_loss(u, p, n):                      # util/utils.py:25-29
+        return torch.mean(-torch.log(10e-6 + torch.sigmoid((u * p).sum(1) - (u * n).sum(1))))
+
+    def l2_reg(reg, *embs):                     # util/utils.py:44-48
+        loss = 0
+        for e in embs:
+            loss = loss + torch.norm(e, p=2) / e.shape[0]
+        return loss * reg
+
+    def train(n_u, n_i, n_pairs, d, B, layers, steps=60):
+        rng = np.random.default_rng(1)
+        U = torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(n_u, d, device=dev)))
+        V = torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(n_i, d, device=dev)))
+        opt = torch.optim.Adam([U, V], lr=1e-3)
+        adj = None
+        if layers:
+            pairs = np.unique(np.stack([rng.integers(0, n_u, n_pairs), rng.integers(0, n_i, n_pairs)], 1), axis=0)
+            rowptr, col, val = bipartite_norm_adj_csr(pairs[:, 0], pairs[:, 1], n_u, n_i)
+            rows = np.repeat(np.arange(n_u + n_i), np.diff(rowptr))
+            adj = torch.sparse_coo_tensor(np.stack([rows, col]), val, (n_u + n_i, n_u + n_i)).coalesce().to(dev)
+        tri = [tuple(torch.from_numpy(rng.integers(0, n, B)).to(dev) for n in (n_u, n_i, n_i)) for _ in range(8)]
+
+        def step(s):
+            u, i, j = tri[s % 8]
+            if layers:                          # model/LightGCN.py:86-96
+                ego = torch.cat([U, V], 0)
+                outs = [ego]
+                for _ in range(layers):
+                    ego = torch.sparse.mm(adj, ego)
+                    outs.append(ego)
+                out = torch.mean(torch.stack(outs, dim=1), dim=1)
+                ue, ie = out[:n_u], out[n_u:]
+            else:
+                ue, ie = U, V
+            a, b, c = ue[u], ie[i], ie[j]
+            loss = bpr_loss(a, b, c) + l2_reg(1e-4, a, b, c)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        for s in range(5):
+            step(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            step(s)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return {"ms_per_step": ms, "triples_per_s": B / ms * 1e3}
+
+    out = {"note": "stock PyTorch-ROCm (%s) running the reference's calls on this GPU; eager, as the reference" % torch.__version__,
+           "train_mf": train(6040, 3706, 0, 128, 4096, 0),
+           "train_lightgcn": train(5551, 16980, 131000, 128, 4096, 3)}
+    n_users, n_items, d, k = 1024, 10_000_000, 128, 20
+    V = item_shard(n_items, d, 0, n_items, dev)
+    U = xavier_(n_users, d, 17, dev, 1_000_000)
+    rowptr, col = rated_lists(n_users, n_items, 50, seed=4)
+    cold = torch.from_numpy(np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]).to(dev)
+    rated = [torch.from_numpy(col[rowptr[r]:rowptr[r + 1]].astype(np.int64)).to(dev) for r in range(n_users)]
+
+    def block():                                # model/BaseRecommender.py:172-183 for one user block
+        S = U @ V.T
+        for r in range(n_users):
+            S[r, rated[r]] = -10e8
+        S[:, cold] = -10e8
+        return torch.topk(S, k, dim=1, largest=True, sorted=True)
+
+    block()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        block()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / 2
+    out["eval"] = {"users_per_block": n_users, "items": n_items, "ms_per_block": sec * 1e3,
+                   "items_per_s": n_users * n_items / sec}
+    del V, U
+    return {"torch_rocm_same_gpu": out}
+
+
 def train_legs(dev, with_cpu, e2e_epochs=30):
     """Secondary metric of BASELINE.json: BPR triples/s (train): configs[1] (BPR-MF, MovieLens shape, d=128) with
     Adam as the reference and with plain SGD (the north_star's "BPR loss + SGD update"), configs[2] (LightGCN L=3,
@@ -472,7 +559,8 @@ def eval_f16_leg(dev, steps=3, warmup=1, n_items=50_000_000, d=256, Bu=131072, k
                         "note": "peak is the nominal dense fp16 figure; a bare v_mfma_f32_32x32x16_f16 stream with random "
                                 "operands sustains 0.65-0.68 of it on this chip (power-limited, ~1.57 GHz; 0.60 once the A "
                                 "fragments come from LDS at one read per two MFMAs): tools/probes/mfma_energy_probe.hip, "
-                                "profiles/r02_mfma_energy_probe.log"}}
+                                "profiles/r02_mfma_energy_probe.log; hipBLASLt fp16 GEMMs reach 0.60 at best and 0.25 at this "
+                                "K = 256 shape: profiles/r02_gemm_f16_probe.log"}}
     tr = measured_traffic(("score_topk_wg_kernel<_Float16, %d" % d, "score_topk_wg_kernelIDF16_Li%dE" % d), float(Bu))
     if tr:
         leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1]})
@@ -688,7 +776,7 @@ def main():
     ap.add_argument("--cpu-sample-users", type=int, default=2048,
                     help="users of the CPU baseline (blocks of 256 against the WHOLE item table, SURVEY.md 8(d))")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="the CPU baseline stops after this many seconds")
-    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train,eval_validation,eval_midsize",
+    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train,eval_validation,eval_midsize,torch_rocm",
                     help="N=1: secondary legs carried in the same JSON line (comma separated; 'none' = headline only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the last timed step")
     args = ap.parse_args()
@@ -902,7 +990,8 @@ def main():
                              ("train_xl", lambda: {"train_xl": train_xl(dev, 3, 1)}),
                              ("train", lambda: train_legs(dev, not args.no_cpu_baseline)),
                              ("eval_validation", lambda: validation_eval_leg(dev)),
-                             ("eval_midsize", lambda: midsize_eval_leg(dev))):
+                             ("eval_midsize", lambda: midsize_eval_leg(dev)),
+                             ("torch_rocm", lambda: torch_rocm_leg(dev))):
             if leg_name in legs:
                 result.update(fn())
                 torch.cuda.empty_cache()
