@@ -229,3 +229,21 @@ def test_dense_truth_lookup_equals_sorted_membership():
     assert np.array_equal(hit_matrix(rp, gt, pred), hit_matrix(rp, gt, pred, dense))
     assert ranking_metrics(rp, gt, pred, [10, 20]) == ranking_metrics(rp, gt, pred, [10, 20], dense=dense)
     assert truth_dense(rp, gt, n_i, max_cells=1000) is None    # too large: callers fall back to the sort
+
+
+def test_metrics_from_a_precomputed_hit_matrix_and_sequential_sums():
+    """ranking_metrics(hit=...) (the trainers test membership on the GPU and bring back one bit per prediction) ==
+    the same metrics from the predictions; the per-user averages are summed left to right like the reference's
+    Python sum() (np.cumsum), not pairwise."""
+    from coldrec_amd.util.evaluator import _seq_sum, hit_matrix, ranking_metrics
+    rng = np.random.default_rng(5)
+    n_u, n_i, k = 3000, 900, 20
+    lens = rng.integers(0, 30, n_u)
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    gt = np.concatenate([rng.choice(n_i, l, replace=False) for l in lens])
+    pred = np.stack([rng.choice(n_i, k, replace=False) for _ in range(n_u)])
+    hit = hit_matrix(rp, gt, pred)
+    assert ranking_metrics(rp, gt, None, [10, 20], hit=hit) == ranking_metrics(rp, gt, pred, [10, 20])
+    x = rng.random(100_000) / 3.0
+    assert _seq_sum(x) == float(sum(x.tolist()))
+    assert _seq_sum(np.zeros(0)) == 0.0
