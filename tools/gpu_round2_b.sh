@@ -1,9 +1,5 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
-for i in 1 2; do
-python bench.py --train-only --no-cpu-baseline 2>&1 | grep -v amdgpu | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); v=d['train_lightgcn']; print('occ7 lightgcn ms/step', v['ms_per_step'], 'e2e', v.get('value_end_to_end'))"
-done
-timeout 600 python -m pytest tests/test_train_gpu.py -x -q -k "spmm or lgcn or lightgcn" 2>&1 | grep -v -i -E "rccl|amdgpu|^$" | tail -3
+SHAPES=E python tools/midsize_probe.py auto,perwav,dense 2>&1 | grep -E "^(auto|dense|perwav)"
+python bench.py --legs eval_midsize --no-cpu-baseline --no-verify --steps 1 --warmup 0 2>&1 | grep -v amdgpu | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:round(v['ms'],2) for k,v in d['eval_midsize'].items()})"

@@ -24,7 +24,8 @@ SHAPES_B = [(16384, 131072), (16384, 524288), (32768, 131072), (32768, 262144), 
 SHAPES_C = [(8192, 262144), (16384, 131072), (65536, 65536), (32768, 131072), (6040, 3706), (262144, 16384)]
 SHAPES_D = [(131072, 65536), (65536, 131072), (32768, 262144), (262144, 32768), (131072, 131072), (524288, 16384),
             (524288, 32768)]
-SHAPES = {"B": SHAPES_B, "C": SHAPES_C, "D": SHAPES_D}.get(os.environ.get("SHAPES"), SHAPES_A)
+SHAPES_E = [(65536, 131072), (65536, 131072), (131072, 262144)]
+SHAPES = {"B": SHAPES_B, "C": SHAPES_C, "D": SHAPES_D, "E": SHAPES_E}.get(os.environ.get("SHAPES"), SHAPES_A)
 
 
 def child():
