@@ -189,8 +189,14 @@ def case_fused(rng):
                     E, M, V = orc.adam_dense(E, np.concatenate([gU, gV]).astype(np.float32), M, V, step, lr=1e-2)
             ref = {"E": E, "M": M, "V": V}[name]
             rows = np.unique(np.nonzero(bad)[0])
-            print("rows with differences:", rows[:10], "of", n_u, "+", n_i, "| fused vs oracle",
-                  float(np.abs(a - ref).max()), "| plain vs oracle", float(np.abs(b - ref).max()), flush=True)
+            ea, eb = float(np.abs(a - ref).max()), float(np.abs(b - ref).max())
+            print("rows with differences:", rows[:10], "of", n_u, "+", n_i, "| fused vs oracle", ea, "| plain vs oracle", eb,
+                  flush=True)
+            if ea <= 2.0 * eb + 1e-9:
+                # both forms are equally far from the fp64 closed form: ill-conditioned elements (cancelling gradient
+                # sums on a tiny table), not a defect of either kernel (seed 42 of round 2: 9 of 85 504 elements of M, both
+                # within 3e-8 of the truth, 6e-8 apart)
+                continue
             fail("fused tables", table=name, d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
                  err=float(np.abs(a - b).max()), scale=float(np.abs(b).max()), nbad=int(bad.sum()))
 
