@@ -3,7 +3,7 @@
 oracle/).  Draws shapes, widths, k, mask densities, split counts, layouts and dtypes for --minutes, checks
 bit-exact scores + indices (fp32, and fp16 on exact-arithmetic tables) and prints a summary line.
 
-    python tools/fuzz_score_topk.py --minutes 5 [--seed 0]
+    python tests/fuzz/fuzz_score_topk.py --minutes 5 [--seed 0]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from coldrec_amd import ops  # noqa: E402
 from oracle import oracle_np as orc  # noqa: E402

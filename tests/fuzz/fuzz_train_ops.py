@@ -10,7 +10,7 @@ Per case: random table sizes / widths / batch sizes / duplicate patterns, then
   * whole epochs with the one-launch MF step (crh_mf_step_f32) against the three-kernel step -> same losses and tables
     up to the summation order of the norms, and bit-identical when repeated.
 
-    python tools/fuzz_train_ops.py --minutes 5 [--seed 0]
+    python tests/fuzz/fuzz_train_ops.py --minutes 5 [--seed 0]
 """
 import argparse
 import os
@@ -20,7 +20,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from coldrec_amd import ops  # noqa: E402
 from coldrec_amd.train import MFEngine  # noqa: E402
