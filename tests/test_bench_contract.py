@@ -1,0 +1,35 @@
+"""bench.py's host-side contract pieces that need no GPU: the committed-profile traffic lookup (kernel instantiation +
+grid must match, newest record wins) and the argument defaults the driver relies on."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_traffic_lookup_matches_instantiation_and_grid():
+    import bench
+    head = bench.measured_traffic("score_topk_wg_kernel<float, 128, 2, 8,", 131072.0)
+    assert head is not None and head[1].startswith("r02_") and 3.5e10 < head[0] < 6e10       # 8 XCDs x the 5.12 GB table
+    assert bench.measured_traffic("score_topk_wg_kernel<float, 128, 2, 8,", 12345.0) is None   # another grid: no record
+    f16 = bench.measured_traffic(("score_topk_wg_kernel<_Float16, 256", "score_topk_wg_kernelIDF16_Li256E"), 131072.0)
+    assert f16 is not None and 1.5e11 < f16[0] < 3e11                                          # 8 x the 25.6 GB table
+    mk = bench.measured_traffic("mask_topk_kernel<1", 4096 * 64.0)
+    assert mk is not None and 1.6e10 <= mk[0] < 3.5e10                                         # the 16.4 GB block (+ write-back share)
+    assert bench.measured_traffic("no_such_kernel", None) is None
+
+
+def test_default_command_line_and_legs():
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for leg in ("eval_f16", "mask_topk", "train_xl", "train", "eval_validation", "eval_midsize", "torch_rocm"):
+        assert leg in src
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_c.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["vs_baseline"] is None and rec["roofline"]["bound"] == "mfma" and rec["cpu_baseline"]["kind"] == "port"
+    assert set(rec["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-9
+    assert bench.MFMA_F32_PEAK_TFLOPS == 157.3 and bench.HBM_PEAK_GBS == 8000.0
