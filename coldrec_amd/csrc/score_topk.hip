@@ -13,10 +13,11 @@
 //   * fp32: v_mfma_f32_32x32x2_f32 issued in k order into ONE accumulator per (item tile, user tile) --
 //     bit-identical to the canonical fp32 fma chain of the oracle (oracle/topk_oracle.c).  fp16 tables:
 //     v_mfma_f32_32x32x16_f16 with fp32 accumulation.
-//   * only tiles that contain a score above tau take the slow path: each candidate is checked against the
-//     masks (bitmap bit + rated list in one memory round trip) and inserted into the user's sorted list in
-//     LDS by the whole wave (topk_list.h).  Expected slow-path events per user are ~ k*ln(range/k),
-//     against range/32 tiles.
+//   * only tiles that contain a score above tau take the slow path (tile_slow_path): the candidate-bitmap bits of the
+//     tile are one wave-uniform load, masked candidates of full lists are dropped up front, the rated list is searched
+//     in memory only when the user's LDS membership filter says so, and survivors are inserted into the user's sorted
+//     list in LDS by the whole wave (topk_list.h).  Expected slow-path events per user are ~ k*ln(range/k), against
+//     range/32 tiles.
 //   * the grid is (user groups) x (item-range splits); partial lists are merged by merge_topk with the same
 //     canonical key, so the result does not depend on the split count, on the tiling or (after the
 //     all-gather) on the GPU count.
@@ -25,10 +26,12 @@
 // Two kernels:
 //   * score_topk_kernel      one wave = one workgroup, waves never synchronise; two waves per SIMD hide each
 //                            other's stalls; optional soft lockstep of the waves of an XCD (L2 locality).
-//                            Small launches, every width, the row-major fallback.
+//                            Small and mid-size catalogues (below 2 M items), every width, the row-major fallback; also
+//                            the producer of the dense score block that crh_mask_topk_f32 ranks (small calls).
 //   * score_topk_wg_kernel   the 8 waves of a workgroup walk the tiles together through a three-slot LDS ring
-//                            (1/8 of the L2 -> CU traffic): fp16 (where the per-wave stream is the bound) and
-//                            fp32 d=128 launches of >= 512 user groups.
+//                            (1/8 of the L2 -> CU traffic), 1 / 2 / 4 tiles per slot by row width, the workgroups of an
+//                            XCD in soft lockstep: fp16 (where the per-wave stream is the bound) and fp32 d=128
+//                            launches of >= 2 M items whose 512-user workgroups fill the CUs.
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
