@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <string>
 #include <new>
 
 #include "crh_common.h"
@@ -30,6 +31,7 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_once;
+std::string g_rccl_err;      // dlerror() of the last failed dlopen, captured once (a second dlerror() call returns NULL)
 
 void load_rccl() {
     static const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -37,8 +39,11 @@ void load_rccl() {
     for (const char* n : names)                      // a copy that is already mapped (PyTorch's) wins
         if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     if (!h)
-        for (const char* n : names)
+        for (const char* n : names) {
             if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+            const char* e = dlerror();
+            if (e) g_rccl_err = e;
+        }
     if (!h) return;
     g_rccl.handle = h;
 #define CRH_SYM(field, sym) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, sym))
@@ -54,7 +59,7 @@ void load_rccl() {
 
 bool need_rccl(const char* who) {
     std::call_once(g_once, load_rccl);
-    if (!g_rccl.ok) crh_set_error("%s: librccl.so could not be loaded (%s)", who, dlerror() ? dlerror() : "symbols missing");
+    if (!g_rccl.ok) crh_set_error("%s: librccl.so could not be loaded (%s)", who, g_rccl_err.empty() ? "symbols missing" : g_rccl_err.c_str());
     return g_rccl.ok;
 }
 

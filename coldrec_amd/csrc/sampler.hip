@@ -195,7 +195,8 @@ struct crh_sampler {
     std::thread worker;
     std::mutex wm;
     std::condition_variable wcv;
-    std::atomic<int> job{0};              // 0 idle, 1 queued, 2 running, 3 done, -1 shut down
+    std::atomic<int> job{0};              // 0 idle, 1 queued, 2 running, 3 done
+    std::atomic<bool> shutdown{false};    // set by crh_sampler_destroy only; never overwritten by a finishing job
     int64_t job_batch = 0;
     int32_t *job_u = nullptr, *job_p = nullptr, *job_n = nullptr;
     int job_rc = 0, job_snapshot = 0;
@@ -281,8 +282,11 @@ extern "C" void crh_sampler_destroy(crh_sampler* s) {
     if (!s) return;
     if (s->worker.joinable()) {
         {
-            std::lock_guard<std::mutex> lk(s->wm);
-            s->job.store(-1);
+            // an epoch that is queued or running is allowed to finish first: the worker writes the caller's output
+            // arrays until then, so returning earlier would let them be freed under it
+            std::unique_lock<std::mutex> lk(s->wm);
+            s->wcv.wait(lk, [&] { const int j = s->job.load(); return j == 0 || j == 3; });
+            s->shutdown.store(true);
         }
         s->wcv.notify_all();
         s->worker.join();
@@ -464,19 +468,20 @@ namespace {
 void sampler_worker(crh_sampler* s) {
     for (;;) {
         int st = s->job.load(std::memory_order_acquire);
-        if (st != 1 && st != -1) {      // stay hot for ~30 ms, then sleep until a job (or the shutdown) arrives
+        if (st != 1 && !s->shutdown.load(std::memory_order_acquire)) {
+            // stay hot for ~30 ms, then sleep until a job (or the shutdown) arrives
             const auto t0 = std::chrono::steady_clock::now();
-            while ((st = s->job.load(std::memory_order_acquire)) != 1 && st != -1) {
+            while ((st = s->job.load(std::memory_order_acquire)) != 1 && !s->shutdown.load(std::memory_order_acquire)) {
                 __builtin_ia32_pause();
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(30)) {
                     std::unique_lock<std::mutex> lk(s->wm);
-                    s->wcv.wait(lk, [&] { const int j = s->job.load(); return j == 1 || j == -1; });
+                    s->wcv.wait(lk, [&] { return s->job.load() == 1 || s->shutdown.load(); });
                     st = s->job.load();
                     break;
                 }
             }
         }
-        if (st == -1) return;
+        if (st != 1) return;            // shut down (destroy never sets the flag while a job is queued or running)
         s->job.store(2, std::memory_order_release);
         // the snapshot is taken HERE, on the core that is about to shuffle: copied by the calling thread, the 2.6 MB
         // permutation would sit in that core's cache and every line of it would have to migrate back (measured at
@@ -515,7 +520,7 @@ extern "C" int crh_sampler_epoch_async(crh_sampler* s, int64_t batch_size, int32
 extern "C" int crh_sampler_epoch_wait(crh_sampler* s) {
     CRH_CHECK_ARG(s, "crh_sampler_epoch_wait: NULL sampler");
     int st = s->job.load(std::memory_order_acquire);
-    CRH_CHECK_ARG(st != 0 && st != -1, "crh_sampler_epoch_wait: no epoch in flight");
+    CRH_CHECK_ARG(st != 0, "crh_sampler_epoch_wait: no epoch in flight");
     // SLEEP until the worker is done: a waiter that spins (or yields in a loop) on the hyperthread next to the worker
     // takes a third of its speed (measured: 4.2 ms per epoch with a spinning waiter, 2.6 ms with a sleeping one)
     if ((st = s->job.load(std::memory_order_acquire)) != 3) {

@@ -213,13 +213,19 @@ class EpochPrefetcher:
             self._t_sync = time.perf_counter() - _t
         pu, pi, pj = self._ptrs(k)
         self._slot, self._async = k, self.enabled
-        try:
-            if self.enabled:
+        if self.enabled:
+            try:
                 _lib.check(self.s._L.crh_sampler_epoch_async(self.s._h, self.B, pu, pi, pj, 1), "crh_sampler_epoch_async")
-            else:
-                _lib.check(self.s._L.crh_sampler_epoch(self.s._h, self.B, pu, pi, pj), "crh_sampler_epoch")
+            except BaseException:
+                # the job was never queued, so the worker took no snapshot of THIS epoch and nothing has moved:
+                # restoring here would roll permutation and generator back to the previous epoch's snapshot
+                self._base = self._slot = None
+                raise
+            return
+        try:
+            _lib.check(self.s._L.crh_sampler_epoch(self.s._h, self.B, pu, pi, pj), "crh_sampler_epoch")
         except BaseException:
-            self._abort()
+            self._abort()      # the snapshot taken above belongs to this epoch
             raise
 
     def _abort(self) -> None:

@@ -346,7 +346,10 @@ class LGCNEngine(_TableState):
         e0, e1 = int(self.rowptr[r0]), int(self.rowptr[r1])
         self.rs_rowptr = (self.rowptr[r0:r1 + 1] - e0).contiguous()
         self.rs_col, self.rs_val = self.col[e0:e1].contiguous(), self.val[e0:e1].contiguous()
-        self.rs_sched = self.k.SpmmSchedule(self.rs_rowptr.cpu().numpy(), dev) if r1 > r0 else None
+        # the heavy-row threshold of the FULL graph: a row block of a bipartite graph (all user rows / all item rows) can
+        # have a mean degree on the other side of the automatic rule, and a row summed as "heavy" on one engine and
+        # "light" on the other would differ in its fp32 association
+        self.rs_sched = self.k.SpmmSchedule(self.rs_rowptr.cpu().numpy(), dev, seg=self.sched.seg) if r1 > r0 else None
         self.rs = (rows, r0, r1)
         pad = G * rows
         E_pad = torch.zeros((pad, d), dtype=torch.float32, device=dev)     # E becomes a view of the gather target

@@ -178,24 +178,42 @@ def case_fused(rng):
         # a handful of such elements, bounded by what the steps taken can move them
         bad = ~np.isclose(a, b, rtol=5e-4, atol=1e-5 * np.abs(b).max())
         if bad.sum() > max(2, 1e-4 * bad.size) or (name == "E" and np.abs(a - b).max() > 2 * 1e-2 * n_steps):
-            # which of the two left the closed form?  (fp64 gradients + the oracle's Adam, step by step)
+            # Which of the two left the closed form?  fp64 gradients + the oracle's Adam, step by step, and beside each
+            # gradient element the sum of the ABSOLUTE values of its terms, A: an fp32 sum of those terms -- in any
+            # order -- is only good to ~d * eps32 * A, so an element with |g| below that floor carries a gradient whose
+            # sign is rounding noise, and Adam's m / (sqrt(v) + eps) turns that into anything in [-lr, lr].
             E, M, V = np.concatenate([U0, V0]), np.zeros((n_u + n_i, d), np.float32), np.zeros((n_u + n_i, d), np.float32)
-            step = 0
+            step, eps32 = 0, float(np.finfo(np.float32).eps)
+            a_max = np.zeros((n_u + n_i, d))
+            noisy = np.zeros((n_u + n_i, d), bool)
             for (eu, ei, ej) in epochs:
                 for lo in range(0, n_rec, B):
                     sl = slice(lo, min(lo + B, n_rec))
-                    _, _, gU, gV, _ = orc.bpr_l2_fwd_bwd(E[:n_u], E[n_u:], eu[sl], ei[sl], ej[sl], 1e-3)
+                    _, _, gU, gV, (tu, tp, tn) = orc.bpr_l2_fwd_bwd(E[:n_u], E[n_u:], eu[sl], ei[sl], ej[sl], 1e-3)
+                    A = np.zeros((n_u + n_i, d))
+                    np.add.at(A, eu[sl], np.abs(tu))
+                    np.add.at(A, n_u + ei[sl].astype(np.int64), np.abs(tp))
+                    np.add.at(A, n_u + ej[sl].astype(np.int64), np.abs(tn))
+                    g = np.concatenate([gU, gV])
+                    noisy |= (A > 0) & (np.abs(g) <= 4.0 * d * eps32 * A)
+                    a_max = np.maximum(a_max, A)
                     step += 1
-                    E, M, V = orc.adam_dense(E, np.concatenate([gU, gV]).astype(np.float32), M, V, step, lr=1e-2)
+                    E, M, V = orc.adam_dense(E, g.astype(np.float32), M, V, step, lr=1e-2)
             ref = {"E": E, "M": M, "V": V}[name]
             rows = np.unique(np.nonzero(bad)[0])
             ea, eb = float(np.abs(a - ref).max()), float(np.abs(b - ref).max())
             print("rows with differences:", rows[:10], "of", n_u, "+", n_i, "| fused vs oracle", ea, "| plain vs oracle", eb,
-                  flush=True)
-            if ea <= 2.0 * eb + 1e-9:
-                # both forms are equally far from the fp64 closed form: ill-conditioned elements (cancelling gradient
-                # sums on a tiny table), not a defect of either kernel (seed 42 of round 2: 9 of 85 504 elements of M, both
-                # within 3e-8 of the truth, 6e-8 apart)
+                  "| noise-floor elements among them:", int((bad & noisy).sum()), "of", int(bad.sum()), flush=True)
+            if name == "M":
+                # m is linear in the gradients: an ABSOLUTE bound for each form on its own (a convex combination of the
+                # steps' gradients, each good to ~d * eps32 * A) -- the one-launch step gets no credit for the
+                # three-kernel step being worse
+                tol = 8.0 * d * eps32 * a_max + 1e-12
+                if (np.abs(a - ref) <= tol).all() and (np.abs(b - ref) <= tol).all():
+                    continue
+            elif not (bad & ~noisy).any():
+                # E and V are not linear in g; the only elements excused are those whose gradient sat on its own noise
+                # floor in some step (seed 42 of round 2: 9 of 85 504 elements on a 50 x 284 table)
                 continue
             fail("fused tables", table=name, d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
                  err=float(np.abs(a - b).max()), scale=float(np.abs(b).max()), nbad=int(bad.sum()))

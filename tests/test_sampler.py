@@ -1,5 +1,6 @@
 """CPU: the product's C++ host sampler against the reference's own triples (golden g1) and
 against the numpy-RNG oracle on other seeds / batch sizes."""
+import os
 import time
 
 import numpy as np
@@ -397,3 +398,37 @@ def test_shuffle_scan_groups_of_64_equal_the_serial_draws():
             i -= 1
         got, used, _, _ = dnp.shuffle_scan(raw, n)
         assert used == q and np.array_equal(got, J), n
+
+
+def test_destroy_while_a_background_epoch_is_running_returns():
+    """ADVICE.md (round 2): crh_sampler_destroy during a RUNNING background epoch used to hang -- the finishing job
+    overwrote the shutdown flag.  Destroy now lets the epoch finish (the worker owns the output arrays until then),
+    then stops the worker.  Run in a child process so a regression is a timeout, not a hung suite."""
+    import subprocess
+    import sys
+    code = r"""
+import time, numpy as np
+from coldrec_amd.sampler import PairwiseSampler
+rng = np.random.default_rng(0)
+n_u, n_i, n = 20000, 30000, 3000000
+s = PairwiseSampler(rng.integers(0, n_u, n), rng.integers(0, n_i, n), n_u, n_i)
+s.seed(1)
+out = [np.empty(n, np.int32) for _ in range(3)]
+for delay, wait in ((0.0, True), (0.05, True), (0.003, False)):
+    out[0][:] = -1
+    rc = s._L.crh_sampler_epoch_async(s._h, 4096, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, 1)
+    assert rc == 0
+    time.sleep(delay)
+    if wait:
+        assert s._L.crh_sampler_epoch_wait(s._h) == 0
+assert (out[0] < 0).any()            # 3 ms into a 3 M-record epoch: the worker is still writing
+h, s._h = s._h, None
+t0 = time.perf_counter()
+s._L.crh_sampler_destroy(h)          # job == 2 (running) at this point
+assert (out[0] >= 0).all() and (out[0] < n_u).all()      # the epoch was completed before the worker stopped
+print("destroyed in %.3f s" % (time.perf_counter() - t0))
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "destroyed in" in r.stdout
