@@ -935,8 +935,9 @@ size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
     if (n_items > max_items || (n_items > 32768 && (double)n_users * (double)n_items > max_pairs)) return 0;
     const size_t row = (size_t)((n_items + 31) / 32) * 32 * sizeof(float);
     const size_t all = (size_t)n_users * row;
-    static const size_t max_block = getenv("CRH_SCORE_DENSE_BLOCK_MB") ? (size_t)atoll(getenv("CRH_SCORE_DENSE_BLOCK_MB")) << 20
-                                                                        : DENSE_MAX_BLOCK;
+    // read per call (like CRH_SCORE_WG): the chunking tests lower it to cut a small block into many user chunks
+    const char* mb_env = getenv("CRH_SCORE_DENSE_BLOCK_MB");
+    const size_t max_block = mb_env && atoll(mb_env) > 0 ? (size_t)atoll(mb_env) << 20 : DENSE_MAX_BLOCK;
     if (all <= max_block) return (all + 255) & ~(size_t)255;
     const size_t groups = std::max<size_t>(1, max_block / (row * 64));
     return (groups * 64 * row + 255) & ~(size_t)255;       // whole 64-user groups

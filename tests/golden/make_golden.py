@@ -22,6 +22,10 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g8_e2e.json      model/BaseRecommender.py:353-370  MF.run() d=64, 3 epochs, test metrics
   g9_dropoutnet.*  model/DropoutNet.py:12-72  DropoutNet.run() on the g8 tables, 2 epochs: losses, tables, metrics
   g10_samplers.npz util/utils.py:160-336   next_batch_pairwise_LARA / _CLCRec / _CCFCRec / next_batch_cgrc, 2 epochs each
+  g11_lgcn_e2e.*   model/LightGCN.py:14-51 + BaseRecommender.py:353-370  LightGCN.run() L=3, d=64, 3 epochs: losses,
+                   metrics, best-epoch snapshot tables, final top-20 lists of the three test settings
+  g8_lists.npz / g9_lists.npz  model/BaseRecommender.py:153-188  the final top-20 lists of the g8 / g9 runs (re-run,
+                   tables asserted equal to the stored ones) with the eval inputs needed to re-derive rank margins
 """
 import json
 import os
@@ -458,7 +462,99 @@ def g10_samplers(split):
     np.savez_compressed(out("g10_samplers.npz"), **res)
 
 
+def _final_lists(trainer, data):
+    """trainer.test(t) for the three settings -> ids (internal), fp32 scores, eval users, rated CSR, candidate mask."""
+    res = {}
+    for t in ("all", "cold", "warm"):
+        test_set = {"all": data.overall_test_set, "warm": data.warm_test_set, "cold": data.cold_test_set}[t]
+        rec = trainer.test(t)
+        users = list(test_set.keys())
+        assert list(rec.keys()) == users
+        cache = trainer._get_eval_cache(test_set, t)
+        rated = [r.numpy() if r is not None else np.zeros(0, np.int64) for r in cache["rated_item_ids"]]
+        cand = cache["candidate_mask"].numpy() if cache["candidate_mask"] is not None else np.zeros(0, np.int64)
+        res.update({
+            f"{t}_users_int": np.array([data.user[u] for u in users], np.int64),
+            f"{t}_rated_rowptr": np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64),
+            f"{t}_rated_col": np.concatenate(rated).astype(np.int64) if rated else np.zeros(0, np.int64),
+            f"{t}_cand": cand.astype(np.int64),
+            f"{t}_idx": np.array([[data.item[it] for it, _ in rec[u]] for u in users], np.int64),
+            f"{t}_score": np.array([[sc for _, sc in rec[u]] for u in users], np.float32)})
+    return res
+
+
+def _run_quiet(trainer):
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        trainer.run()
+    return [ln for ln in buf.getvalue().splitlines() if ln.startswith("training:")]
+
+
+def g8_lists(split):
+    """The g8 run again (same seeds -> same tables, asserted) for the lists its final tables produce."""
+    data = ref_builder(split)
+    cfg = ref_config(data, emb_size=64, epochs=3, bs=512)
+    set_seed(2024, False)
+    trainer = MF(cfg)
+    _run_quiet(trainer)
+    emb = np.load(out("g8_e2e_emb.npz"))
+    assert np.array_equal(trainer.user_emb.detach().numpy(), emb["U"]) and np.array_equal(trainer.item_emb.detach().numpy(), emb["V"])
+    np.savez_compressed(out("g8_lists.npz"), **_final_lists(trainer, data))
+
+
+def g9_lists(split):
+    import tempfile
+    from model.DropoutNet import DropoutNet  # noqa: E402  (reference)
+    data = ref_builder(split)
+    emb = np.load(out("g8_e2e_emb.npz"))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "emb"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(emb["U"])), os.path.join(tmp, "emb", "toy_cold_item_MF_user_emb.pt"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(emb["V"])), os.path.join(tmp, "emb", "toy_cold_item_MF_item_emb.pt"))
+        os.chdir(tmp)
+        try:
+            cfg = ref_config(data, model="DropoutNet", emb_size=64, epochs=3, bs=128, n_dropout=0.5,
+                             dropoutnet_hidden1=200, dropoutnet_hidden2=100)
+            set_seed(2024, False)
+            trainer = DropoutNet(cfg)
+            _run_quiet(trainer)
+        finally:
+            os.chdir(cwd)
+    want = np.load(out("g9_dropoutnet_emb.npz"))
+    assert np.array_equal(trainer.user_emb.detach().numpy(), want["U"]) and np.array_equal(trainer.item_emb.detach().numpy(), want["V"])
+    np.savez_compressed(out("g9_lists.npz"), **_final_lists(trainer, data))
+
+
+def g11_lgcn_e2e(split):
+    """model/LightGCN.py:14-51 through BaseRecommender.run(): config 3's trainer (L=3) on the toy split."""
+    data = ref_builder(split)
+    cfg = ref_config(data, model="LightGCN", layers=3, emb_size=64, epochs=3, bs=512)
+    set_seed(2024, False)
+    trainer = LightGCN(cfg)
+    loss_lines = _run_quiet(trainer)
+    payload = dict(
+        args=vars(cfg.args), overall=trainer.overall_test_results, cold=trainer.cold_test_results,
+        warm=trainer.warm_test_results, best=[trainer.bestPerformance[0], trainer.bestPerformance[1]],
+        epochs_ran=trainer.epochs_ran, loss_lines=loss_lines,
+        user_emb_norm=float(trainer.user_emb.norm()), item_emb_norm=float(trainer.item_emb.norm()))
+    with open(out("g11_lgcn_e2e.json"), "w") as f:
+        json.dump(payload, f, indent=1)
+    enc = trainer.model
+    np.savez_compressed(out("g11_lgcn_e2e_emb.npz"), U=trainer.user_emb.detach().numpy(), V=trainer.item_emb.detach().numpy(),
+                        E0_user=enc.embedding_dict["user_emb"].detach().numpy(),
+                        E0_item=enc.embedding_dict["item_emb"].detach().numpy(), **_final_lists(trainer, data))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":         # add the round-3 fixtures without redoing G1-G10
+        split = make_dataset("toy", "item", seed=1)
+        g8_lists(split)
+        g9_lists(split)
+        g11_lgcn_e2e(split)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g10":         # add the sampler fixture without redoing G1-G9
         g10_samplers(make_dataset("toy", "item", seed=1))
         return
@@ -484,6 +580,9 @@ def main():
     g8_e2e(split_i)
     g9_dropoutnet(split_i)
     g10_samplers(split_i)
+    g8_lists(split_i)
+    g9_lists(split_i)
+    g11_lgcn_e2e(split_i)
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

@@ -25,8 +25,8 @@ class NpKernels:
     """CPU stand-ins with the signatures of coldrec_amd.ops (tests only), assigned to coldrec_amd.train.ops below."""
 
     class SpmmSchedule:
-        def __init__(self, rowptr, device):
-            pass
+        def __init__(self, rowptr, device, seg=None):
+            self.seg = 64 if seg is None else seg
 
     @staticmethod
     def bpr_workspace(batch, device):

@@ -404,32 +404,61 @@ def test_f32_workgroup_kernel_is_bit_exact(n_splits, n_items, monkeypatch):
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
 
 
-def test_dense_route_chunks_users_and_equals_fused_route():
-    """Small-catalogue route of crh_score_topk_f32 (score block + wave-per-user ranking) on a shape whose block
-    exceeds 1 GiB, so the users go in chunks: user indirection, rated lists, bitmap and item_base must follow the
-    chunk offsets.  Same bits as the fused selection (forced single split) and, on a sample of rows, as the oracle."""
+def _dense_chunk_case(n_rows, n_users, n_items, d, k, base, seed, boundary_rows_of):
+    """Dense route (score block + wave-per-user ranking) vs the fused selection (forced single split) on the whole
+    block, and vs the oracle on the rows either side of every chunk boundary."""
     from coldrec_amd import ops
-    rng = np.random.default_rng(99)
-    n_rows, n_users, n_items, d, k, base = 21000, 20011, 16384, 8, 20, 1000
+    rng = np.random.default_rng(seed)
     U = (rng.standard_normal((n_rows, d)) * 0.5).astype(np.float32)
     V = (rng.standard_normal((n_items, d)) * 0.5).astype(np.float32)
     users = rng.permutation(n_rows)[:n_users].astype(np.int32)
     lens = rng.integers(0, 6, n_users)
     rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    col = np.concatenate([np.sort(rng.choice(n_items, l, replace=False)) + base for l in lens]).astype(np.int32)
+    col = (rng.integers(0, n_items, int(rowptr[-1])) + base).astype(np.int64)
+    key = np.repeat(np.arange(n_users, dtype=np.int64), lens) << 32 | col        # ascending within a user
+    key = np.unique(key)                                                         # (and distinct)
+    lens = np.bincount((key >> 32).astype(np.int64), minlength=n_users)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = (key & 0xFFFFFFFF).astype(np.int32)
     cold = (np.where(rng.random(n_items) < 0.3)[0] + base).astype(np.int64)
     DEV = _dev()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     tU, tV, tu = t(U), t(V), t(users)
     rp, rc = t(rowptr), t(col)
     bm = ops.make_bitmap(base + n_items, cold, DEV)
-    assert n_users * n_items * 4 > (1 << 30)                       # more than one chunk
     s0, i0 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base)             # dispatcher: dense route
     s1, i1 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base, n_splits=1)  # fused selection
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
-    rows = np.concatenate([np.arange(5), [16383, 16384, 16385, n_users - 1]])       # around the chunk boundary
+    rows = boundary_rows_of(n_users)
     sub_ptr = np.concatenate([[0], np.cumsum(lens[rows])]).astype(np.int64)
     sub_col = np.concatenate([col[rowptr[r]:rowptr[r + 1]] for r in rows]).astype(np.int64)
     ws, wi = orc.score_topk(U, users[rows], V, k, sub_ptr, sub_col, orc.make_bitmap(base + n_items, cold), item_base=base)
     assert np.array_equal(i0.cpu().numpy()[rows], wi)
     assert np.array_equal(s0.cpu().numpy()[rows].view(np.uint32), ws.view(np.uint32))
+
+
+def test_dense_route_chunks_users_and_equals_fused_route(monkeypatch):
+    """The `u0 > 0` branch of the dense route (score_topk.hip: `users + u0`, `rated_rowptr + u0`, `user_base`): the
+    block limit is lowered to 64 MiB for this call (CRH_SCORE_DENSE_BLOCK_MB is read per call), which cuts 20 011
+    users x 16 384 items into 20 chunks of 1 024 users; user indirection, rated lists, bitmap and item_base must
+    follow every chunk offset.  Rows on both sides of EVERY chunk boundary are compared with the oracle."""
+    monkeypatch.setenv("CRH_SCORE_DENSE_BLOCK_MB", "64")
+    chunk = (64 << 20) // (16384 * 4 * 64) * 64
+    assert chunk == 1024
+
+    def rows(n_users):
+        b = np.arange(chunk, n_users, chunk)
+        return np.unique(np.concatenate([[0, 1, n_users - 1], b - 1, b, b + 1]))
+
+    _dense_chunk_case(21000, 20011, 16384, 8, 20, 1000, 99, rows)
+
+
+def test_dense_route_block_above_the_default_8_gib_limit():
+    """The shipped limit itself: 70 000 users x 32 768 items is a 9.2 GB block, above DENSE_MAX_BLOCK = 8 GiB, so the
+    users go in two chunks of 65 536 + 4 464 (whole 64-user groups); rows either side of that boundary vs the oracle."""
+    n_users, n_items = 70000, 32768
+    assert n_users * n_items * 4 > (8 << 30)
+    chunk = (8 << 30) // (n_items * 4 * 64) * 64
+    assert chunk == 65536
+    _dense_chunk_case(70500, n_users, n_items, 8, 20, 64, 7,
+                      lambda n: np.array([0, 63, 64, chunk - 65, chunk - 1, chunk, chunk + 1, chunk + 63, chunk + 64, n - 1]))
