@@ -136,7 +136,7 @@ def build(force: bool = False) -> str:
     stale = not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-s", "-C", CSRC, "all"])
+        subprocess.check_call(["make", "-s", "-j8", "-C", CSRC, "all"])
     return LIB_PATH
 
 

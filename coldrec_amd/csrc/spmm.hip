@@ -147,73 +147,37 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
 // Light path: work item = one row (no schedule) or one single-segment row; a lane group of G lanes owns the
 // row's 16*G-byte column slice and finishes it (bit-identical to the oracle's edge-order chain).
 // Heavy path (rows with several segments): one wave per (row, slice).
-template <int G>
-__global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
-    const int lig = threadIdx.x % G;
-    const int xcd = blockIdx.x & 7;
-    const int slice = xcd % a.cs;
-    const int64_t j = (int64_t)(blockIdx.x >> 3) * (8 / a.cs) + xcd / a.cs;
-    const int c = slice * G + lig;                   // this lane's float4 column
-    const bool on = c < (a.d >> 2);                  // d/4 not a power of two: the lane group is padded
-    const bool seg = a.sched.n_seg > 0;
-    if (j < a.light_blocks) {
-        if (CRH_ABLATE(a.skip) & 2) return;
-        const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
-        // rows_per_group work items per lane group, a whole "grid" apart: with the schedule's descending-length order a
-        // long row is paired with a short one, and fewer, fully resident workgroups replace a second round of them
-        for (int64_t w = j * (256 / G) + threadIdx.x / G; w < n_work; w += a.light_blocks * (256 / G)) {
-            int64_t row, e0, e1;
-            if (seg && a.sched.seg_desc) {
-                // ONE 16-byte descriptor per work item instead of three dependent loads (seg_row / seg_slot, then
-                // rowptr[row], rowptr[row + 1]): tools/probes/spmm_steps_probe.hip prices the schedule indirection at
-                // 2.4 us and the rowptr reads at 1.0 us of a 15 us launch
-                const i32x4 dsc = reinterpret_cast<const i32x4*>(a.sched.seg_desc)[w];
-                if (dsc.w >= 0) continue;                             // a heavy row: done below
-                row = dsc.x;
-                e0 = dsc.y;
-                e1 = e0 + dsc.z;
-            } else {
-                if (seg && a.sched.seg_slot[w] >= 0) continue;        // a heavy row: done below
-                row = seg ? a.sched.seg_row[w] : w;
-                e0 = a.rowptr[row];
-                e1 = a.rowptr[row + 1];                               // a light work item is a whole row
-            }
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            row_edges<G>(a, e0, e1, c, on, lig, acc);
-            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
-        }
-        return;
-    }
-    // heavy rows: one block per (row, slice); the NGB lane groups of the block split the row's edge list;
-    // partial sums meet in a fixed order: shuffle tree inside a wave, then the 4 waves through LDS.  (One WAVE per
-    // heavy row of up to 256 / 512 / 1024 edges instead, four rows per block, measured no gain: LightGCN step 158.7 ->
-    // 159.4 / 161.8 / 165.7 us.)
-    __shared__ f32x4 wsum[4][G];
-    const int64_t m = j - a.light_blocks;
-    if (m >= a.sched.n_multi || (CRH_ABLATE(a.skip) & 1)) return;
-    constexpr int NGB = 256 / G;
-    const int64_t row = a.sched.multi_row[m];
+// One heavy row (more than the schedule's segment length of edges) by a whole workgroup: its 256 / GG lane groups of GG
+// lanes split the edge list into contiguous chunks (multiples of 8 edges); partial sums meet in a fixed order: shuffle
+// tree inside a wave, then the 4 waves through LDS.  c0 = first float4 column of this workgroup's column range.
+// (One WAVE per heavy row of up to 256 / 512 / 1024 edges instead, four rows per block, measured no gain: LightGCN step
+// 158.7 -> 159.4 / 161.8 / 165.7 us.)
+template <int GG>
+__device__ __forceinline__ void heavy_row(const SpmmArgs& a, int64_t row, int c0, int c_end, f32x4 (*wsum)[64]) {
+    constexpr int NGB = 256 / GG;
+    const int lig = threadIdx.x % GG, gg = threadIdx.x / GG;
+    const int c = c0 + lig;
+    const bool on = c < c_end;
     const int64_t r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
-    const int gg = threadIdx.x / G;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    {   // the row is cut into NGB contiguous chunks (multiples of 8 edges): every lane group gets one
+    {
         int64_t chunk = (r1 - r0 + NGB - 1) / NGB;
         chunk = (chunk + 7) & ~(int64_t)7;
         const int64_t e0 = r0 + (int64_t)gg * chunk;
         const int64_t e1 = e0 + chunk < r1 ? e0 + chunk : r1;
-        if (e0 < r1) row_edges<G>(a, e0, e1, c, on, lig, acc);
+        if (e0 < r1) row_edges<GG>(a, e0, e1, c, on, lig, acc);
     }
 #pragma unroll
-    for (int off = G; off < 64; off <<= 1) {
+    for (int off = GG; off < 64; off <<= 1) {
         acc.x += __shfl_down(acc.x, off);
         acc.y += __shfl_down(acc.y, off);
         acc.z += __shfl_down(acc.z, off);
         acc.w += __shfl_down(acc.w, off);
     }
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) < G) wsum[wv][lig] = acc;
+    if ((threadIdx.x & 63) < GG) wsum[wv][lig] = acc;
     __syncthreads();
-    if (threadIdx.x < G && on) {
+    if (threadIdx.x < GG && on) {
         f32x4 t0 = wsum[0][lig], t1 = wsum[1][lig], t2 = wsum[2][lig], t3 = wsum[3][lig];
         f32x4 r;
         r.x = (t0.x + t1.x) + (t2.x + t3.x);
@@ -224,25 +188,79 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     }
 }
 
+// Block b -> (slice, work block): slice = (b % 8) % cs keeps every XCD on one column slice; the blocks of a
+// slice are numbered j = (b / 8) * (8 / cs) + (b % 8) / cs.
+// HEAVY blocks lead the grid (j < n_multi; round 3: they trailed it): a heavy row is the longest dependent chain of the
+// launch, so it has to start with the first wave of workgroups, whatever the number of rounds the light rows take.  The
+// schedule lists one entry per heavy BLOCK in descending row length: multi_row[m] = row, multi_count[m] = n_sub | sub << 8:
+// rows above 1024 edges are cut into n_sub = 2 (4 above 4096) COLUMN ranges of the slice, one workgroup each, with G / n_sub
+// lanes per lane group -- twice (four times) the lane groups per row, so the chain of the longest row of a Zipf-shaped
+// catalogue is half (a quarter) as long; columns are independent, so nothing is combined across workgroups and the result
+// stays deterministic (CiteULike shape: three rows of 1 150 - 2 950 edges set the launch's critical path).
+// Light path: work item = one row (no schedule) or one single-segment row; a lane group of G lanes owns the
+// row's 16*G-byte column slice and finishes it (bit-identical to the oracle's edge-order chain).
+template <int G>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
+    const int lig = threadIdx.x % G;
+    const int xcd = blockIdx.x & 7;
+    const int slice = xcd % a.cs;
+    const int64_t j = (int64_t)(blockIdx.x >> 3) * (8 / a.cs) + xcd / a.cs;
+    const int c = slice * G + lig;                   // this lane's float4 column
+    const bool on = c < (a.d >> 2);                  // d/4 not a power of two: the lane group is padded
+    const bool seg = a.sched.n_seg > 0;
+    const int64_t heavy_blocks = seg ? a.sched.n_multi : 0;
+    if (j >= heavy_blocks) {
+        const int64_t jl = j - heavy_blocks;
+        if (jl >= a.light_blocks || (CRH_ABLATE(a.skip) & 2)) return;
+        const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
+        // rows_per_group work items per lane group, a whole "grid" apart: with the schedule's descending-length order a
+        // long row is paired with a short one, and fewer, fully resident workgroups replace a second round of them
+        for (int64_t w = jl * (256 / G) + threadIdx.x / G; w < n_work; w += a.light_blocks * (256 / G)) {
+            int64_t row, e0, e1;
+            if (seg && a.sched.seg_desc) {
+                // ONE 16-byte descriptor per work item instead of three dependent loads (seg_row / seg_slot, then
+                // rowptr[row], rowptr[row + 1]): tools/probes/spmm_steps_probe.hip prices the schedule indirection at
+                // 2.4 us and the rowptr reads at 1.0 us of a 15 us launch
+                const i32x4 dsc = reinterpret_cast<const i32x4*>(a.sched.seg_desc)[w];
+                if (dsc.w >= 0) continue;                             // a heavy row: done by its own workgroup(s)
+                row = dsc.x;
+                e0 = dsc.y;
+                e1 = e0 + dsc.z;
+            } else {
+                if (seg && a.sched.seg_slot[w] >= 0) continue;        // a heavy row
+                row = seg ? a.sched.seg_row[w] : w;
+                e0 = a.rowptr[row];
+                e1 = a.rowptr[row + 1];                               // a light work item is a whole row
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            row_edges<G>(a, e0, e1, c, on, lig, acc);
+            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc);
+        }
+        return;
+    }
+    if (CRH_ABLATE(a.skip) & 1) return;
+    __shared__ f32x4 wsum[4][64];
+    const int64_t row = a.sched.multi_row[j];
+    const int cut = a.sched.multi_count ? a.sched.multi_count[j] : 1;
+    const int n_sub = cut & 255, sub = cut >> 8;
+    const int c_end = (a.d >> 2) < (slice + 1) * G ? (a.d >> 2) : (slice + 1) * G;
+    if (G >= 4 && n_sub == 4) heavy_row<(G >= 4 ? G / 4 : 1)>(a, row, slice * G + sub * (G / 4), c_end, wsum);
+    else if (G >= 2 && n_sub == 2) heavy_row<(G >= 2 ? G / 2 : 1)>(a, row, slice * G + sub * (G / 2), c_end, wsum);
+    else heavy_row<G>(a, row, slice * G, c_end, wsum);
+}
+
 template <int G>
 int launch_spmm(SpmmArgs a, hipStream_t st) {
-    // Rows per lane group: the smallest count (up to 4) that makes the whole launch resident at once -- 256 CUs x 7
-    // workgroups at this kernel's 70 VGPRs -- instead of a second, partly filled round of workgroups.  CiteULike
-    // shape (4 slices): 3 rows -> 1612 workgroups, LightGCN step 0.182 -> 0.164 ms (2: 0.176, 4: 0.172, 8: 0.229).
-    // Launches of many rounds (catalogue-scale graphs) keep one row per group.  CRH_SPMM_ROWS forces a count.
+    // Rows per lane group.  Rounds 1-2 took the smallest count (up to 4) that made the whole launch resident at once, because
+    // the heavy workgroups TRAILED the grid and a second round of workgroups delayed the launch's longest chains (CiteULike
+    // shape, 4 slices: 3 rows -> 1612 workgroups, LightGCN step 0.182 -> 0.164 ms).  With the heavy workgroups leading the
+    // grid one row per group is the faster schedule -- the light rows' chains are a third as long and the workgroups of the
+    // later rounds fill the slots the early ones free (same shape: 1 row 141.6 us per step, 2 rows 142.1, 3 rows 154.5;
+    // profiles/r03_lgcn_sweep1.log).  CRH_SPMM_ROWS forces a count.
     static const int force_rows = getenv("CRH_SPMM_ROWS") ? atoi(getenv("CRH_SPMM_ROWS")) : 0;
     const int64_t n_work = a.sched.n_seg > 0 ? a.sched.n_seg : a.n_rows;
     const int64_t heavy_blocks = a.sched.n_seg > 0 ? (int64_t)a.sched.n_multi : 0;
-    int rows_per_group = 1;
-    if (force_rows > 0) {
-        rows_per_group = force_rows;
-    } else {
-        const int64_t resident = 256 * 7;
-        for (int r = 1; r <= 4; ++r) {
-            const int64_t lb = (n_work + (256 / G) * r - 1) / ((256 / G) * r);
-            if ((lb + heavy_blocks) * a.cs <= resident) { rows_per_group = r; break; }
-        }
-    }
+    const int rows_per_group = force_rows > 0 ? force_rows : 1;
     const int64_t per_block = (256 / G) * rows_per_group;
     a.light_blocks = (n_work + per_block - 1) / per_block;
     const int64_t per_slice = a.light_blocks + heavy_blocks;

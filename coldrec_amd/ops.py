@@ -476,10 +476,17 @@ class SpmmSchedule:
         seg_row = order.astype(np.int32)
         seg_slot = np.where(heavy[order], 0, -1).astype(np.int32)
         seg_ptr = np.zeros(len(seg_row) + 1, np.int64)              # not read any more (kept for the ABI struct)
-        multi_row = np.nonzero(heavy)[0].astype(np.int32)
-        multi_count = (-(-deg[heavy] // seg)).astype(np.int32)
-        multi_first = np.zeros(len(multi_row) + 1, np.int64)
-        np.cumsum(multi_count, out=multi_first[1:])
+        # heavy rows: one entry per heavy BLOCK, longest rows first (they lead the grid: the longest chains start with the
+        # first wave of workgroups).  Rows above GIANT edges are cut into 2 (4 above 4 * GIANT) column ranges of the slice,
+        # one workgroup each with half (a quarter) of the lanes per lane group: multi_count = n_sub | sub << 8.
+        giant = int(os.environ.get("CRH_SPMM_GIANT", "1024"))
+        hrows = np.nonzero(heavy)[0]
+        hrows = hrows[np.argsort(-deg[hrows], kind="stable")]
+        n_sub = np.where(deg[hrows] > 4 * giant, 4, np.where(deg[hrows] > giant, 2, 1)) if giant > 0 else np.ones(len(hrows), np.int64)
+        multi_row = np.repeat(hrows, n_sub).astype(np.int32)
+        sub = (np.arange(len(multi_row)) - np.repeat(np.cumsum(n_sub) - n_sub, n_sub)).astype(np.int64)
+        multi_count = (np.repeat(n_sub, n_sub) | (sub << 8)).astype(np.int32)
+        multi_first = np.zeros(len(multi_row) + 1, np.int64)          # not read any more (kept for the ABI struct)
         # one 16-byte descriptor per work item: {row, first edge, edges, slot}
         desc = None
         if len(deg) and int(rp[-1]) < (1 << 31):

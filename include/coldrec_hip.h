@@ -238,10 +238,14 @@ int crh_adam_rows_f32(float* p, float* g, float* m, float* v, int32_t* last_step
  *     seg_row[w] = the row; seg_slot[w] = -1: finished by one lane group, bit-identical to the edge-order fma
  *     chain; >= 0: the row is "heavy" (more than crh_spmm_segment_edges() edges) and skipped here;
  *     seg_ptr: not read (kept for layout compatibility, must be non-NULL);
- *     multi_row[m]: the n_multi heavy rows -- each is given to a whole workgroup whose
- *     lane groups split its edge list and combine their partial sums in a fixed order (deterministic; the
- *     association differs from the single chain); multi_first / multi_count / n_partial describe the
- *     segments of the heavy rows (informational); nnz = number of stored edges.
+ *     multi_row[m], m < n_multi: the heavy WORKGROUPS, which lead the grid (list the longest rows first) -- a heavy
+ *     row is given to a whole workgroup whose lane groups split its edge list and combine their partial sums in a
+ *     fixed order (deterministic; the association differs from the single chain);
+ *     multi_count[m] = n_sub | sub << 8 (NULL = 1 everywhere): n_sub in {1, 2, 4} cuts the row's column slice into
+ *     n_sub ranges, workgroup `sub` taking one of them with 1 / n_sub of the lanes per lane group (n_sub times the
+ *     lane groups per row: for the few rows of thousands of edges that set a launch's critical path); a row with
+ *     n_sub > 1 is listed n_sub times, sub = 0 .. n_sub - 1;
+ *     multi_first / n_partial: not read; nnz = number of stored edges.
  * With a schedule, and when the dense operand is larger than one XCD's L2 but a half / quarter of its columns
  * is not (and the edge list is small against it), the feature columns are processed in 2 / 4 slices pinned
  * to XCDs (block b -> slice (b % 8) % slices) so the random row gathers stay in that XCD's L2.

@@ -258,10 +258,14 @@ def test_spmm_bit_exact_vs_oracle(d):
     np.testing.assert_allclose(A.cpu().numpy(), (Z * np.float32(0.5) + want) * np.float32(0.25), rtol=1e-6, atol=1e-7)
 
 
-def test_spmm_segment_schedule_on_skewed_graph():
-    """Zipf catalogue: rows with thousands of edges are given to a workgroup each (lane groups split the list, partial
-    sums combined in a fixed order); the other rows are work items ordered by descending length."""
+@pytest.mark.parametrize("giant", [1024, 200, 0])
+def test_spmm_segment_schedule_on_skewed_graph(monkeypatch, giant):
+    """Zipf catalogue: rows above the segment length are given to a workgroup each (lane groups split the list, partial
+    sums combined in a fixed order), the longest first at the head of the grid; rows above `giant` edges are cut into 2
+    (4 above 4 * giant) column ranges with a workgroup each (giant = 200 exercises both cuts, 0 switches them off); the
+    other rows are work items ordered by descending length."""
     from coldrec_amd import ops
+    monkeypatch.setenv("CRH_SPMM_GIANT", str(giant))
     rng = np.random.default_rng(11)
     n_u, n_i, d = 3000, 500, 64
     w = 1.0 / np.arange(1, n_i + 1) ** 1.1
@@ -272,12 +276,23 @@ def test_spmm_segment_schedule_on_skewed_graph():
     sched = ops.SpmmSchedule(rowptr, DEV)
     T = sched.seg                                                                 # 64, or 256 for dense graphs
     assert T in (64, 256)
-    assert deg.max() > 1500 and sched.n_seg == len(deg) and sched.n_partial == np.where(deg > T, -(-deg // T), 0).sum()
+    assert deg.max() > 1500 and sched.n_seg == len(deg)
     order, slot = sched.t[0].cpu().numpy(), sched.t[2].cpu().numpy()
     assert np.array_equal(np.sort(order), np.arange(len(deg)))                   # every row exactly once
     n_light = int((deg <= T).sum())
     assert (slot[:n_light] == -1).all() and (slot[n_light:] >= 0).all() and (deg[order[n_light:]] > T).all()
     assert (np.diff(deg[order[:n_light]]) <= 0).all()                            # light rows by descending length
+    # heavy workgroups: longest rows first, n_sub consecutive entries (sub = 0 .. n_sub - 1) per row
+    hrow, hcut = sched.t[3].cpu().numpy(), sched.t[5].cpu().numpy()
+    n_sub, sub = hcut & 255, hcut >> 8
+    want_sub = np.where(deg[hrow] > 4 * giant, 4, np.where(deg[hrow] > giant, 2, 1)) if giant else np.ones(len(hrow), int)
+    assert np.array_equal(n_sub, want_sub) and (np.diff(deg[hrow]) <= 0).all()
+    assert len(hrow) == int(want_sub[sub == 0].sum()) and set(hrow.tolist()) == set(np.nonzero(deg > T)[0].tolist())
+    starts = np.nonzero(sub == 0)[0]
+    for s0 in starts:
+        assert (hrow[s0:s0 + n_sub[s0]] == hrow[s0]).all() and np.array_equal(sub[s0:s0 + n_sub[s0]], np.arange(n_sub[s0]))
+    if giant == 200:
+        assert (n_sub == 4).any() and (n_sub == 2).any() and (n_sub == 1).any()
     X = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
     Z = rng.standard_normal((n_u + n_i, d)).astype(np.float32)
     tX, tZ = t(X), t(Z)
@@ -293,6 +308,14 @@ def test_spmm_segment_schedule_on_skewed_graph():
     Y2 = torch.empty_like(tX)
     ops.spmm_csr(t(rowptr), t(col), t(val), tX, y=Y2, sched=sched)
     assert torch.equal(Y1, Y2)                                                      # deterministic
+    # narrow tables: fewer lanes per lane group than column cuts (d = 8: two lanes) -- every cut falls back to the whole
+    # slice and the duplicate workgroups write identical rows
+    Xn = np.ascontiguousarray(X[:, :8])
+    Yn = torch.empty((n_u + n_i, 8), dtype=torch.float32, device=DEV)
+    ops.spmm_csr(t(rowptr), t(col), t(val), t(Xn), y=Yn, sched=sched)
+    wn = orc.spmm(rowptr, col, val, Xn)
+    np.testing.assert_array_equal(Yn.cpu().numpy()[one], wn[one])
+    np.testing.assert_allclose(Yn.cpu().numpy()[~one], wn[~one], rtol=1e-5, atol=1e-6)
 
 
 def test_lgcn_forward_golden_g5_and_training():
