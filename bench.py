@@ -742,6 +742,95 @@ def train_xl(dev, steps, warm, lazy=False):
     return out
 
 
+def xl_graph(dev, n_u, n_i, n_inter, seed):
+    """S-TRAIN-XL interaction graph built ON the GPU: users uniform, items Zipf(0.8) with shuffled ids,
+    distinct pairs, then the symmetric bipartite adjacency D^-1/2 A D^-1/2 over n_u + n_i nodes as CSR (int64 rowptr,
+    ascending int32 col, fp32 val = d_inv[row] * d_inv[col] -- util/databuilder.py:220-254 restated with torch ops; the
+    CiteULike-sized legs use the product's own host builder)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    N = n_u + n_i
+    u = torch.randint(0, n_u, (n_inter,), generator=g, device=dev)
+    cdf = torch.cumsum(torch.arange(1, n_i + 1, device=dev, dtype=torch.float64).pow_(-0.8), 0)
+    cdf /= cdf[-1].clone()
+    it = torch.searchsorted(cdf, torch.rand(n_inter, generator=g, device=dev, dtype=torch.float64)).clamp_(max=n_i - 1)
+    del cdf
+    it = torch.randperm(n_i, generator=g, device=dev)[it]
+    key = torch.unique(u * n_i + it)
+    del u, it
+    u, it = key // n_i, key % n_i + n_u
+    del key
+    rows, cols = torch.cat([u, it]), torch.cat([it, u])
+    del u, it
+    deg = torch.bincount(rows, minlength=N)
+    order = torch.argsort(rows * N + cols)
+    rows, cols = rows[order], cols[order]
+    del order
+    rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    d_inv = torch.where(deg > 0, deg.to(torch.float32).pow(-0.5), torch.zeros((), device=dev))
+    val = d_inv[rows] * d_inv[cols]
+    return rowptr, cols.to(torch.int32), val, deg
+
+
+def train_xl_lightgcn(dev, steps, warm, n_u=1_000_000, n_i=10_000_000, n_inter=200_000_000, d=128, L=3, B=65536):
+    """the LightGCN step where HBM is the bound -- SURVEY.md 8(d)'s S-TRAIN-XL WITH its graph
+    (N = 1.1e7 nodes, E2 ~ 4e8 stored edges, d = 128, L = 3, B = 65 536).  Every layer state is 5.6 GB, far beyond L2
+    and Infinity Cache, so every gathered neighbour row is an HBM access: the honest figures are the gather rate
+    (E2 x d x 4 bytes per SpMM over its time) against the HBM peak, and SURVEY's formula (which counts the dense operand
+    once) beside it; their ratio is the gathered-row re-read factor the formula leaves out."""
+    from coldrec_amd import ops
+    from coldrec_amd.train import LGCNEngine
+    t0 = time.perf_counter()
+    rowptr, col, val, deg = xl_graph(dev, n_u, n_i, n_inter, 7)
+    torch.cuda.synchronize()
+    t_graph = time.perf_counter() - t0
+    N, E2 = n_u + n_i, int(col.numel())
+    eng = LGCNEngine.from_device(xavier_(N, d, 1, dev, n_i), n_u, rowptr, col, val, L, 1e-3, 1e-4)
+    g = torch.Generator(device=dev).manual_seed(3)
+    # triples from the graph itself: a stored (user, item) edge as the positive, a uniform item as the negative
+    tri = []
+    for _ in range(4):
+        e = torch.randint(0, int(rowptr[n_u]), (B,), generator=g, device=dev)
+        uu = (torch.searchsorted(rowptr[:n_u + 1], e, right=True) - 1).to(torch.int32)
+        tri.append((uu, (col[e] - n_u).to(torch.int32), torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32)))
+
+    def step(s):
+        u, i, j = tri[s % 4]
+        eng.step(u, i, j, plan=ops.build_plans_device(u, i, j, B)[0])
+
+    sec = _time_steps(step, steps, warm)
+    # the SpMM alone (forward layer 1 of the step: gathers E, reads E as acc_in, writes the next layer's input and the sum)
+    def one_spmm(_s):
+        ops.spmm_csr(eng.rowptr, eng.col, eng.val, eng.E, y=eng.X[0], acc_in=eng.E, s_in=1.0, acc_out=eng.OUT, s_out=1.0,
+                     sched=eng.sched)
+    spmm_sec = _time_steps(one_spmm, 3, 1)
+    spmm_formula = E2 * 8 + (N + 1) * 4 + 2 * N * d * 4
+    layer_mean = 2 * (L + 2) * N * d * 4
+    bytes_step = 2 * L * spmm_formula + layer_mean + 24 * d * B + 32 * N * d
+    gathered = E2 * d * 4
+    G = 1
+    while G < d // 4 and G < 64:
+        G <<= 1
+    tr = measured_traffic("spmm_csr_kernel<%d>" % G, None)
+    return {"metric": "BPR triples/sec (train)", "value": B / sec, "unit": "triples/s", "ms_per_step": sec * 1e3,
+            "config": {"workload": "S-TRAIN-XL with its graph: LightGCN L=%d, %d users + %d items, %d stored edges "
+                                   "(mean degree %.1f, max %d), d=%d, B=%d, Adam in the last SpMM's epilogue"
+                                   % (L, n_u, n_i, E2, E2 / N, int(deg.max()), d, B),
+                       "graph_build_s": t_graph, "heavy_workgroups": int(eng.sched.c.n_multi), "segment": eng.sched.seg},
+            "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
+                         "formula": "SURVEY.md 8(d): 2L (E2*8 + (N+1)*4 + 2*N*d*4) + 2 (L+2) N d 4 + 24 d B + 32 N d",
+                         "traffic": None},
+            "spmm": {"ms": spmm_sec * 1e3, "formula_bytes": spmm_formula,
+                     "formula_GBps": spmm_formula / spmm_sec / 1e9, "formula_frac": spmm_formula / spmm_sec / 1e9 / HBM_PEAK_GBS,
+                     "gathered_row_bytes": gathered, "gather_GBps": gathered / spmm_sec / 1e9,
+                     "gather_frac_of_hbm_peak": gathered / spmm_sec / 1e9 / HBM_PEAK_GBS,
+                     "reread_factor_of_the_dense_operand": gathered / (N * d * 4.0),
+                     "traffic": tr[0] if tr else None, "traffic_source": ("committed profile " + tr[1]) if tr else None,
+                     "note": "every gathered neighbour row (512 B) is an HBM access at this size: the kernel's bound is "
+                             "the random-row gather rate, not SURVEY's formula, which counts the dense operand once"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -773,10 +862,12 @@ def main():
     ap.add_argument("--train-xl", action="store_true",
                     help="only run the S-TRAIN-XL roofline case of SURVEY.md 8(d) (1M users x 10M items, d=128, "
                          "B=65536 MF steps; 22.5 GB of state) and print its JSON line")
+    ap.add_argument("--train-xl-lightgcn", action="store_true",
+                    help="only run the S-TRAIN-XL LightGCN leg (1.1e7 nodes, ~4e8 stored edges, d=128, L=3)")
     ap.add_argument("--cpu-sample-users", type=int, default=2048,
                     help="users of the CPU baseline (blocks of 256 against the WHOLE item table, SURVEY.md 8(d))")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="the CPU baseline stops after this many seconds")
-    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train,eval_validation,eval_midsize,torch_rocm",
+    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train_xl_lightgcn,train,eval_validation,eval_midsize,torch_rocm",
                     help="N=1: secondary legs carried in the same JSON line (comma separated; 'none' = headline only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the last timed step")
     args = ap.parse_args()
@@ -806,6 +897,9 @@ def main():
 
     if args.train_xl:
         print(json.dumps(train_xl(dev, args.steps, args.warmup, lazy=args.lazy_adam)), flush=True)
+        return
+    if args.train_xl_lightgcn:
+        print(json.dumps(train_xl_lightgcn(dev, args.steps, args.warmup)), flush=True)
         return
     if args.train_only:
         legs = train_legs(dev, not args.no_cpu_baseline)
@@ -988,6 +1082,7 @@ def main():
         torch.cuda.empty_cache()
         for leg_name, fn in (("eval_f16", lambda: eval_f16_leg(dev)), ("mask_topk", lambda: mask_topk_leg(dev)),
                              ("train_xl", lambda: {"train_xl": train_xl(dev, 3, 1)}),
+                             ("train_xl_lightgcn", lambda: {"train_xl_lightgcn": train_xl_lightgcn(dev, 2, 1)}),
                              ("train", lambda: train_legs(dev, not args.no_cpu_baseline)),
                              ("eval_validation", lambda: validation_eval_leg(dev)),
                              ("eval_midsize", lambda: midsize_eval_leg(dev)),

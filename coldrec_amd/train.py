@@ -324,6 +324,26 @@ class LGCNEngine(_TableState):
         self.fuse_adam = hasattr(self.k, 'spmm_csr_adam') and os.environ.get("CRH_LGCN_FUSED", "1") != "0"
         self.keep_grad = False       # also store dE0 into self.G (tests compare it with the reference's autograd)
 
+    @classmethod
+    def from_device(cls, E: torch.Tensor, user_num: int, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
+                    n_layers: int, lr: float, reg: float, optimizer: str = 'adam', seg: Optional[int] = None):
+        """Engine over a device-resident (user_num + item_num, d) table and a device-resident CSR adjacency (int64 rowptr,
+        int32 col, fp32 val): nothing is copied through the host except rowptr for the schedule -- for graphs built on the
+        GPU (bench.py S-TRAIN-XL).  ``seg``: heavy-row threshold of the schedule (None = the automatic rule)."""
+        self = cls.from_table(E, user_num, lr, reg, optimizer)
+        assert n_layers >= 1 and rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
+        assert rowptr.shape[0] == E.shape[0] + 1
+        self.L = int(n_layers)
+        self.rowptr, self.col, self.val = rowptr.contiguous(), col.contiguous(), val.contiguous()
+        self.sched = self.k.SpmmSchedule(self.rowptr.cpu().numpy(), self.device, seg=seg)
+        self.X = [torch.empty_like(self.E) for _ in range(2)]
+        self.OUT = torch.empty_like(self.E)
+        self.dOUT = torch.zeros_like(self.E)
+        self._dout_clean = True
+        self.fuse_adam = hasattr(self.k, 'spmm_csr_adam') and os.environ.get("CRH_LGCN_FUSED", "1") != "0"
+        self.keep_grad = False
+        return self
+
     def enable_row_sharding(self, dp: DPContext) -> None:
         """SURVEY.md 8(e), "scalable variant": the propagation itself is sharded.  Rank r owns the contiguous row block
         [r0, r1) of the adjacency and of every layer state: per layer it multiplies ITS rows (1/G of the SpMM work) and

@@ -182,6 +182,17 @@ rp = torch.from_numpy(np.concatenate([[0], np.cumsum([len(r) for r in rated])]).
 rc = torch.from_numpy(np.concatenate(rated).astype(np.int32))
 bm = torch.from_numpy(orc.make_bitmap(n_items, np.where(rng.random(n_items) < 0.2)[0]).view(np.int32))
 lo, hi = shard_bounds(n_items, world, rank)
+# shard bounds: contiguous, cover the table once, sizes differ by at most one row (1001 items: uneven for 2 and for 8)
+bounds = [shard_bounds(n_items, world, r) for r in range(world)]
+assert bounds[0][0] == 0 and bounds[-1][1] == n_items and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+sizes = [b - a for a, b in bounds]
+assert max(sizes) - min(sizes) <= 1 and (n_items % world == 0 or max(sizes) != min(sizes))
+# data-parallel batch slices (train.DPContext.slice): a 4 096-triple batch and an odd one, cut into `world` slices
+from coldrec_amd.train import DPContext
+for B in (4096, 1001, 5):
+    cuts = [DPContext(world, r).slice(B) for r in range(world)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == B and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+    assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
 eng = ShardedTopK(V[lo:hi], lo, n_items, k, world, rank)
 s, i = eng.topk(U, None, rp, rc, bm)
 ws, wi = local_topk(U, None, V, k, rp, rc, bm)
@@ -199,17 +210,19 @@ dist.destroy_process_group()
 '''
 
 
-def test_sharded_eval_plumbing_world2_gloo(tmp_path):
-    """The N>1 path (contiguous item shards -> packed all_gather -> canonical merge) on 2 CPU ranks;
-    the compute kernels are stood in by the oracle, which is legitimate in tests."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_eval_plumbing_gloo(tmp_path, world):
+    """The N>1 path (contiguous item shards -> packed all_gather -> canonical k * world-way merge) on 2 and on 8 CPU
+    ranks (the node size the north_star names), uneven last shard (1001 items), 37 users cut into 8 user slices, the
+    data-parallel slices of a 4 096 batch; the compute kernels are stood in by the oracle, which is legitimate in tests."""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
     env = dict(os.environ, CR_ROOT=ROOT, OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
-                         env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29611 + world), str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    assert "SHARDED_OK 2" in out.stdout
+    assert f"SHARDED_OK {world}" in out.stdout
 
 
 def test_dense_truth_lookup_equals_sorted_membership():

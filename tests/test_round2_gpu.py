@@ -267,7 +267,7 @@ from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
 
 # ---- evaluation: item-row shards + all-gather + canonical merge, and the user-sharded alternative
 g = torch.Generator(device=dev).manual_seed(7)
-n_users, n_items, d, k = 20000, 200000, 128, 20
+n_users, n_items, d, k = int(os.environ.get("CR_NUSERS", "20000")), int(os.environ.get("CR_NITEMS", "200000")), 128, 20
 U = (torch.rand((n_users, d), generator=g, device=dev) - 0.5) * 0.3
 V = (torch.rand((n_items, d), generator=g, device=dev) - 0.5) * 0.3
 rng = np.random.default_rng(5)
@@ -286,7 +286,7 @@ assert torch.equal(got[1], want[1]) and torch.equal(got[0].view(torch.int32), wa
 
 # ---- data-parallel training steps vs the one-rank engine (same triples on every rank: replicated sampler)
 rng = np.random.default_rng(9)
-n_u, n_i, dd, B = 300, 500, 64, 1001                 # odd batch: uneven slices
+n_u, n_i, dd, B = 300, 500, 64, int(os.environ.get("CR_B", "1001"))     # 1001: odd batch, uneven slices
 U0 = (rng.standard_normal((n_u, dd)) * 0.1).astype(np.float32)
 V0 = (rng.standard_normal((n_i, dd)) * 0.1).astype(np.float32)
 pairs = np.unique(np.stack([rng.integers(0, n_u, 4000), rng.integers(0, n_i - 9, 4000)], 1), axis=0)
@@ -362,6 +362,88 @@ def test_two_ranks_real_hip_kernels_on_one_gpu_over_gloo(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "TWO_RANK_HIP_OK 2" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
+def test_eight_ranks_real_hip_kernels_on_one_gpu_over_gloo(tmp_path):
+    """The node size the north_star names, with the HIP kernels in the loop: EIGHT ranks share the one GPU (gloo for the
+    exchange).  4 096 users x 200 003 items: eight item shards whose sizes differ (200 003 = 8 x 25 000 + 3) + all-gather
+    + the 160-candidate canonical merge == one rank, bit for bit; eight user slices likewise; the data-parallel slices of
+    a 4 096-triple batch (MF, LightGCN, MF-SGD) and the row-sharded propagation (800 rows into 8 blocks) as in the
+    two-rank test."""
+    script = tmp_path / "eight_rank_worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, CR_ROOT=ROOT, OMP_NUM_THREADS="2", CR_NUSERS="4096", CR_NITEMS="200003", CR_B="4096")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29648", str(script)],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "TWO_RANK_HIP_OK 8" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
+_COMM_WORKER = r'''
+import ctypes, os, sys, time
+sys.path.insert(0, os.environ["CR_ROOT"])
+import numpy as np, torch
+rank, world, uid_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+ndev = torch.cuda.device_count()
+torch.cuda.set_device(rank % ndev)
+dev = torch.device("cuda", rank % ndev)
+from coldrec_amd import _lib, ops
+L = _lib.lib()
+uid = (ctypes.c_char * 128)()
+if rank == 0:
+    _lib.check(L.crh_comm_unique_id(ctypes.addressof(uid)), "crh_comm_unique_id")
+    open(uid_path + ".tmp", "wb").write(bytes(uid)); os.replace(uid_path + ".tmp", uid_path)
+else:
+    t0 = time.time()
+    while not os.path.exists(uid_path):
+        assert time.time() - t0 < 60
+        time.sleep(0.05)
+    ctypes.memmove(uid, open(uid_path, "rb").read(), 128)
+comm = L.crh_comm_init(rank, world, ctypes.addressof(uid))
+if not comm:
+    print("COMM_INIT_REFUSED", L.crh_last_error().decode()); sys.exit(0)
+st = torch.cuda.current_stream().cuda_stream
+n_users, n_items, d, k = 1000, 40001, 64, 20
+g = torch.Generator(device=dev).manual_seed(11)
+U = (torch.rand((n_users, d), generator=g, device=dev) - 0.5)
+V = (torch.rand((n_items, d), generator=g, device=dev) - 0.5)
+lo, hi = rank * n_items // world, (rank + 1) * n_items // world
+s, i = ops.score_topk(U, None, V[lo:hi].contiguous(), k, item_base=lo)
+gs = torch.empty((world, n_users, k), device=dev)
+gi = torch.empty((world, n_users, k), dtype=torch.int32, device=dev)
+_lib.check(L.crh_comm_allgather_topk(comm, s.data_ptr(), i.data_ptr(), n_users, k, gs.data_ptr(), gi.data_ptr(), st),
+           "crh_comm_allgather_topk")
+ms, mi = ops.merge_topk(gs, gi, k)
+ws, wi = ops.score_topk(U, None, V, k)
+x = torch.full((1000,), float(rank + 1), device=dev)
+_lib.check(L.crh_comm_allreduce_f32(comm, x.data_ptr(), x.numel(), st), "crh_comm_allreduce_f32")
+torch.cuda.synchronize()
+assert torch.equal(mi, wi) and torch.equal(ms.view(torch.int32), ws.view(torch.int32)), "shards + C-ABI all-gather + merge != one rank"
+assert float(x[0]) == world * (world + 1) / 2 and float(x.min()) == float(x.max())
+_lib.check(L.crh_comm_destroy(comm), "crh_comm_destroy")
+print("COMM_OK", rank, world)
+'''
+
+
+def test_comm_c_abi_two_ranks(tmp_path):
+    """crh_comm_unique_id / _init / _allgather_topk / _allreduce_f32 / _destroy driven by TWO processes with no
+    torch.distributed anywhere (what a non-Python caller of the C ABI does): item shards ranked per rank, the packed
+    top-k exchanged by the library's RCCL all-gather, crh_merge_topk == the one-rank ranking, bit for bit.  Needs two
+    GPUs: RCCL refuses two ranks on one device ("Duplicate GPU detected"), so on a one-GPU box the ranks report the
+    refusal (a named error from crh_comm_init, not a hang) and the test is skipped -- the documented limitation."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(_COMM_WORKER)
+    env = dict(os.environ, CR_ROOT=ROOT, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(tmp_path / "uid.bin")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    text = "".join(o[0] for o in outs)
+    if "COMM_INIT_REFUSED" in text:
+        assert torch.cuda.device_count() < 2, text
+        assert all(p.returncode == 0 for p in procs)
+        pytest.skip("one GPU: RCCL refuses two ranks on one device -- " + text.strip().splitlines()[0][:200])
+    assert all(p.returncode == 0 for p in procs), (text[-2000:], outs[0][1][-3000:], outs[1][1][-3000:])
+    assert "COMM_OK 0 2" in text and "COMM_OK 1 2" in text
 
 
 def test_private_workspace_survives_bigger_calls_between_graph_replays():
