@@ -222,7 +222,10 @@ def midsize_eval_leg(dev):
     from coldrec_amd import ops
     from oracle import oracle_np as orc
     out = {}
-    for n_users, n_items in ((8192, 262144), (65536, 131072), (131072, 262144), (131072, 1048576)):
+    for n_users, n_items in ((8192, 262144), (65536, 131072), (131072, 262144), (131072, 1048576),
+                             (4096, 10_000_000),        # the reference's own user block (--bs 4096) on the S-EVAL catalogue
+                             (131072, 1_250_000)):      # one rank's item shard of the 8-GPU run
+
         U = xavier_(n_users, 128, 31, dev, n_items)
         V = item_shard(n_items, 128, 0, n_items, dev)
         rowptr, col = rated_lists(n_users, n_items, 50, seed=4)

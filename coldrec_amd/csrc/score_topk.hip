@@ -68,6 +68,11 @@ struct ScoreArgs {
     float* dense;           // small catalogues: write the score tiles here (slot-major, `dense_stride` floats per
     int64_t dense_stride;   // user, a multiple of 32) instead of selecting; crh_mask_topk_f32 ranks the block
     int64_t user_base;      // first table row of the block when `users` is NULL
+    // SEEDED lists (score_topk_seeded): every user's list starts as the finished top-k of an item PREFIX that was ranked
+    // beforehand ([n_users][k], canonical order, padded with (-inf, PAD)), so the thresholds are tight from the first
+    // tile and an item-range cut no longer repeats the top-k warm-up.  The seeds' ids lie below this launch's item_base.
+    const float* seed_score;
+    const int32_t* seed_idx;
 };
 
 // in : lane (i,0) holds k = 8q+0..3 of row i, lane (i,1) holds k = 8q+4..7
@@ -213,6 +218,26 @@ __device__ __forceinline__ void wave_lds_init(const WaveLds<UPW>& w, const Score
         const bool has = a.rated_rowptr && slot < a.n_users;
         w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
         w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
+    }
+    if (a.seed_score) {
+        // seeded lists: copy each slot's prefix top-k into LDS; its fill = the entries before the padding
+        const int K = a.k;
+        for (int j = 0; j < UPW; ++j) {
+            const int64_t slot = slot0 + j;
+            if (slot >= a.n_users) break;                         // wave-uniform
+            int n = 0;
+            for (int e0 = 0; e0 < K; e0 += 64) {
+                const int e = e0 + lane;
+                int gi = CRH_PAD_IDX;
+                if (e < K) {
+                    gi = a.seed_idx[slot * K + e];
+                    w.ls[j * K + e] = a.seed_score[slot * K + e];
+                    w.li[j * K + e] = gi;
+                }
+                n += __popcll(__ballot(gi != CRH_PAD_IDX));
+            }
+            if (lane == 0) w.cnt[j] = n;
+        }
     }
     if (!filter || !a.rated_rowptr) return;
     for (int j = lane; j < UPW * 8; j += 64) w.rfilter[j] = 0u;
@@ -397,6 +422,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         // padding columns of the last group: duplicate the last user, threshold +inf (with -inf every tile of the
         // wave would enter the slow path to find nothing: 100 000 users ran 2.2x slower than 131 072)
         tau[u] = slot < a.n_users ? CRH_NEG_INF : __builtin_inff();
+        if (a.seed_score && slot < a.n_users) tau[u] = wave_list_tau(w.ls + (32 * u + i) * K, w.cnt[32 * u + i], K);
         if (slot >= a.n_users) slot = a.n_users - 1;
         const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
         const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
@@ -525,7 +551,11 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         if (slot >= a.n_users) break;
         const int n = __builtin_amdgcn_readfirstlane(w.cnt[j]);
         const int64_t o = ((int64_t)split * a.n_users + slot) * K;
-        wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
+        if (a.seed_score && S > 1)    // a cut keeps its own item range (the first cut: and the seeds below it)
+            wave_list_store_range(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane,
+                                  split == 0 ? INT32_MIN : (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end));
+        else
+            wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
     }
 }
 
@@ -580,6 +610,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
         // padding columns of the last group: duplicate the last user, threshold +inf (with -inf every tile of the
         // wave would enter the slow path to find nothing: 100 000 users ran 2.2x slower than 131 072)
         tau[u] = slot < a.n_users ? CRH_NEG_INF : __builtin_inff();
+        if (a.seed_score && slot < a.n_users) tau[u] = wave_list_tau(w.ls + (32 * u + i) * K, w.cnt[32 * u + i], K);
         if (slot >= a.n_users) slot = a.n_users - 1;
         const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
         const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
@@ -749,7 +780,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
             if (slot >= a.n_users) break;
             const int n = __builtin_amdgcn_readfirstlane(w.cnt[j]);
             const int64_t o = ((int64_t)split * a.n_users + slot) * K;
-            wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
+            if (a.seed_score && S > 1)
+                wave_list_store_range(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane,
+                                      split == 0 ? INT32_MIN : (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end));
+            else
+                wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
         }
     }
 }
@@ -943,12 +978,95 @@ size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
     return (groups * 64 * row + 255) & ~(size_t)255;       // whole 64-user groups
 }
 
+// Prefix length of the seeded route (0 = not applicable): 1/16 of the catalogue, 4 096 .. 16 384 items, whole tiles.
+// After a prefix of P items a user takes ~k ln(N / P) candidates through the slow path instead of k (1 + ln(N / k)), and
+// every item-range cut shares that total instead of repeating the warm-up; the prefix itself is ranked by the dense route
+// at 8 bytes of traffic per (user, item) pair.
+int64_t seed_prefix_items(int64_t n_items) {
+    if (n_items < 65536) return 0;
+    const char* pe = getenv("CRH_SCORE_SEED_ITEMS");                  // tuning hook (read per call)
+    int64_t p = pe && atoll(pe) >= 1024 ? std::min<int64_t>(atoll(pe), n_items / 4) : n_items / 16;
+    if (!pe) p = std::max<int64_t>(4096, std::min<int64_t>(16384, p));
+    return p & ~(int64_t)31;
+}
+size_t seed_bytes(int64_t n_users, int k) { return (((size_t)n_users * k * 8) + 255) & ~(size_t)255; }
+
+// Split count under seeded lists: cuts are (nearly) free, so fill whole rounds of wave slots; a small per-cut charge for the
+// filter rebuild, the seed copy and the merge.
+int pick_splits_seeded(int64_t n_units, int64_t n_items, double cap) {
+    const int64_t T = (n_items + 31) / 32;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && T / s < 64) break;
+        const double w = (double)n_units * s;
+        const double rounds = ceil(w / cap);
+        const double cost = rounds * cap / w * (1.0 + 0.004 * s);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
+}
+
+int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
+                    int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
+                    const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
+                    void* workspace, size_t workspace_bytes, void* stream, int n_splits, void* ev_kernel_start,
+                    void* ev_kernel_stop, const char* who, const float* seed_score, const int32_t* seed_idx);
+
 // esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
+// Route of a call (n_splits == 0; a caller that names a split count gets the plain fused selection):
+//   seeded  : users that do not fill the chip on their own (the unseeded picker would cut the item range) and a catalogue of
+//             >= 65 536 items: rank a prefix by the dense route, then the fused selection over the rest, lists seeded;
+//   dense   : small catalogues (score block + wave-per-user ranking);
+//   fused   : everything else (the headline).
 int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
                    int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
                    const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
                    void* workspace, size_t workspace_bytes, void* stream, int n_splits, void* ev_kernel_start,
                    void* ev_kernel_stop, const char* who) {
+    const char* sm = getenv("CRH_SCORE_SEED");                       // read per call: 0 never, 1 auto (default), 2 whenever possible
+    const int seed_mode = sm ? atoi(sm) : 1;
+    const int64_t P = seed_prefix_items(n_items);
+    if (seed_mode && n_splits == 0 && P > 0 && user_emb && item_emb && out_score && out_idx && n_users > 0 && k >= 1 &&
+        k <= CRH_MAX_K && workspace) {
+        const int upw = users_per_wave(esz, d);
+        const int64_t n_ug = (n_users + upw - 1) / upw;
+        const bool cuts = pick_splits(n_ug, n_items, 2) > 1;          // the users alone do not fill the wave slots
+        const size_t sb = seed_bytes(n_users, k);
+        const size_t stage1 = dense_block_bytes(n_users, P) + packed_bytes(P, d, esz);
+        const size_t stage2 = lists_bytes(n_users, k) + packed_bytes(n_items - P, d, esz);
+        if ((cuts || seed_mode == 2) && dense_block_bytes(n_users, P) > 0 && workspace_bytes >= sb + std::max(stage1, stage2)) {
+            float* seed_s = reinterpret_cast<float*>(workspace);
+            int32_t* seed_i = reinterpret_cast<int32_t*>(seed_s + (size_t)n_users * k);
+            void* ws2 = reinterpret_cast<char*>(workspace) + sb;
+            hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+            if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
+            int rc = score_topk_impl(esz, user_emb, users, n_users, item_emb, P, d, rated_rowptr, rated_col, cand_bitmap, k,
+                                     item_base, seed_s, seed_i, ws2, workspace_bytes - sb, stream, 0, nullptr, nullptr, who,
+                                     nullptr, nullptr);
+            if (rc != CRH_OK) return rc;
+            rc = score_topk_impl(esz, user_emb, users, n_users,
+                                 reinterpret_cast<const char*>(item_emb) + (size_t)P * d * esz, n_items - P, d, rated_rowptr,
+                                 rated_col, cand_bitmap, k, item_base + P, out_score, out_idx, ws2, workspace_bytes - sb, stream,
+                                 0, nullptr, nullptr, who, seed_s, seed_i);
+            if (rc != CRH_OK) return rc;
+            if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
+            return CRH_OK;
+        }
+    }
+    return score_topk_impl(esz, user_emb, users, n_users, item_emb, n_items, d, rated_rowptr, rated_col, cand_bitmap, k,
+                           item_base, out_score, out_idx, workspace, workspace_bytes, stream, n_splits, ev_kernel_start,
+                           ev_kernel_stop, who, nullptr, nullptr);
+}
+
+int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
+                    int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
+                    const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
+                    void* workspace, size_t workspace_bytes, void* stream, int n_splits, void* ev_kernel_start,
+                    void* ev_kernel_stop, const char* who, const float* seed_score, const int32_t* seed_idx) {
     CRH_CHECK_ARG(user_emb && item_emb && out_score && out_idx, "%s: NULL table/output pointer", who);
     CRH_CHECK_ARG(n_users > 0 && n_items > 0, "%s: empty block (n_users=%lld, n_items=%lld)", who,
                   (long long)n_users, (long long)n_items);
@@ -1006,6 +1124,8 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     a.dense = nullptr;
     a.dense_stride = 0;
     a.user_base = 0;
+    a.seed_score = seed_score;
+    a.seed_idx = seed_idx;
     const int64_t T = (n_items + 31) / 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
@@ -1017,7 +1137,7 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     // ranks it; users go in chunks if the block would pass 8 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
     static const int dense_mode = getenv("CRH_SCORE_DENSE") ? atoi(getenv("CRH_SCORE_DENSE")) : 1;
     const size_t dense_b = dense_block_bytes(n_users, n_items);
-    if (dense_mode && n_splits == 0 && dense_b && workspace && workspace_bytes >= dense_b) {
+    if (dense_mode && n_splits == 0 && !seed_score && dense_b && workspace && workspace_bytes >= dense_b) {
         const int64_t stride = T * 32;
         const int upw_pw = users_per_wave(esz, d);
         int64_t chunk = (int64_t)(dense_b / ((size_t)stride * sizeof(float)));
@@ -1060,6 +1180,8 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     }
 
     a.n_splits = n_splits > 0 ? n_splits
+                 : seed_score ? pick_splits_seeded(use_wg ? (a.n_ugroups + wg_waves - 1) / wg_waves : a.n_ugroups, n_items,
+                                                   use_wg ? (wg_waves == 8 ? 256.0 : 512.0) : 1024.0 * occ)
                  : use_wg     ? pick_splits_wg((a.n_ugroups + wg_waves - 1) / wg_waves, n_items, k, wg_waves == 8 ? 256 : 512,
                                                esz == 2 ? 18750.0 : 5700.0)
                               : pick_splits(a.n_ugroups, n_items, occ);
@@ -1094,10 +1216,14 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
     a.sync_window = sync_win;
     a.sync_stride = 0;
     const int64_t n_wg_launch = (a.n_ugroups + wg_waves - 1) / wg_waves;
-    const bool sync_pw = !use_wg && occ == 2 && a.n_ugroups <= 2048 && a.n_ugroups > 256;
+    // Item-range cuts under SEEDED lists take part too (per-wave kernel): every cut walks its own range, window by window
+    // from its own start, and the cuts' window counts differ by at most one, so no wave ever waits for a window another
+    // wave will not report; the L2 of an XCD then holds two windows of each cut instead of the cuts' drifting streams.
+    const bool cuts_ok = a.n_splits == 1 || (seed_score && !use_wg && T / a.n_splits >= 4 * sync_win);
+    const bool sync_pw = !use_wg && occ == 2 && a.n_ugroups * a.n_splits <= 2048 && a.n_ugroups * a.n_splits > 256;
     const bool sync_wg = use_wg && n_wg_launch <= (wg_waves == 8 ? 256 : 512) && n_wg_launch > 8;   // one resident round
-    if (sync_win > 0 && (sync_pw || sync_wg) && a.n_splits == 1 && a.packed) {
-        const int64_t n_win = (T + sync_win - 1) / sync_win + 1;
+    if (sync_win > 0 && (sync_pw || sync_wg) && cuts_ok && a.packed) {
+        const int64_t n_win = (T / a.n_splits + 1 + sync_win - 1) / sync_win + 1;
         const size_t need = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);
         if (workspace_bytes >= need && (size_t)(n_win + 1) * 8 * sizeof(unsigned) <= sync_bytes(n_items)) {
             a.sync_stride = n_win + 1;
@@ -1156,16 +1282,27 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
 // Partial lists of the item-range splits + the fragment-ordered copy of the item shard.  A caller that can
 // only afford the first part (crh_score_topk_min_workspace_bytes) still gets the same results from the
 // row-major kernel, at ~0.9x the speed.
-extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
+namespace {
+// everything a call can use: partial lists / dense block, packed copy, lockstep counters -- and for the seeded route the
+// seed lists in front plus the prefix's own dense block
+size_t full_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k, int esz, bool dim_ok) {
     if (n_users <= 0 || k <= 0) return 0;
-    return std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) +
-           (crh_score_topk_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 4) + sync_bytes(n_items) : 0);
+    const size_t tail = dim_ok && n_items > 0 ? packed_bytes(n_items, d, esz) + sync_bytes(n_items) : 0;
+    size_t need = std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) + tail;
+    const int64_t P = seed_prefix_items(n_items);
+    if (P > 0 && dim_ok)
+        need = std::max(need, std::max(dense_block_bytes(n_users, P) + packed_bytes(P, d, esz), lists_bytes(n_users, k) + tail)) +
+               seed_bytes(n_users, k);
+    return need;
+}
+}  // namespace
+
+extern "C" size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
+    return full_workspace_bytes(n_users, n_items, d, k, 4, crh_score_topk_supports_dim(d) != 0);
 }
 
 extern "C" size_t crh_score_topk_f16_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k) {
-    if (n_users <= 0 || k <= 0) return 0;
-    return std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) +
-           (crh_score_topk_f16_supports_dim(d) && n_items > 0 ? packed_bytes(n_items, d, 2) + sync_bytes(n_items) : 0);
+    return full_workspace_bytes(n_users, n_items, d, k, 2, crh_score_topk_f16_supports_dim(d) != 0);
 }
 
 extern "C" size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k) {

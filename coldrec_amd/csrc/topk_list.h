@@ -53,6 +53,35 @@ __device__ __forceinline__ void wave_list_store(const float* ls, const int* li, 
     }
 }
 
+// The same with a filter on the item id: only entries with lo <= id < hi are written (compacted, order kept), the rest
+// of out[0..K) is padding.  Seeded lists under item-range cuts: every cut starts from the same prefix top-k, so a cut
+// writes the entries of ITS range only (the first cut also the prefix's) and the merge sees every item once.
+__device__ __forceinline__ void wave_list_store_range(const float* ls, const int* li, int n, int K, float* out_s, int* out_i,
+                                                      int lane, int lo, int hi) {
+    int base = 0;
+    for (int e0 = 0; e0 < K; e0 += 64) {
+        const int e = e0 + lane;
+        float sc = CRH_NEG_INF;
+        int gi = CRH_PAD_IDX;
+        if (e < n) {
+            sc = ls[e];
+            gi = li[e];
+        }
+        const bool keep = e < n && gi >= lo && gi < hi;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            out_s[pos] = sc;
+            out_i[pos] = gi;
+        }
+        base += __popcll(m);
+    }
+    for (int e = base + lane; e < K; e += 64) {
+        out_s[e] = CRH_NEG_INF;
+        out_i[e] = CRH_PAD_IDX;
+    }
+}
+
 // true when the candidate cannot enter a FULL list even at its best possible value
 // (the masked value -1e9 may exceed a raw score below -1e9, hence the max)
 __device__ __forceinline__ bool wave_list_rejects(const float* lsu, const int* liu, int n, int K,

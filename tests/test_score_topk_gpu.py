@@ -462,3 +462,81 @@ def test_dense_route_block_above_the_default_8_gib_limit():
     assert chunk == 65536
     _dense_chunk_case(70500, n_users, n_items, 8, 20, 64, 7,
                       lambda n: np.array([0, 63, 64, chunk - 65, chunk - 1, chunk, chunk + 1, chunk + 63, chunk + 64, n - 1]))
+
+
+@pytest.mark.parametrize("case", ["plain", "ties", "masked_prefix", "k128", "shard", "fp16"])
+def test_seeded_route_prefix_then_fused_equals_plain_and_oracle(monkeypatch, case):
+    """Round 3: catalogues of >= 65 536 items whose users do not fill the chip are ranked in two stages -- a prefix of
+    4 096 .. 16 384 items by the dense route, then the fused selection over the rest with every list SEEDED by the
+    prefix's top-k, item-range cuts keeping their own ids only (score_topk_seeded).  Same bits as the plain fused
+    selection (forced single range) and as the oracle: heavy ties across the prefix boundary, a prefix in which a user
+    has fewer than k unmasked items (masked entries are seeds too), k = 128, a shard with an item base off the tile
+    grid, fp16 tables."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng({"plain": 1, "ties": 2, "masked_prefix": 3, "k128": 4, "shard": 5, "fp16": 6}[case])
+    n_rows, n_users, n_items, d, k, base = 700, 333, 70001, 16, 20, 0
+    if case == "k128":
+        k = 128
+    if case == "shard":
+        base, n_items = 12345, 131072 + 77
+    U = (rng.standard_normal((n_rows, d)) * 0.5).astype(np.float32)
+    V = (rng.standard_normal((n_items, d)) * 0.5).astype(np.float32)
+    if case in ("ties", "fp16"):
+        U, V = np.round(U * 4) / 4, np.round(V * 4) / 4                   # exact arithmetic, many equal scores
+    users = rng.permutation(n_rows)[:n_users].astype(np.int32)
+    lens = rng.integers(0, 40, n_users)
+    key = np.unique(np.repeat(np.arange(n_users, dtype=np.int64), lens) << 32 | (rng.integers(0, n_items, int(lens.sum())) + base))
+    lens = np.bincount((key >> 32).astype(np.int64), minlength=n_users)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = (key & 0xFFFFFFFF).astype(np.int64)
+    cold = np.where(rng.random(n_items) < 0.2)[0] + base
+    if case == "masked_prefix":                                           # the whole prefix masked except 7 items
+        P = 4096 if n_items < 16 * 4096 + 4096 else min(16384, n_items // 16) // 32 * 32
+        keep = rng.choice(P, 7, replace=False)
+        cold = np.union1d(np.setdiff1d(np.arange(P), keep) + base, cold)
+    DEV = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dt = torch.float16 if case == "fp16" else torch.float32
+    tU, tV, tu = t(U).to(dt), t(V).to(dt), t(users)
+    rp, rc = t(rowptr), t(col.astype(np.int32))
+    bm = ops.make_bitmap(base + n_items, cold, DEV)
+    monkeypatch.setenv("CRH_SCORE_SEED", "2")                             # seeded whenever possible
+    s0, i0 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base)
+    monkeypatch.setenv("CRH_SCORE_SEED", "0")
+    s1, i1 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base, n_splits=1)      # plain fused selection
+    s2, i2 = ops.score_topk(tU, tu, tV, k, rp, rc, bm, item_base=base)                  # the dispatcher without seeding
+    torch.cuda.synchronize()
+    for s, i in ((s1, i1), (s2, i2)):
+        assert torch.equal(i0, i) and torch.equal(s0.view(torch.int32), s.view(torch.int32))
+    ws, wi = orc.score_topk(U, users.astype(np.int64), V, k, rowptr, col, orc.make_bitmap(base + n_items, cold), item_base=base)
+    assert np.array_equal(i0.cpu().numpy(), wi)
+    if case != "fp16":
+        assert np.array_equal(s0.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    if case == "masked_prefix":
+        assert (ws[:, 0] > -1e8).all()                                    # real candidates exist beyond the prefix
+
+
+def test_seeded_route_is_what_the_dispatcher_picks_for_few_users_on_a_large_catalogue(monkeypatch):
+    """8 192 users x 262 144 items (a `eval_midsize` shape): the dispatcher's own choice (no switches) must equal the
+    plain fused selection bit for bit, with rated lists, bitmap and a user index; spot-checked against the oracle."""
+    from coldrec_amd import ops
+    monkeypatch.delenv("CRH_SCORE_SEED", raising=False)
+    rng = np.random.default_rng(8)
+    n_users, n_items, d, k = 8192, 262144, 32, 20
+    DEV = _dev()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    U = (torch.rand((n_users, d), generator=g, device=DEV) - 0.5)
+    V = (torch.rand((n_items, d), generator=g, device=DEV) - 0.5)
+    rated = [np.unique(rng.integers(0, n_items, 10)) for _ in range(n_users)]
+    rp, rc = ops.rated_csr(rated, DEV)
+    cold = np.where(rng.random(n_items) < 0.2)[0]
+    bm = ops.make_bitmap(n_items, cold, DEV)
+    s0, i0 = ops.score_topk(U, None, V, k, rp, rc, bm)
+    s1, i1 = ops.score_topk(U, None, V, k, rp, rc, bm, n_splits=1)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    pick = np.array([0, 63, 64, 4097, n_users - 1])
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    ws, wi = orc.score_topk(U.cpu().numpy(), pick.astype(np.int64), V.cpu().numpy(), k, sub_rp, sub_col,
+                            orc.make_bitmap(n_items, cold))
+    assert np.array_equal(i0.cpu().numpy()[pick], wi) and np.array_equal(s0.cpu().numpy()[pick].view(np.uint32), ws.view(np.uint32))
