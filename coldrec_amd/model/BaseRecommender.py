@@ -67,6 +67,7 @@ class BaseColdStartTrainer(ABC):
         self.epochs_ran = 0
         self.eval_every = max(1, int(getattr(a, 'eval_every', 1)))
         self._eval_cache: Dict[Any, Dict[str, Any]] = {}
+        ops.warm_up(self.device)          # the library's device code is loaded here, not inside the first timed epoch
 
     # ------------------------------------------------------------------ plugin contract
     @abstractmethod
@@ -108,7 +109,8 @@ class BaseColdStartTrainer(ABC):
         if hit is not None:
             return hit
         d = self.data
-        users, gt_rowptr, gt_items = truth_csr(data_set, item_of=d.item)
+        cached = d.truth_csr_cached(data_set) if hasattr(d, 'truth_csr_cached') else None
+        users, gt_rowptr, gt_items = cached if cached is not None else truth_csr(data_set, item_of=d.item)
         uint = d.get_user_id_list(users)
         lens = d.rated_rowptr[uint + 1] - d.rated_rowptr[uint]
         rowptr = np.zeros(len(users) + 1, np.int64)

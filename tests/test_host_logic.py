@@ -260,3 +260,24 @@ def test_metrics_from_a_precomputed_hit_matrix_and_sequential_sums():
     x = rng.random(100_000) / 3.0
     assert _seq_sum(x) == float(sum(x.tolist()))
     assert _seq_sum(np.zeros(0)) == 0.0
+
+
+@pytest.mark.parametrize("name", ["toy_item.npz", "toy_user.npz"])
+def test_builder_truth_csr_equals_the_dict_walk(name):
+    """The ground-truth CSR the builder precomputes for its six valid / test sets (vectorised, at load time) is what
+    evaluator.truth_csr derives from the nested dicts the trainers pass around: same users in the same order, same
+    rowptr, same internal item ids in the same order -- including duplicate (user, item) records (counted once)."""
+    from coldrec_amd.util.evaluator import truth_csr
+    _, d = builder(name)
+    for key in ("warm_valid", "warm_test", "cold_valid", "cold_test", "overall_valid", "overall_test"):
+        s = getattr(d, key + "_set")
+        users, rp, items = truth_csr(s, item_of=d.item)
+        cu, crp, ci = d.truth_csr_cached(s)
+        assert cu == users and np.array_equal(crp, rp) and np.array_equal(ci, items), key
+    assert d.truth_csr_cached({}) is None
+    # duplicates and interleaved users
+    p = np.array([[5, 9], [3, 9], [5, 7], [5, 9], [3, 1], [5, 7], [4, 9]], np.int64)
+    import types
+    fake = types.SimpleNamespace(item_keys=np.array([9, 7, 1], np.int64))
+    u, rp, it = type(d)._pairs_truth_csr(fake, p)
+    assert u == [5, 3, 4] and rp.tolist() == [0, 2, 4, 5] and it.tolist() == [0, 1, 0, 2, 0]
