@@ -62,6 +62,7 @@ SIGNATURES = {
     "crh_adam_step_scalars_host": (None, [_f64, _f64, _f64, _i64, _vp]),
     "crh_adam_step_scalars_range_host": (None, [_f64, _f64, _f64, _i64, _i64, _vp]),
     "crh_spmm_segment_edges": (_i32, []),
+    "crh_spmm_lane_group": (_i32, [_i64, _i32, _i64]),
     "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),
     "crh_spmm_csr_adam_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _f32, _vp, _f32, _vp, _vp, _vp, _vp,
                                      _f64, _f64, _f64, _f64, _i64, _vp, _i32, _vp]),
@@ -119,7 +120,9 @@ class SpmmSched(ctypes.Structure):
     """crh_spmm_sched of include/coldrec_hip.h."""
     _fields_ = [("seg_row", _vp), ("seg_ptr", _vp), ("seg_slot", _vp), ("n_seg", _i64),
                 ("multi_row", _vp), ("multi_first", _vp), ("multi_count", _vp), ("n_multi", _i32),
-                ("n_partial", _i64), ("nnz", _i64), ("seg_desc", _vp)]
+                ("n_partial", _i64), ("nnz", _i64), ("seg_desc", _vp),
+                ("slab", _vp), ("slab_lanes", _i32), ("slab_buckets", _i32), ("n_slab", _i64),
+                ("slab_first", _i32 * 12), ("slab_units", _i32 * 12), ("slab_base", _i64 * 12)]
 
 
 class DSamplerIO(ctypes.Structure):

@@ -52,6 +52,7 @@ struct SpmmArgs {
     const float* step_scalars;
     int zero_acc_in;        // clear acc_in's row once it has been consumed (ready for the next step's scatter)
     int sgd;                // optimiser epilogue is plain SGD: p <- fma(neg_step_size, g, p), no m / v
+    int use_slab;           // light rows from the schedule's record stream (sched.slab, laid out for this launch's G)
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -61,11 +62,18 @@ __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
     acc.w = fmaf(v, x.w, acc.w);
 }
 
+__device__ __forceinline__ void store_row_z(const SpmmArgs& a, int64_t o, const f32x4& acc, f32x4 z);
+
 __device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if ((a.acc_out || a.adam_p) && a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
+    store_row_z(a, o, acc, z);
+}
+
+// z = the row's acc_in (zeros without one), already loaded: the record path requests it before the gathers
+__device__ __forceinline__ void store_row_z(const SpmmArgs& a, int64_t o, const f32x4& acc, f32x4 z) {
     if (a.Y) *reinterpret_cast<f32x4*>(a.Y + o) = acc;
     if (a.acc_out || a.adam_p) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
         f32x4 r;
         r.x = (z.x * a.s_in + acc.x) * a.s_out;
         r.y = (z.y * a.s_in + acc.y) * a.s_out;
@@ -147,6 +155,87 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
 // Light path: work item = one row (no schedule) or one single-segment row; a lane group of G lanes owns the
 // row's 16*G-byte column slice and finishes it (bit-identical to the oracle's edge-order chain).
 // Heavy path (rows with several segments): one wave per (row, slice).
+// ---- record stream ("slab") light path, round 3 --------------------------------------------------------------------
+// One lane group = one record (see crh_spmm_sched::slab).  A lane holds ONE pair of each unit; pair q of a unit is
+// broadcast to the lane group by shuffles; the fma chain runs in edge order, so the row's bits are those of the
+// descriptor path and of the oracle's chain.
+#define CRH_SLAB_LD(Q)                                                                                         \
+    float v##Q = 0.f;                                                                                          \
+    f32x4 x##Q = {0.f, 0.f, 0.f, 0.f};                                                                         \
+    if constexpr (Q0 + Q < G) {                                                                                \
+        const int cc = __shfl((int)u.x, Q0 + Q, G);                                                            \
+        v##Q = __int_as_float(__shfl((int)u.y, Q0 + Q, G));                                                    \
+        if (on && ebase + Q < cnt) x##Q = reinterpret_cast<const f32x4*>(a.X + (int64_t)cc * a.d)[c];          \
+    }
+#define CRH_SLAB_FM(Q) \
+    if constexpr (Q0 + Q < G) { if (ebase + Q < cnt) fma4(acc, v##Q, x##Q); }
+
+// lanes Q0 .. Q0 + 7 of a unit (as far as the lane group goes); lane Q0 holds edge `ebase` of the row
+template <int G, int Q0>
+__device__ __forceinline__ void slab_batch(const SpmmArgs& a, const uint2& u, int ebase, int cnt, int c, bool on, f32x4& acc) {
+    CRH_SLAB_LD(0) CRH_SLAB_LD(1) CRH_SLAB_LD(2) CRH_SLAB_LD(3) CRH_SLAB_LD(4) CRH_SLAB_LD(5) CRH_SLAB_LD(6) CRH_SLAB_LD(7)
+    CRH_SLAB_FM(0) CRH_SLAB_FM(1) CRH_SLAB_FM(2) CRH_SLAB_FM(3) CRH_SLAB_FM(4) CRH_SLAB_FM(5) CRH_SLAB_FM(6) CRH_SLAB_FM(7)
+}
+
+// all lanes from START on; e_lane0 = edge index lane 0 would hold (-1 in unit 0, whose lane 0 is the header)
+template <int G, int START>
+__device__ __forceinline__ void slab_unit(const SpmmArgs& a, const uint2& u, int e_lane0, int cnt, int c, bool on, f32x4& acc) {
+    if constexpr (START < G) {
+        slab_batch<G, START>(a, u, e_lane0 + START, cnt, c, on, acc);
+        slab_unit<G, START + 8>(a, u, e_lane0, cnt, c, on, acc);
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c, bool on, int lig) {
+    const crh_spmm_sched& sc = a.sched;
+    const uint2* stream = reinterpret_cast<const uint2*>(sc.slab);
+    const int64_t w = jl * (256 / G) + threadIdx.x / G;
+    // the record's address is arithmetic: bucket by comparing against the buckets' first work items (unused: INT32_MAX)
+    int64_t bs = sc.slab_base[0];
+    int fs = 0, un = sc.slab_units[0];
+#pragma unroll
+    for (int b = 1; b < CRH_SPMM_SLAB_BUCKETS; ++b)
+        if (w >= sc.slab_first[b]) {
+            bs = sc.slab_base[b];
+            fs = sc.slab_first[b];
+            un = sc.slab_units[b];
+        }
+    if (w >= sc.n_slab) un = 0;
+    const int64_t base = bs + (w - fs) * (int64_t)un * G;
+    // header + first edges and the second unit are requested together (a read past a one-unit record lands in the next
+    // record or in the stream's tail padding)
+    uint2 u0 = {0u, 0u}, u1 = {0u, 0u};
+    if (un > 0) {
+        u0 = stream[base + lig];
+        u1 = stream[base + G + lig];
+    }
+    int mu = un;                                           // the wave's longest record decides the trip count
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+        const int o = __shfl_xor(mu, off);
+        mu = o > mu ? o : mu;
+    }
+    if (mu == 0) return;
+    const int64_t row = __shfl((int)u0.x, 0, G);
+    const int cnt = un > 0 ? __shfl((int)u0.y, 0, G) : 0;
+    const int64_t o = row * a.d + (int64_t)c * 4;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (un > 0 && on && (a.acc_out || a.adam_p) && a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    slab_unit<G, 1>(a, u0, -1, cnt, c, on, acc);
+    if (mu > 1) {
+        uint2 cur = u1;
+        for (int k = 1; k < mu; ++k) {
+            uint2 nxt = {0u, 0u};
+            if (k + 1 < un) nxt = stream[base + (int64_t)(k + 1) * G + lig];
+            slab_unit<G, 0>(a, cur, (G - 1) + (k - 1) * G, cnt, c, on, acc);
+            cur = nxt;
+        }
+    }
+    if (un > 0 && on) store_row_z(a, o, acc, z);
+}
+
 // One heavy row (more than the schedule's segment length of edges) by a whole workgroup: its 256 / GG lane groups of GG
 // lanes split the edge list into contiguous chunks (multiples of 8 edges); partial sums meet in a fixed order: shuffle
 // tree inside a wave, then the 4 waves through LDS.  c0 = first float4 column of this workgroup's column range.
@@ -212,6 +301,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     if (j >= heavy_blocks) {
         const int64_t jl = j - heavy_blocks;
         if (jl >= a.light_blocks || (CRH_ABLATE(a.skip) & 2)) return;
+        if constexpr (G >= 8) {
+            if (a.use_slab) {
+                slab_light<G>(a, jl, c, on, lig);
+                return;
+            }
+        }
         const int64_t n_work = seg ? a.sched.n_seg : a.n_rows;
         // rows_per_group work items per lane group, a whole "grid" apart: with the schedule's descending-length order a
         // long row is paired with a short one, and fewer, fully resident workgroups replace a second round of them
@@ -261,8 +356,10 @@ int launch_spmm(SpmmArgs a, hipStream_t st) {
     const int64_t n_work = a.sched.n_seg > 0 ? a.sched.n_seg : a.n_rows;
     const int64_t heavy_blocks = a.sched.n_seg > 0 ? (int64_t)a.sched.n_multi : 0;
     const int rows_per_group = force_rows > 0 ? force_rows : 1;
-    const int64_t per_block = (256 / G) * rows_per_group;
-    a.light_blocks = (n_work + per_block - 1) / per_block;
+    static const int no_slab = getenv("CRH_SPMM_SLAB") ? !atoi(getenv("CRH_SPMM_SLAB")) : 0;
+    a.use_slab = !no_slab && G >= 8 && a.sched.n_seg > 0 && a.sched.slab && a.sched.slab_lanes == G && a.sched.n_slab >= 0;
+    const int64_t per_block = a.use_slab ? (256 / G) : (256 / G) * rows_per_group;
+    a.light_blocks = ((a.use_slab ? (int64_t)a.sched.n_slab : n_work) + per_block - 1) / per_block;
     const int64_t per_slice = a.light_blocks + heavy_blocks;
     const int64_t groups8 = (per_slice + (8 / a.cs) - 1) / (8 / a.cs);      // grid in units of 8 blocks
     hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)(groups8 * 8)), dim3(256), 0, st, a);
@@ -285,6 +382,26 @@ extern "C" size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d) {
 }
 
 namespace {
+// Column slices and lanes per lane group of a launch.  Slices: as few as make one slice of the dense operand fit an XCD's
+// L2 (leaving room for the edge stream), at most 4, and only while a slice keeps >= 4 lanes (64 B) per row; only with a
+// schedule (nnz >= 0), and only while re-reading the edge list once per slice stays below the operand.
+void spmm_shape(int64_t n_rows, int d, int64_t nnz, int* cs_out, int* g_out) {
+    const int nvec = d / 4;
+    static const int force_cs = getenv("CRH_SPMM_SLICES") ? atoi(getenv("CRH_SPMM_SLICES")) : 0;
+    int cs = 1;
+    const double bytes = (double)n_rows * d * 4;
+    if (nnz >= 0 && bytes > 3.0e6 && bytes <= 4 * 3.2e6) {
+        while (cs < 4 && bytes / cs > 3.2e6) cs <<= 1;
+        while (cs > 1 && (double)nnz * 8.0 * cs > bytes) cs >>= 1;
+    }
+    if (force_cs) cs = force_cs;
+    while (cs > 1 && (nvec % cs != 0 || nvec / cs < 4)) cs >>= 1;
+    int G = 1;
+    while (G < nvec / cs && G < 64) G <<= 1;
+    *cs_out = cs;
+    *g_out = G;
+}
+
 int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* x,
              int d, float* y, float* acc_in, float s_in, float* acc_out, float s_out, const crh_spmm_sched* sched,
              float* adam_p, float* adam_m, float* adam_v, AdamK k, float bc2_sqrt, float nss, const float* step_scalars,
@@ -299,7 +416,7 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
                   "%s: dense operands must be 16-byte aligned", who);
     static const int skip = CRH_PROFILE_ENV("CRH_SPMM_SKIP");
     SpmmArgs a{rowptr, col, val, n_rows, x, d, y, acc_in, acc_out, s_in, s_out, {}, nullptr, 1, 0, skip,
-               adam_p, adam_m, adam_v, k, bc2_sqrt, nss, step_scalars, zero_acc_in, sgd};
+               adam_p, adam_m, adam_v, k, bc2_sqrt, nss, step_scalars, zero_acc_in, sgd, 0};
     if (sched && sched->n_seg > 0) {
         CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "%s: incomplete schedule", who);
         CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "%s: incomplete schedule (heavy rows)", who);
@@ -310,27 +427,13 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
         a.sched.n_seg = 0;
         a.sched.n_multi = 0;
         a.sched.seg_desc = nullptr;
+        a.sched.slab = nullptr;
     }
-    // column slices: as few as make one slice of the dense operand fit an XCD's L2 (leaving room for the
-    // edge stream), at most 4, and only while a slice keeps >= 4 lanes (64 B) per row
+    int cs, G;
+    spmm_shape(n_rows, d, sched && sched->n_seg > 0 ? sched->nnz : -1, &cs, &G);
     const int nvec = d / 4;
-    static const int force_cs = getenv("CRH_SPMM_SLICES") ? atoi(getenv("CRH_SPMM_SLICES")) : 0;
-    int cs = 1;
-    const double bytes = (double)n_rows * d * 4;
-    if (sched && sched->n_seg > 0 && bytes > 3.0e6 && bytes <= 4 * 3.2e6) {
-        while (cs < 4 && bytes / cs > 3.2e6) cs <<= 1;
-        // every slice re-reads the edge list (8 B per edge): only worth it while that stays below the operand
-        while (cs > 1 && (double)sched->nnz * 8.0 * cs > bytes) cs >>= 1;
-    }
-    if (force_cs) cs = force_cs;
-    while (cs > 1 && (nvec % cs != 0 || nvec / cs < 4)) cs >>= 1;
-    a.cs = cs;
-    int G = 1;
-    while (G < nvec / cs && G < 64) G <<= 1;
     CRH_CHECK_ARG(G * cs == nvec || cs == 1, "%s: internal slice error", who);
-    if (G * cs != nvec) {   // d/4 not a power of two (or > 64 lanes): fall back to one slice, padded lane group
-        a.cs = 1;
-    }
+    a.cs = G * cs != nvec ? 1 : cs;   // d/4 not a power of two (or > 64 lanes): one slice, padded lane group
     CRH_CHECK_ARG(a.cs > 1 || G >= nvec, "%s: d=%d above 256 is not supported", who, d);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (G) {
@@ -344,6 +447,13 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
     }
 }
 }  // namespace
+
+extern "C" int crh_spmm_lane_group(int64_t n_rows, int d, int64_t nnz) {
+    if (n_rows <= 0 || d < 4 || d % 4) return 0;
+    int cs, G;
+    spmm_shape(n_rows, d, nnz, &cs, &G);
+    return G;
+}
 
 extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                                 const float* x, int d, float* y, const float* acc_in, float s_in,

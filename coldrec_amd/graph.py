@@ -64,7 +64,8 @@ class HipSparseAdj(torch.Tensor):
             self._dev[key] = (torch.from_numpy(m.indptr.astype(np.int64)).to(device),
                               torch.from_numpy(m.indices.astype(np.int32)).to(device),
                               torch.from_numpy(m.data.astype(np.float32)).to(device),
-                              ops.SpmmSchedule(m.indptr, device))
+                              ops.SpmmSchedule(m.indptr, device, col=m.indices.astype(np.int32),
+                                               val=m.data.astype(np.float32)))
         return self._dev[key]
 
     @classmethod

@@ -439,7 +439,7 @@ def spmm_csr_sgd(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: float
     assert p.dtype == torch.float32 and p.is_contiguous() and p.shape == (n_rows, d)
     rc = _lib.lib().crh_spmm_csr_sgd_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                          _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                         ctypes.byref(sched.c) if sched is not None else None, _lib.ptr(p), float(lr),
+                                         ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None, _lib.ptr(p), float(lr),
                                          int(bool(zero_acc_in)), _lib.current_stream())
     _lib.check(rc, "crh_spmm_csr_sgd_f32")
 
@@ -480,7 +480,7 @@ def spmm_csr_adam(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: floa
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n_rows, d)
     rc = _lib.lib().crh_spmm_csr_adam_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                           _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                          ctypes.byref(sched.c) if sched is not None else None, _lib.ptr(p),
+                                          ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None, _lib.ptr(p),
                                           _lib.ptr(m), _lib.ptr(v), float(lr), float(betas[0]), float(betas[1]),
                                           float(eps), int(step), _lib.ptr(step_scalars), int(bool(zero_acc_in)),
                                           _lib.current_stream())
@@ -495,9 +495,15 @@ class SpmmSchedule:
     each); they sit at the end of the list with seg_slot >= 0 and the light path skips them.  Rows are independent,
     so the order does not change any result."""
 
-    def __init__(self, rowptr, device, seg: Optional[int] = None):
+    SLAB_MAX_EDGES = 1 << 26          # the record stream is built for graphs up to this many stored edges
+    SLAB_BUCKETS = 12                 # CRH_SPMM_SLAB_BUCKETS of include/coldrec_hip.h
+
+    def __init__(self, rowptr, device, seg: Optional[int] = None, col=None, val=None):
+        """``col`` / ``val`` (the matrix's edge arrays, host or device): with them the schedule can also lay the light rows
+        out as a record stream (crh_spmm_sched::slab) for the lane-group width of a launch -- see ``for_launch``."""
         rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
         rp = rp.astype(np.int64)
+        self._rp, self._col, self._val, self._device, self._slabs = rp, col, val, device, {}
         deg = np.diff(rp)
         if seg is None:
             # heavy threshold: crh_spmm_segment_edges() (64) for sparse graphs; for dense ones (MovieLens shape: mean
@@ -541,6 +547,57 @@ class SpmmSchedule:
         self.n_partial = int(multi_first[-1])
         self.n_seg = len(seg_row)
         self._ws = {}
+        self._light = order[~heavy[order]].astype(np.int64)        # light rows in work-item order (descending length)
+
+    def _build_slab(self, G: int):
+        """The light rows as a stream of (col, val-bits) pairs for lane groups of G lanes: record = header pair {row, cnt}
+        + the edges in order, padded to whole units of G pairs; rows are in descending length, so equal unit counts are
+        contiguous buckets.  Returns (stream tensor, first, units, base) or None when it does not apply."""
+        if self._col is None or self._val is None or G < 8 or int(self._rp[-1]) > self.SLAB_MAX_EDGES:
+            return None
+        rows = self._light
+        deg = (self._rp[rows + 1] - self._rp[rows]).astype(np.int64)
+        units = np.where(deg <= G - 1, 1, 1 + (deg - (G - 1) + G - 1) // G)
+        cuts = np.nonzero(np.diff(units))[0] + 1 if len(units) else np.zeros(0, np.int64)
+        first = np.concatenate([[0], cuts]).astype(np.int64) if len(units) else np.zeros(0, np.int64)
+        if len(first) > self.SLAB_BUCKETS or len(rows) >= (1 << 31) - 1:
+            return None
+        start = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum(units * G, out=start[1:])
+        n_pairs = int(start[-1]) + 2 * G                                   # tail: a one-unit record's second-unit read
+        col = self._col.cpu().numpy() if torch.is_tensor(self._col) else np.asarray(self._col)
+        val = self._val.cpu().numpy() if torch.is_tensor(self._val) else np.asarray(self._val)
+        stream = np.zeros((n_pairs, 2), np.uint32)
+        stream[start[:-1], 0] = rows.astype(np.uint32)
+        stream[start[:-1], 1] = deg.astype(np.uint32)
+        tot = int(deg.sum())
+        if tot:
+            within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(deg) - deg, deg)
+            dst = np.repeat(start[:-1] + 1, deg) + within
+            src = np.repeat(self._rp[rows], deg) + within
+            stream[dst, 0] = col[src].astype(np.uint32)
+            stream[dst, 1] = np.ascontiguousarray(val[src], np.float32).view(np.uint32)
+        return (torch.from_numpy(stream.view(np.int32)).to(self._device), first, units[first] if len(first) else first,
+                start[first] if len(first) else first)
+
+    def for_launch(self, n_rows: int, d: int):
+        """Point the C struct at the record stream laid out for THIS launch's lane-group width (built once per width);
+        without edge arrays, or where the stream does not apply, the launch takes the descriptor path."""
+        c = self.c
+        G = int(_lib.lib().crh_spmm_lane_group(int(n_rows), int(d), int(self._rp[-1]))) if self._col is not None else 0
+        if G not in self._slabs:
+            self._slabs[G] = self._build_slab(G) if G else None
+        slab = self._slabs[G]
+        if slab is None:
+            c.slab, c.slab_lanes, c.slab_buckets, c.n_slab = None, 0, 0, 0
+            return c
+        stream, first, units, base = slab
+        c.slab, c.slab_lanes, c.slab_buckets, c.n_slab = _lib.ptr(stream), G, len(first), len(self._light)
+        for b in range(self.SLAB_BUCKETS):
+            c.slab_first[b] = int(first[b]) if b < len(first) else 0x7fffffff
+            c.slab_units[b] = int(units[b]) if b < len(first) else 1
+            c.slab_base[b] = int(base[b]) if b < len(first) else 0
+        return c
 
     def workspace(self, d: int, device) -> Optional[torch.Tensor]:
         """Heavy rows are combined on chip: crh_spmm_workspace_bytes() is 0 and no scratch is needed."""
@@ -557,7 +614,7 @@ def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_ou
     ws = sched.workspace(d, x.device) if sched is not None else None
     rc = _lib.lib().crh_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                      _lib.ptr(y), _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                     ctypes.byref(sched.c) if sched is not None else None,
+                                     ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None,
                                      _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0,
                                      _lib.current_stream())
     _lib.check(rc, "crh_spmm_csr_f32")

@@ -315,7 +315,7 @@ class LGCNEngine(_TableState):
         self.col = torch.as_tensor(np.asarray(col, np.int32)).to(dev)
         self.val = torch.as_tensor(np.asarray(val, np.float32)).to(dev)
         assert self.rowptr.shape[0] == self.E.shape[0] + 1
-        self.sched = self.k.SpmmSchedule(np.asarray(rowptr), dev)
+        self.sched = self.k.SpmmSchedule(np.asarray(rowptr), dev, col=np.asarray(col), val=np.asarray(val))
         self.X = [torch.empty_like(self.E) for _ in range(2)]   # layer ping-pong
         self.OUT = torch.empty_like(self.E)                     # mean of the layer outputs
         self.dOUT = torch.zeros_like(self.E)
@@ -335,7 +335,7 @@ class LGCNEngine(_TableState):
         assert rowptr.shape[0] == E.shape[0] + 1
         self.L = int(n_layers)
         self.rowptr, self.col, self.val = rowptr.contiguous(), col.contiguous(), val.contiguous()
-        self.sched = self.k.SpmmSchedule(self.rowptr.cpu().numpy(), self.device, seg=seg)
+        self.sched = self.k.SpmmSchedule(self.rowptr.cpu().numpy(), self.device, seg=seg, col=self.col, val=self.val)
         self.X = [torch.empty_like(self.E) for _ in range(2)]
         self.OUT = torch.empty_like(self.E)
         self.dOUT = torch.zeros_like(self.E)
@@ -369,7 +369,8 @@ class LGCNEngine(_TableState):
         # the heavy-row threshold of the FULL graph: a row block of a bipartite graph (all user rows / all item rows) can
         # have a mean degree on the other side of the automatic rule, and a row summed as "heavy" on one engine and
         # "light" on the other would differ in its fp32 association
-        self.rs_sched = self.k.SpmmSchedule(self.rs_rowptr.cpu().numpy(), dev, seg=self.sched.seg) if r1 > r0 else None
+        self.rs_sched = self.k.SpmmSchedule(self.rs_rowptr.cpu().numpy(), dev, seg=self.sched.seg, col=self.rs_col,
+                                             val=self.rs_val) if r1 > r0 else None
         self.rs = (rows, r0, r1)
         pad = G * rows
         E_pad = torch.zeros((pad, d), dtype=torch.float32, device=dev)     # E becomes a view of the gather target

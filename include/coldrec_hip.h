@@ -252,6 +252,7 @@ int crh_adam_rows_f32(float* p, float* g, float* m, float* v, int32_t* last_step
  * workspace: unused since the heavy rows are combined on chip (crh_spmm_workspace_bytes returns 0).
  * Without a schedule one lane group walks each row (bit-identical to the edge-order fma chain).
  */
+#define CRH_SPMM_SLAB_BUCKETS 12
 typedef struct {
     const int32_t* seg_row;
     const int64_t* seg_ptr;
@@ -266,8 +267,26 @@ typedef struct {
     /* optional (NULL = absent): seg_desc[w] = {row, first edge, edges, slot} as four int32 -- the work item, its edge
      * range and its class in ONE 16-byte load instead of three dependent ones (needs nnz < 2^31) */
     const int32_t* seg_desc;
+    /* optional (NULL = absent), round 3: the light rows as a STREAM of 8-byte pairs in work-item order.  Record of a row
+     * with cnt edges: pair 0 = {row, cnt}, pairs 1.. = {col, fp32 bits of val} in edge order, padded with {0, 0} to
+     * `units` units of slab_lanes pairs (units = 1 for cnt <= slab_lanes - 1, else 1 + ceil((cnt - (slab_lanes - 1)) /
+     * slab_lanes)).  Work items are ordered by descending length, so the records of one unit count are contiguous
+     * ("bucket" b: work items slab_first[b] .. slab_first[b + 1] - 1, units slab_units[b], first pair slab_base[b]) and
+     * the address of a record is arithmetic: the dependent chain of a row is {record} -> {gathers} -> {store} instead of
+     * {descriptor} -> {edge list} -> {gathers} -> ...  Used when slab_lanes equals the launch's lanes per lane group
+     * (crh_spmm_lane_group); the stream must be followed by 2 * slab_lanes readable pairs.  n_slab = light work items. */
+    const void* slab;
+    int32_t slab_lanes;
+    int32_t slab_buckets;
+    int64_t n_slab;
+    int32_t slab_first[CRH_SPMM_SLAB_BUCKETS];
+    int32_t slab_units[CRH_SPMM_SLAB_BUCKETS];
+    int64_t slab_base[CRH_SPMM_SLAB_BUCKETS];
 } crh_spmm_sched;
 int crh_spmm_segment_edges(void);
+/* lanes per lane group (16 bytes of a row each) the SpMM launches use for an n_rows x d operand and nnz stored edges under
+ * a schedule: d / 4 / (column slices), a power of two -- what a caller needs to lay out crh_spmm_sched::slab */
+int crh_spmm_lane_group(int64_t n_rows, int d, int64_t nnz);
 size_t crh_spmm_workspace_bytes(const crh_spmm_sched* sched, int d);
 int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                      const float* x, int d, float* y, const float* acc_in, float s_in,

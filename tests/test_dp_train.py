@@ -25,7 +25,7 @@ class NpKernels:
     """CPU stand-ins with the signatures of coldrec_amd.ops (tests only), assigned to coldrec_amd.train.ops below."""
 
     class SpmmSchedule:
-        def __init__(self, rowptr, device, seg=None):
+        def __init__(self, rowptr, device, seg=None, col=None, val=None):
             self.seg = 64 if seg is None else seg
 
     @staticmethod

@@ -318,6 +318,49 @@ def test_spmm_segment_schedule_on_skewed_graph(monkeypatch, giant):
     np.testing.assert_allclose(Yn.cpu().numpy()[~one], wn[~one], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("d", [32, 64, 128, 200, 256])
+def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, d):
+    """Round 3: with the edge arrays at hand the schedule lays the light rows out as a record stream
+    (crh_spmm_sched::slab: header + edges in whole units of G pairs, buckets by unit count, arithmetic record addresses)
+    for the launch's lane-group width G (8, 16, 32, 64 here; d = 200: a padded lane group).  Same bits as the descriptor
+    path and as the oracle's edge-order chain on every light row -- rows of 0, G - 2, G - 1, G, 2G - 1 and 64 edges
+    included -- with the fused layer sum and with the optimiser epilogue."""
+    from coldrec_amd import _lib, ops
+    rng = np.random.default_rng(d)
+    n = 3000
+    G = int(_lib.lib().crh_spmm_lane_group(n, d, 1))
+    want_deg = np.concatenate([[0, 1, G - 2, G - 1, G, G + 1, 2 * G - 1, 2 * G, 63, 64, 65, 300, 1500],
+                               rng.integers(0, 40, n - 13)])
+    rowptr = np.concatenate([[0], np.cumsum(want_deg)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in want_deg]).astype(np.int32)
+    val = rng.standard_normal(len(col)).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Z = rng.standard_normal((n, d)).astype(np.float32)
+    tX, tZ, rp, cl, vl = t(X), t(Z), t(rowptr), t(col), t(val)
+    plain = ops.SpmmSchedule(rowptr, DEV)                               # no edge arrays: descriptor path
+    slab = ops.SpmmSchedule(rowptr, DEV, col=col, val=val)
+    assert slab.for_launch(n, d).slab and slab.for_launch(n, d).slab_lanes == G and not plain.for_launch(n, d).slab
+    outs = []
+    for sc in (plain, slab):
+        Y, A = torch.empty_like(tX), torch.empty_like(tX)
+        ops.spmm_csr(rp, cl, vl, tX, y=Y, acc_in=tZ, s_in=0.5, acc_out=A, s_out=0.25, sched=sc)
+        P, M, V = tX.clone(), torch.zeros_like(tX), torch.zeros_like(tX)
+        Zc = tZ.clone()
+        ops.spmm_csr_adam(rp, cl, vl, tX, Zc, 1.0, None, 0.25, sc, P, M, V, 3, lr=1e-2, zero_acc_in=True)
+        outs.append((Y, A, P, M, V, Zc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    want = orc.spmm(rowptr, col, val, X)
+    light = want_deg <= plain.seg
+    np.testing.assert_array_equal(outs[1][0].cpu().numpy()[light], want[light])
+    np.testing.assert_allclose(outs[1][0].cpu().numpy()[~light], want[~light], rtol=1e-5, atol=2e-4)   # sums of up to 1500 N(0,1) products
+    monkeypatch.setenv("CRH_SPMM_GIANT", "0")                           # and under another heavy-row layout
+    again = ops.SpmmSchedule(rowptr, DEV, col=col, val=val)
+    Y2 = torch.empty_like(tX)
+    ops.spmm_csr(rp, cl, vl, tX, y=Y2, sched=again)
+    np.testing.assert_array_equal(Y2.cpu().numpy()[light], want[light])
+
+
 def test_lgcn_forward_golden_g5_and_training():
     from coldrec_amd.train import LGCNEngine
     g5 = load_golden("g5_lgcn.npz")

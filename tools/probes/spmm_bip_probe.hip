@@ -794,7 +794,7 @@ int main(int argc, char** argv) {
             });
         }
     }
-    if (0) {
+    if (getenv("RUN_OCT")) {
     // ---- octet stream: byte offsets, padded units, buckets padded to whole octets
     std::vector<uint2> ostream;
     OctArgs oa{};
@@ -873,7 +873,7 @@ int main(int argc, char** argv) {
     run_oct("octet R2 occ6 no heavy", 2, 8, 6);
     run_oct("octet R2 occ6 no heavy no stores no acc_in", 2, 11, 6);
     run_oct("octet R2 occ6 no light", 2, 16, 6);
-    if (0)
+    if (getenv("RUN_SLAB"))
     for (int occ : {6, 4}) {
         printf("---- occupancy target %d waves / SIMD\n", occ);
         run_slab("slab R1 PF2", 1, 2, 0, occ);
