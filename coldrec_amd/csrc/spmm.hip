@@ -62,40 +62,53 @@ __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
     acc.w = fmaf(v, x.w, acc.w);
 }
 
-__device__ __forceinline__ void store_row_z(const SpmmArgs& a, int64_t o, const f32x4& acc, f32x4 z);
+// What a row's epilogue reads, requested EARLY by the record path (before the gathers) so that the loads are in flight
+// beside them: the row's acc_in and, with the optimiser in the epilogue, its p / m / v.
+struct RowPre {
+    f32x4 z, p, m, v;
+};
 
-__device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if ((a.acc_out || a.adam_p) && a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
-    store_row_z(a, o, acc, z);
+__device__ __forceinline__ RowPre row_prefetch(const SpmmArgs& a, int64_t o, bool live) {
+    RowPre r;
+    r.z = r.p = r.m = r.v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!live) return r;
+    if ((a.acc_out || a.adam_p) && a.acc_in) r.z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
+    if (a.adam_p) {
+        r.p = *reinterpret_cast<const f32x4*>(a.adam_p + o);
+        if (!a.sgd) {
+            r.m = *reinterpret_cast<const f32x4*>(a.adam_m + o);
+            r.v = *reinterpret_cast<const f32x4*>(a.adam_v + o);
+        }
+    }
+    return r;
 }
 
-// z = the row's acc_in (zeros without one), already loaded: the record path requests it before the gathers
-__device__ __forceinline__ void store_row_z(const SpmmArgs& a, int64_t o, const f32x4& acc, f32x4 z) {
+__device__ __forceinline__ void store_row_pre(const SpmmArgs& a, int64_t o, const f32x4& acc, RowPre q) {
     if (a.Y) *reinterpret_cast<f32x4*>(a.Y + o) = acc;
     if (a.acc_out || a.adam_p) {
         f32x4 r;
-        r.x = (z.x * a.s_in + acc.x) * a.s_out;
-        r.y = (z.y * a.s_in + acc.y) * a.s_out;
-        r.z = (z.z * a.s_in + acc.z) * a.s_out;
-        r.w = (z.w * a.s_in + acc.w) * a.s_out;
+        r.x = (q.z.x * a.s_in + acc.x) * a.s_out;
+        r.y = (q.z.y * a.s_in + acc.y) * a.s_out;
+        r.z = (q.z.z * a.s_in + acc.z) * a.s_out;
+        r.w = (q.z.w * a.s_in + acc.w) * a.s_out;
         if (a.acc_out) *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
         if (a.adam_p && a.sgd) {
-            f32x4 p = *reinterpret_cast<const f32x4*>(a.adam_p + o);
-            sgd_elem4(p, r, a.neg_step_size);
-            *reinterpret_cast<f32x4*>(a.adam_p + o) = p;
+            sgd_elem4(q.p, r, a.neg_step_size);
+            *reinterpret_cast<f32x4*>(a.adam_p + o) = q.p;
         } else if (a.adam_p) {
-            f32x4 p = *reinterpret_cast<const f32x4*>(a.adam_p + o), m = *reinterpret_cast<const f32x4*>(a.adam_m + o);
-            f32x4 v = *reinterpret_cast<const f32x4*>(a.adam_v + o);
             const float b2s = a.step_scalars ? a.step_scalars[0] : a.bc2_sqrt;
             const float nss = a.step_scalars ? a.step_scalars[1] : a.neg_step_size;
-            adam_elem4(p, m, v, r, a.k, b2s, nss);
-            *reinterpret_cast<f32x4*>(a.adam_p + o) = p;
-            *reinterpret_cast<f32x4*>(a.adam_m + o) = m;
-            *reinterpret_cast<f32x4*>(a.adam_v + o) = v;
+            adam_elem4(q.p, q.m, q.v, r, a.k, b2s, nss);
+            *reinterpret_cast<f32x4*>(a.adam_p + o) = q.p;
+            *reinterpret_cast<f32x4*>(a.adam_m + o) = q.m;
+            *reinterpret_cast<f32x4*>(a.adam_v + o) = q.v;
         }
         if (a.zero_acc_in && a.acc_in) *reinterpret_cast<f32x4*>(a.acc_in + o) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+
+__device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc) {
+    store_row_pre(a, o, acc, row_prefetch(a, o, true));
 }
 
 // Accumulate edges [e0, e1) of one row into acc for this lane's 16-B column slice, in edge order.
@@ -220,8 +233,7 @@ __device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c,
     const int64_t row = __shfl((int)u0.x, 0, G);
     const int cnt = un > 0 ? __shfl((int)u0.y, 0, G) : 0;
     const int64_t o = row * a.d + (int64_t)c * 4;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (un > 0 && on && (a.acc_out || a.adam_p) && a.acc_in) z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
+    const RowPre pre = row_prefetch(a, o, un > 0 && on);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     slab_unit<G, 1>(a, u0, -1, cnt, c, on, acc);
     if (mu > 1) {
@@ -233,7 +245,7 @@ __device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c,
             cur = nxt;
         }
     }
-    if (un > 0 && on) store_row_z(a, o, acc, z);
+    if (un > 0 && on) store_row_pre(a, o, acc, pre);
 }
 
 // One heavy row (more than the schedule's segment length of edges) by a whole workgroup: its 256 / GG lane groups of GG
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     if (j >= heavy_blocks) {
         const int64_t jl = j - heavy_blocks;
         if (jl >= a.light_blocks || (CRH_ABLATE(a.skip) & 2)) return;
-        if constexpr (G >= 8) {
+        if constexpr (G == 8) {       // (wider lane groups: 16 - 32 gathers of a unit in flight cost the kernel its occupancy)
             if (a.use_slab) {
                 slab_light<G>(a, jl, c, on, lig);
                 return;
@@ -357,7 +369,7 @@ int launch_spmm(SpmmArgs a, hipStream_t st) {
     const int64_t heavy_blocks = a.sched.n_seg > 0 ? (int64_t)a.sched.n_multi : 0;
     const int rows_per_group = force_rows > 0 ? force_rows : 1;
     static const int no_slab = getenv("CRH_SPMM_SLAB") ? !atoi(getenv("CRH_SPMM_SLAB")) : 0;
-    a.use_slab = !no_slab && G >= 8 && a.sched.n_seg > 0 && a.sched.slab && a.sched.slab_lanes == G && a.sched.n_slab >= 0;
+    a.use_slab = !no_slab && G == 8 && a.sched.n_seg > 0 && a.sched.slab && a.sched.slab_lanes == G && a.sched.n_slab >= 0;
     const int64_t per_block = a.use_slab ? (256 / G) : (256 / G) * rows_per_group;
     a.light_blocks = ((a.use_slab ? (int64_t)a.sched.n_slab : n_work) + per_block - 1) / per_block;
     const int64_t per_slice = a.light_blocks + heavy_blocks;

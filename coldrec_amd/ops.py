@@ -553,7 +553,7 @@ class SpmmSchedule:
         """The light rows as a stream of (col, val-bits) pairs for lane groups of G lanes: record = header pair {row, cnt}
         + the edges in order, padded to whole units of G pairs; rows are in descending length, so equal unit counts are
         contiguous buckets.  Returns (stream tensor, first, units, base) or None when it does not apply."""
-        if self._col is None or self._val is None or G < 8 or int(self._rp[-1]) > self.SLAB_MAX_EDGES:
+        if self._col is None or self._val is None or G != 8 or int(self._rp[-1]) > self.SLAB_MAX_EDGES:    # (kernel: G == 8 only)
             return None
         rows = self._light
         deg = (self._rp[rows + 1] - self._rp[rows]).astype(np.int64)

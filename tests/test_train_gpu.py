@@ -318,20 +318,20 @@ def test_spmm_segment_schedule_on_skewed_graph(monkeypatch, giant):
     np.testing.assert_allclose(Yn.cpu().numpy()[~one], wn[~one], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("d", [32, 64, 128, 200, 256])
-def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, d):
+@pytest.mark.parametrize("n,d", [(3000, 32), (16000, 128), (3000, 64), (3000, 200)])
+def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, n, d):
     """Round 3: with the edge arrays at hand the schedule lays the light rows out as a record stream
     (crh_spmm_sched::slab: header + edges in whole units of G pairs, buckets by unit count, arithmetic record addresses)
-    for the launch's lane-group width G (8, 16, 32, 64 here; d = 200: a padded lane group).  Same bits as the descriptor
-    path and as the oracle's edge-order chain on every light row -- rows of 0, G - 2, G - 1, G, 2G - 1 and 64 edges
-    included -- with the fused layer sum and with the optimiser epilogue."""
+    for launches whose lane groups have G = 8 lanes -- d = 32 unsliced, d = 128 in four XCD-pinned column slices (the
+    CiteULike-sized LightGCN); other widths (d = 64: G = 16, d = 200: a padded group of 64) keep the descriptor path.
+    Same bits as the descriptor path and as the oracle's edge-order chain on every light row -- rows of 0, G - 2, G - 1,
+    G, 2G - 1 and 64 edges included -- with the fused layer sum and with the optimiser epilogue."""
     from coldrec_amd import _lib, ops
     rng = np.random.default_rng(d)
-    n = 3000
-    G = int(_lib.lib().crh_spmm_lane_group(n, d, 1))
-    want_deg = np.concatenate([[0, 1, G - 2, G - 1, G, G + 1, 2 * G - 1, 2 * G, 63, 64, 65, 300, 1500],
-                               rng.integers(0, 40, n - 13)])
+    want_deg = np.concatenate([[0, 1, 6, 7, 8, 9, 15, 16, 63, 64, 65, 300, 1500], rng.integers(0, 25, n - 13)])
     rowptr = np.concatenate([[0], np.cumsum(want_deg)]).astype(np.int64)
+    G = int(_lib.lib().crh_spmm_lane_group(n, d, int(rowptr[-1])))
+    assert G == {32: 8, 128: 8, 64: 16, 200: 64}[d]
     col = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in want_deg]).astype(np.int32)
     val = rng.standard_normal(len(col)).astype(np.float32)
     X = rng.standard_normal((n, d)).astype(np.float32)
@@ -339,7 +339,11 @@ def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, 
     tX, tZ, rp, cl, vl = t(X), t(Z), t(rowptr), t(col), t(val)
     plain = ops.SpmmSchedule(rowptr, DEV)                               # no edge arrays: descriptor path
     slab = ops.SpmmSchedule(rowptr, DEV, col=col, val=val)
-    assert slab.for_launch(n, d).slab and slab.for_launch(n, d).slab_lanes == G and not plain.for_launch(n, d).slab
+    assert not plain.for_launch(n, d).slab
+    if G == 8:
+        assert slab.for_launch(n, d).slab and slab.for_launch(n, d).slab_lanes == 8
+    else:
+        assert not slab.for_launch(n, d).slab
     outs = []
     for sc in (plain, slab):
         Y, A = torch.empty_like(tX), torch.empty_like(tX)
