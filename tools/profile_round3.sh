@@ -43,6 +43,14 @@ $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/xl_write" -- python3 bench
 python3 tools/prof_summary.py "${TAG}_xl_lightgcn" "$OUT/xl_stats" "$OUT/xl_fetch" "$OUT/xl_write" > "$OUT/summary_xl.txt" 2>&1
 rm -rf "$OUT/xl_stats" "$OUT/xl_fetch" "$OUT/xl_write"
 echo "xl passes done after $SECONDS s"
+# S-TRAIN-XL BPR-MF step (dense Adam): the traffic figure of the `train_xl` leg on THIS build
+MX="--train-xl --steps 4 --warmup 1"
+$T rocprofv3 --kernel-trace --stats -d "$OUT/mx_stats" -- python3 bench.py $MX > "$OUT/mx_under_stats.json" 2> "$OUT/mx_stats.err"
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/mx_fetch" -- python3 bench.py $MX > /dev/null 2> "$OUT/mx_fetch.err"
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/mx_write" -- python3 bench.py $MX > /dev/null 2> "$OUT/mx_write.err"
+python3 tools/prof_summary.py "${TAG}_train_xl" "$OUT/mx_stats" "$OUT/mx_fetch" "$OUT/mx_write" > "$OUT/summary_mx.txt" 2>&1
+rm -rf "$OUT/mx_stats" "$OUT/mx_fetch" "$OUT/mx_write"
+echo "train-xl passes done after $SECONDS s"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null
 cp "$OUT/xl_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_xl_lightgcn_bench_under_rocprof.json
 cp "$OUT/bench_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_eval_bench_under_rocprof.json
