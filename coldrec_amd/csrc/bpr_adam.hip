@@ -974,7 +974,13 @@ int dispatch_group(int g, F&& f) {
 // in batch b.  A row then costs three round trips: {range, mult, p, m, v} -> entries -> gathered rows.
 // Heavy rows (more than BPR_HEAVY entries) are done by the extra blocks, one block per row, exactly as before.
 // Deterministic: no atomics, fixed summation orders.  d <= 256, batch < 32768.
-constexpr int MF_MAX_LIGHT = 2048, MF_HEAVY_BLOCKS = 96, MF_ROWS = 2;
+#ifndef MF_HEAVY_BLOCKS_N
+#define MF_HEAVY_BLOCKS_N 96
+#endif
+#ifndef MF_ROWS_N
+#define MF_ROWS_N 2
+#endif
+constexpr int MF_MAX_LIGHT = 2048, MF_HEAVY_BLOCKS = MF_HEAVY_BLOCKS_N, MF_ROWS = MF_ROWS_N;     // (tuning builds: -D..._N)
 
 struct MfStepArgs {
     const float* pin;      // (U + I, d) parameters before the step, users first
@@ -999,8 +1005,12 @@ struct MfStepArgs {
     const float* step_scalars;
     float neg_lr;          // SGD variant (OPT = 1): p <- fma(-lr, g, p); m, v, step_scalars unused
     int light_blocks;
-    int ablate;            // measurement only (CRH_MF_ABLATE): 1 no entries, 2 no batch sums, 4 no norms, 8 no stores
-};
+    int ablate;            // measurement only (CRH_MF_ABLATE): 1 no entries, 2 no batch sums, 4 no norms, 8 no stores,
+};                         // 16 per-block clocks of the launch -> crh_profile_mf_clocks (profile build only)
+
+#ifdef CRH_PROFILE
+__device__ unsigned long long crh_mf_clk[2 * 4096];   // [block]{start, end} of s_memrealtime (100 MHz), last launch
+#endif
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 #pragma clang fp contract(off)      // the same bits wherever a score difference is recomputed
@@ -1123,6 +1133,9 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     __shared__ f32x4 red4[4];
     __shared__ float red[4];
     __shared__ f32x4 wsum[4][G];
+#ifdef CRH_PROFILE
+    if ((a.ablate & 16) && threadIdx.x == 0 && blockIdx.x < 4096) crh_mf_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lig = threadIdx.x % G;
     const bool on = lig < (a.d >> 2);
     const int64_t R = a.U + a.I;
@@ -1259,8 +1272,18 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     if (threadIdx.x == 0) {
         float* o = a.part_out + (size_t)blockIdx.x * 4;
         o[0] = su; o[1] = sp; o[2] = sn; o[3] = sl;
+#ifdef CRH_PROFILE
+        if ((a.ablate & 16) && blockIdx.x < 4096) crh_mf_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
+
+#ifdef CRH_PROFILE
+// profile build only (not part of the ABI): the per-block clocks of the last mf_step launch
+extern "C" int crh_profile_mf_clocks(unsigned long long* out_host, int n_blocks) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(crh_mf_clk), (size_t)n_blocks * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Flatten the plans of an epoch for mf_step_kernel (grid.y = batch): per table row its entry range and its
 // multiplicities, per entry the two other rows of the triple.  range / mult must be zero on entry.

@@ -116,6 +116,13 @@ def case_spmm(rng):
     a_want = (Z.astype(np.float64) * 0.5 + p64) * 2.0
     if not np.all(np.abs(A1.cpu().numpy() - a_want) <= 2 * bound + 1e-6 * (np.abs(a_want) + np.abs(Z))):
         fail("spmm epilogue", d=d)
+    # round 3: the same launch with the light rows taken from the schedule's record stream (built when the edge arrays are
+    # at hand; used for 8-lane groups, i.e. d = 32 or a sliced d = 128): every bit must agree with the descriptor path
+    slab = ops.SpmmSchedule(rowptr, DEV, col=col, val=val)
+    Y2, A2 = torch.empty_like(tX), torch.empty_like(tX)
+    ops.spmm_csr(rp, cl, vl, tX, y=Y2, acc_in=tZ, s_in=0.5, acc_out=A2, s_out=2.0, sched=slab)
+    if not (torch.equal(Y1, Y2) and torch.equal(A1, A2)):
+        fail("spmm record stream != descriptor path", d=d, n=n_u + n_i, slab=bool(slab.for_launch(n_u + n_i, d).slab))
 
 
 def case_adam(rng):
