@@ -997,6 +997,8 @@ struct MfStepArgs {
     const int32_t* mult2;  // (U + I) multiplicities in the NEXT batch: user rows count, item rows pos | neg << 16; or NULL
     const float* part_in;  // [n_in][4]: norms^2 of THIS batch (u, p, n) and the loss sum of the PREVIOUS one
     int n_in;
+    const float* part_in2; // optional second source, summed with the first (gradient-only variant: the norms come from the
+    int n_in2;             // last forward SpMM's workgroups, the previous batch's loss from the previous gradient launch)
     float* part_out;       // [gridDim.x][4]: norms^2 of the NEXT batch, loss sum of THIS one
     float* loss_prev;      // [2] of the previous step (its bpr is known only now) or NULL
     float inv_b_prev;
@@ -1101,8 +1103,12 @@ __device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoe
 template <int G, int OPT>
 __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, bool on, int lig, f32x4 p, f32x4 m, f32x4 v,
                                               const f32x4& grad, int mult, float bc2_sqrt, float nss, float& su, float& sp,
-                                              float& sn) {
+                                              float& sn, bool touched = true) {
     const int64_t o = row * a.d + lig * 4;
+    if constexpr (OPT == 2) {          // gradient only: the row of d(loss)/d(table) goes to `pout`; untouched rows stay as they are
+        if (on && touched) *reinterpret_cast<f32x4*>(a.pout + o) = grad;
+        return;
+    }
     if (on) {
         if constexpr (OPT == 0) adam_elem4(p, m, v, grad, a.k, bc2_sqrt, nss);
         else sgd_elem4(p, grad, a.neg_lr);
@@ -1168,6 +1174,10 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
             const f32x4 x = reinterpret_cast<const f32x4*>(a.part_in)[i];
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
+        for (int i = threadIdx.x; i < a.n_in2; i += BPR_THREADS) {
+            const f32x4 x = reinterpret_cast<const f32x4*>(a.part_in2)[i];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             s.x += __shfl_xor(s.x, off); s.y += __shfl_xor(s.y, off);
@@ -1218,7 +1228,7 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
             float loss = 0.f;
             if (rg.y > rg.x) mf_row_entries<G>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
             if (lig == 0) sl += loss;
-            mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn);
+            mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn, rg.y > rg.x);
         }
     } else {
         const PlanView pv = plan_view(a.plan);
@@ -1777,9 +1787,10 @@ int mf_step_run(const char* who, int opt, const float* table_in, float* table_ou
                 int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan, const int32_t* range,
                 const int32_t* entries, const int32_t* mult_next, const float* part_in, int n_parts_in, float* part_out,
                 float* loss_prev_out, int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
-                const float* step_scalars, double lr, void* stream) {
+                const float* step_scalars, double lr, void* stream, const float* part_in2 = nullptr, int n_parts_in2 = 0) {
     CRH_CHECK_ARG(table_in && table_out && table_in != table_out, "%s: NULL / aliased tables", who);
-    CRH_CHECK_ARG(opt == 1 || (m && v && step_scalars), "%s: NULL optimiser state / step scalars", who);
+    CRH_CHECK_ARG(opt != 0 || (m && v && step_scalars), "%s: NULL optimiser state / step scalars", who);
+    CRH_CHECK_ARG(n_parts_in2 == 0 || part_in2, "%s: NULL second partial-sum source", who);
     CRH_CHECK_ARG(user_rows > 0 && item_rows > 0 && batch > 0, "%s: empty table or batch", who);
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "%s: d=%d must be a multiple of 4, at most 256", who, d);
     CRH_CHECK_ARG(plan && range && entries, "%s: NULL plan / step tables", who);
@@ -1796,6 +1807,7 @@ int mf_step_run(const char* who, int opt, const float* table_in, float* table_ou
     a.entries = reinterpret_cast<const int2*>(entries);
     a.mult2 = mult_next;
     a.part_in = part_in; a.n_in = n_parts_in; a.part_out = part_out;
+    a.part_in2 = part_in2; a.n_in2 = n_parts_in2;
     a.loss_prev = loss_prev_out; a.inv_b_prev = loss_prev_out ? 1.0f / (float)batch_prev : 0.f;
     a.loss_now = loss_out;
     a.k = AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
@@ -1808,7 +1820,8 @@ int mf_step_run(const char* who, int opt, const float* table_in, float* table_ou
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dispatch_group(pick_group(d), [&](auto gc) -> int {
         constexpr int GG = decltype(gc)::value;
-        if (opt == 1) hipLaunchKernelGGL((mf_step_kernel<GG, 1>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        if (opt == 2) hipLaunchKernelGGL((mf_step_kernel<GG, 2>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        else if (opt == 1) hipLaunchKernelGGL((mf_step_kernel<GG, 1>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         else hipLaunchKernelGGL((mf_step_kernel<GG, 0>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         CRH_HIP(hipGetLastError());
         return CRH_OK;
@@ -1837,6 +1850,23 @@ extern "C" int crh_mf_step_sgd_f32(const float* table_in, float* table_out, int6
     return mf_step_run("crh_mf_step_sgd_f32", 1, table_in, table_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
                        plan, range, entries, mult_next, part_in, n_parts_in, part_out, loss_prev_out, batch_prev, loss_out,
                        0.9, 0.999, 1e-8, nullptr, lr, stream);
+}
+
+// The gradient half of that step alone (LightGCN, model/LightGCN.py:23-26: the tables are the PROPAGATED embeddings, the
+// optimiser acts on the raw ones after the backward propagation): d(bpr_loss + l2_reg_loss)/d(table) row by row into
+// `grad_out` -- rows the batch does not touch are left as they are (keep them zero) -- with the score differences
+// recomputed from the gathered rows, so no forward pass over the batch exists any more: the three batch norms arrive as
+// partial sums from the launch that produced the table (crh_spmm_csr_norms_f32: norm_part / n_norm_parts), the previous
+// batch's loss sum from the previous call of this function (loss_part_prev / n_loss_parts_prev, or NULL / 0);
+// part_out[crh_mf_step_parts(rows, d)][4] receives this batch's loss sum in component 3.
+extern "C" int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows, int64_t item_rows, int d,
+                                     int64_t batch, float reg, const int32_t* plan, const int32_t* range,
+                                     const int32_t* entries, const float* norm_part, int n_norm_parts,
+                                     const float* loss_part_prev, int n_loss_parts_prev, float* part_out,
+                                     float* loss_prev_out, int64_t batch_prev, float* loss_out, void* stream) {
+    return mf_step_run("crh_bpr_grad_rows_f32", 2, table, grad_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
+                       plan, range, entries, nullptr, norm_part, n_norm_parts, part_out, loss_prev_out, batch_prev, loss_out,
+                       0.9, 0.999, 1e-8, nullptr, 0.0, stream, loss_part_prev, n_loss_parts_prev);
 }
 
 // bpr loss of the LAST step of an epoch from its partial sums.

@@ -370,6 +370,22 @@ def mf_step(table_in, table_out, m, v, user_rows: int, batch: int, reg: float, p
     _lib.check(rc, "crh_mf_step_f32")
 
 
+def bpr_grad_rows(table, grad_out, user_rows: int, batch: int, reg: float, plan, rng, entries, norm_part,
+                  n_norm_parts: int, loss_part_prev, n_loss_parts_prev: int, part_out, loss_prev, batch_prev: int,
+                  loss_out) -> None:
+    """d(bpr_loss + l2_reg_loss)/d(table) of one batch, row by row into ``grad_out`` (touched rows only), score differences
+    recomputed, batch norms from the partial sums of the launch that produced ``table`` (crh_bpr_grad_rows_f32)."""
+    _need_cuda(table, grad_out, plan, rng, entries, norm_part, part_out)
+    R, d = table.shape
+    assert table.dtype == torch.float32 and table.is_contiguous() and grad_out.shape == table.shape and grad_out.is_contiguous()
+    assert rng.shape == (R, 2) and rng.dtype == torch.int32 and entries.dtype == torch.int32
+    _lib.check(_lib.lib().crh_bpr_grad_rows_f32(
+        _lib.ptr(table), _lib.ptr(grad_out), int(user_rows), R - int(user_rows), d, int(batch), float(reg), _lib.ptr(plan),
+        _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(norm_part), int(n_norm_parts), _lib.ptr(loss_part_prev),
+        int(n_loss_parts_prev), _lib.ptr(part_out), _lib.ptr(loss_prev), int(batch_prev), _lib.ptr(loss_out),
+        _lib.current_stream()), "crh_bpr_grad_rows_f32")
+
+
 def mf_step_finish(part_in, n_parts_in: int, batch: int, loss_out) -> None:
     _need_cuda(part_in, loss_out)
     _lib.check(_lib.lib().crh_mf_step_finish(_lib.ptr(part_in), int(n_parts_in), int(batch), _lib.ptr(loss_out),
@@ -602,6 +618,26 @@ class SpmmSchedule:
     def workspace(self, d: int, device) -> Optional[torch.Tensor]:
         """Heavy rows are combined on chip: crh_spmm_workspace_bytes() is 0 and no scratch is needed."""
         return None
+
+
+def spmm_norm_parts(n_rows: int, d: int, sched: Optional[SpmmSchedule]) -> int:
+    """Workgroups of an SpMM launch over this matrix = 4-float entries ``spmm_csr(..., norms=...)`` writes."""
+    return int(_lib.lib().crh_spmm_norm_parts(int(n_rows), int(d),
+                                               ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None))
+
+
+def spmm_csr_norms(rowptr, col, val, x, y, acc_in, s_in: float, acc_out, s_out: float, sched, mult, user_rows: int,
+                   norm_part) -> None:
+    """spmm_csr that also leaves the next BPR batch's squared block norms as per-workgroup partial sums
+    (crh_spmm_csr_norms_f32): ``mult`` (rows,) int32 multiplicities of the batch, ``norm_part`` (spmm_norm_parts, 4) fp32."""
+    _need_cuda(rowptr, col, val, x, y, acc_in, acc_out, mult, norm_part)
+    n_rows, d = rowptr.shape[0] - 1, x.shape[1]
+    assert mult.dtype == torch.int32 and mult.shape == (n_rows,) and mult.is_contiguous()
+    assert norm_part.dtype == torch.float32 and norm_part.numel() >= 4 * spmm_norm_parts(n_rows, d, sched)
+    _lib.check(_lib.lib().crh_spmm_csr_norms_f32(
+        _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d, _lib.ptr(y), _lib.ptr(acc_in), float(s_in),
+        _lib.ptr(acc_out), float(s_out), ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None,
+        _lib.ptr(mult), int(user_rows), _lib.ptr(norm_part), _lib.current_stream()), "crh_spmm_csr_norms_f32")
 
 
 def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0,

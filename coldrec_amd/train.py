@@ -437,7 +437,9 @@ class LGCNEngine(_TableState):
             self.rs_own[:own].copy_(Eo)
         self.dp.all_gather_rows(self.rs_E, self.rs_own)      # every rank sees the updated table (rows >= N stay zero)
 
-    def _propagate(self, out: torch.Tensor) -> None:
+    def _propagate(self, out: torch.Tensor, mult: Optional[torch.Tensor] = None) -> None:
+        """``mult``: the next batch's row multiplicities -> the last layer's launch also leaves the batch's squared block
+        norms in ``self._norm_part`` (crh_spmm_csr_norms_f32; the fused step has no forward pass over the batch)."""
         if getattr(self, "rs", None) is not None:
             self._propagate_sharded()
             if out is not self.OUT:
@@ -448,9 +450,51 @@ class LGCNEngine(_TableState):
         for k in range(self.L):
             last = k == self.L - 1
             y = None if last else self.X[k & 1]
-            self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
-                            acc_out=out, s_out=c if last else 1.0, sched=self.sched)
+            if last and mult is not None:
+                self.k.spmm_csr_norms(self.rowptr, self.col, self.val, x, y, self.E if k == 0 else out, 1.0, out, c, self.sched,
+                                      mult, self.user_num, self._norm_part)
+            else:
+                self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
+                                acc_out=out, s_out=c if last else 1.0, sched=self.sched)
             x = y
+
+    # ---------------------------------------------------------------- step without a forward pass over the batch
+    fused = False
+    FUSED_MAX_MAP_BYTES = 1 << 29
+
+    def can_fuse(self, n_batches: int, batch_size: int) -> bool:
+        return (hasattr(self.k, 'bpr_grad_rows') and self.dp is None and getattr(self, "rs", None) is None and self.fuse_adam
+                and self.d <= 256 and self.E.is_cuda and batch_size <= 8192 and 1 <= n_batches <= 65535
+                and n_batches * self.E.shape[0] * 12 <= self.FUSED_MAX_MAP_BYTES)
+
+    def enable_fused_step(self) -> None:
+        """model/LightGCN.py:23-28 in 2L + 1 launches: the last forward SpMM also sums the batch's block norms (row
+        multiplicities x row norms of the table it writes), the row-gradient kernel recomputes the score differences from
+        the rows it gathers (crh_bpr_grad_rows_f32), so ``bpr_fwd`` is gone; the bpr loss of step s is published by step
+        s + 1 (the last one by crh_mf_step_finish), as in the one-launch BPR-MF step.  Driven by ``fused_epoch``."""
+        assert self.can_fuse(1, 1)
+        self.fused = True
+        N, d = self.E.shape
+        self._n_norm = ops.spmm_norm_parts(N, d, self.sched)
+        self._norm_part = torch.zeros(self._n_norm * 4, dtype=torch.float32, device=self.device)
+        self._gparts = ops.mf_step_parts(N, d)
+        self._loss_parts = [torch.zeros(self._gparts * 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+
+    def fused_epoch(self, u, i, j, steps, plans, tables, losses, scalars) -> None:
+        rng, mult, ent = tables
+        prev_parts, prev = None, 0
+        for s, (lo, hi) in enumerate(steps):
+            self._propagate(self.OUT, mult=mult[s])
+            if not self._dout_clean:
+                self.dOUT.zero_()
+            part_out = self._loss_parts[s & 1]
+            ops.bpr_grad_rows(self.OUT, self.dOUT, self.user_num, hi - lo, self.reg, plans[s], rng[s], ent[s], self._norm_part,
+                              self._n_norm, prev_parts, self._gparts if prev_parts is not None else 0, part_out,
+                              losses[s - 1] if s else None, prev, losses[s])
+            self._backward(scalars[s])
+            prev_parts, prev = part_out, hi - lo
+        ops.mf_step_finish(prev_parts, self._gparts, prev, losses[len(steps) - 1])
+        self.loss.copy_(losses[len(steps) - 1])
 
     def forward(self):
         self._propagate(self.OUT)
@@ -475,6 +519,11 @@ class LGCNEngine(_TableState):
             self.k.bpr_fwd_bwd(self.OUT[:U], self.OUT[U:], self.OUT[U:], user_idx, pos_idx, neg_idx, self.reg,
                                self.dOUT[:U], self.dOUT[U:], self.dOUT[U:], loss, plan=plan,
                                workspace=self._ws(user_idx.shape[0]))
+        self._backward(step_scalars)
+
+    def _backward(self, step_scalars) -> None:
+        """Backward propagation of dOUT and the optimiser step (replicated engine)."""
+        c = 1.0 / (self.L + 1)
         # dE0 = c * sum_k A^k dOUT by Horner: H1 = (dOUT + A dOUT) c ; H_{j+1} = dOUT c + A H_j
         x = self.dOUT
         self.step_count += 1
@@ -528,8 +577,13 @@ class EpochRunner:
         # BPR-MF with cache-resident tables: the whole step is one launch (CRH_MF_FUSED=0 keeps the three-kernel step)
         self.tables = None
         if fused is None:
-            fused = os.environ.get("CRH_MF_FUSED", "1") != "0"
-        if fused and isinstance(engine, MFEngine) and engine.can_fuse(len(self.steps), self.B):
+            # BPR-MF: the one-launch step is the default.  LightGCN: the step without a forward pass over the batch is built
+            # and tested but OFF by default -- its row-gradient kernel walks the whole table (it is the BPR-MF step minus the
+            # optimiser) where the plan-based one walks the touched rows only: 137.1 us per step against 127.8 on the same
+            # box (CiteULike shape; profiles/r03_lgcn_fold.log).  CRH_LGCN_FUSED_LOSS=1 switches it on.
+            fused = (os.environ.get("CRH_MF_FUSED", "1") != "0") if isinstance(engine, MFEngine) else \
+                (os.environ.get("CRH_LGCN_FUSED_LOSS", "0") == "1")
+        if fused and isinstance(engine, (MFEngine, LGCNEngine)) and engine.can_fuse(len(self.steps), self.B):
             engine.enable_fused_step()
 
     def _all_steps(self):

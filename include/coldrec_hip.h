@@ -294,6 +294,19 @@ int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val
                      size_t workspace_bytes, void* stream);
 
 /*
+ * crh_spmm_csr_f32 that also leaves the squared Frobenius norms l2_reg_loss needs for the NEXT BPR batch (util/utils.py:44-48
+ * on the gathers of model/LightGCN.py:23-24), summed from the rows this launch writes to acc_out: mult[row] = how often the
+ * batch gathers the row (user rows, i.e. row < user_rows: the count; item rows: positives | negatives << 16 -- the `mult`
+ * table of crh_mf_step_tables).  Every workgroup writes {sum |u|^2, sum |p|^2, sum |n|^2, 0} to norm_part[4 * workgroup];
+ * crh_spmm_norm_parts gives the number of workgroups.  Deterministic (fixed reduction orders).
+ */
+int crh_spmm_csr_norms_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                           const float* x, int d, float* y, const float* acc_in, float s_in, float* acc_out,
+                           float s_out, const crh_spmm_sched* sched, const int32_t* mult, int64_t user_rows,
+                           float* norm_part, void* stream);
+int64_t crh_spmm_norm_parts(int64_t n_rows, int d, const crh_spmm_sched* sched);
+
+/*
  * The last SpMM of LightGCN's backward pass with torch.optim.Adam fused into its epilogue (model/LightGCN.py:26-28):
  * g = (acc_in * s_in + A x) * s_out is the gradient of the embedding table p (also stored to acc_out if not NULL);
  * one Adam step with crh_adam_dense_f32's arithmetic (same bits) on (p, m, v) in place; zero_acc_in != 0 clears
@@ -340,6 +353,19 @@ int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v,
                     const float* part_in, int n_parts_in, float* part_out, float* loss_prev_out,
                     int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
                     const float* step_scalars, void* stream);
+/*
+ * The gradient half of the one-launch step alone (LightGCN, model/LightGCN.py:23-26): d(bpr_loss + l2_reg_loss)/d(table)
+ * row by row into grad_out (rows the batch does not touch are not written: keep them zero), score differences recomputed
+ * from the gathered rows -- no forward pass over the batch.  The batch norms arrive as partial sums from the launch that
+ * produced `table` (crh_spmm_csr_norms_f32), the previous batch's loss sum from the previous call (or NULL / 0);
+ * part_out[crh_mf_step_parts(rows, d)][4] receives this batch's loss sum (component 3); loss_out[1] = l2 now,
+ * loss_prev_out[0] = the previous batch's bpr loss; the last batch's by crh_mf_step_finish(part_out, ...).
+ */
+int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows, int64_t item_rows, int d,
+                          int64_t batch, float reg, const int32_t* plan, const int32_t* range,
+                          const int32_t* entries, const float* norm_part, int n_norm_parts,
+                          const float* loss_part_prev, int n_loss_parts_prev, float* part_out,
+                          float* loss_prev_out, int64_t batch_prev, float* loss_out, void* stream);
 int crh_mf_step_finish(const float* part_in, int n_parts_in, int64_t batch, float* loss_out, void* stream);
 
 /*

@@ -627,6 +627,46 @@ def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B, n_u, n_i):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-5 * np.abs(b).max())   # sums with cancellation
 
 
+@pytest.mark.parametrize("d,L,n_rec,B,n_u,n_i,opt", [(64, 3, 2500, 512, 300, 500, "adam"), (128, 2, 9000, 4096, 2500, 4000, "adam"),
+                                                    (32, 1, 1300, 1000, 90, 140, "adam"), (64, 2, 2500, 512, 300, 500, "sgd")])
+def test_fused_lgcn_step_matches_the_step_with_a_forward_pass(d, L, n_rec, B, n_u, n_i, opt):
+    """Round 3: LightGCN's step without `bpr_fwd` -- the last forward SpMM sums the batch's block norms from the rows it
+    writes (crh_spmm_csr_norms_f32: multiplicity x row norm), the row-gradient kernel recomputes the score differences
+    (crh_bpr_grad_rows_f32), the bpr loss of step s is published by step s + 1 -- against the step with the forward pass
+    over the batch: same losses and tables up to the fp32 summation order of the three norms; bit-reproducible; hot
+    items exercise the heavy rows of both kernels; L = 1 exercises the dOUT clearing; the last batch is short."""
+    from coldrec_amd.train import EpochRunner, LGCNEngine
+    from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
+    rng = np.random.default_rng(d + B + L)
+    U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
+    pairs = np.unique(np.stack([rng.integers(0, n_u, 8 * n_u), np.minimum(rng.zipf(1.3, 8 * n_u) - 1, n_i - 1)], 1), axis=0)
+    rowptr, col, val = bipartite_norm_adj_csr(pairs[:, 0], pairs[:, 1], n_u, n_i)
+    epochs = []
+    for _ in range(3):
+        u = rng.integers(0, n_u, n_rec).astype(np.int32)
+        hot = rng.random(n_rec) < 0.3
+        i = np.where(hot, rng.integers(0, 3, n_rec), rng.integers(0, n_i, n_rec)).astype(np.int32)
+        j = rng.integers(0, n_i, n_rec).astype(np.int32)
+        j = np.where(j == i, (j + 1) % n_i, j).astype(np.int32)
+        epochs.append((u, i, j))
+    runs = {}
+    for tag, fused in (("fused", True), ("fused2", True), ("plain", False)):
+        eng = LGCNEngine(U0, V0, rowptr, col, val, L, 1e-2, 1e-3, DEV, optimizer=opt)
+        runner = EpochRunner(eng, n_rec, B, fused=fused)
+        assert eng.fused == fused
+        losses = [runner.run(*ep).clone() for ep in epochs]           # eager, captured + replayed, replayed
+        torch.cuda.synchronize()
+        uo, io = eng.forward()
+        runs[tag] = (torch.cat(losses).cpu().numpy(), eng.E.cpu().numpy(), uo.cpu().numpy(), io.cpu().numpy(), eng.step_count)
+    for a, b in zip(runs["fused"][:4], runs["fused2"][:4]):
+        assert np.array_equal(a, b)                                   # deterministic
+    assert runs["fused"][4] == runs["plain"][4] == 3 * ((n_rec + B - 1) // B)
+    np.testing.assert_allclose(runs["fused"][0], runs["plain"][0], rtol=2e-6, atol=1e-9)
+    for a, b in zip(runs["fused"][1:4], runs["plain"][1:4]):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-5 * np.abs(b).max())   # sums with cancellation
+
+
 def test_fused_mf_step_first_step_against_oracle():
     """One fused step from the C ABI against the fp64 closed form + the oracle's Adam."""
     from coldrec_amd import ops
