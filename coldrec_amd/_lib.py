@@ -65,6 +65,7 @@ SIGNATURES = {
     "crh_spmm_lane_group": (_i32, [_i64, _i32, _i64]),
     "crh_spmm_csr_norms_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _i64, _vp, _vp]),
     "crh_spmm_norm_parts": (_i64, [_i64, _i32, _vp]),
+    "crh_bpr_grad_parts": (_i32, [_i64, _i32]),
     "crh_bpr_grad_rows_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp,
                                      _i64, _vp, _vp]),
     "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),

@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, 
                                               const f32x4& grad, int mult, float bc2_sqrt, float nss, float& su, float& sp,
                                               float& sn, bool touched = true) {
     const int64_t o = row * a.d + lig * 4;
-    if constexpr (OPT == 2) {          // gradient only: the row of d(loss)/d(table) goes to `pout`; untouched rows stay as they are
+    if constexpr (OPT >= 2) {          // gradient only: the row of d(loss)/d(table) goes to `pout`; untouched rows stay as they are
         if (on && touched) *reinterpret_cast<f32x4*>(a.pout + o) = grad;
         return;
     }
@@ -1150,15 +1150,40 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     const bool light = (int)blockIdx.x >= heavy_blocks;
     const int64_t gid = (int64_t)((int)blockIdx.x - heavy_blocks) * (BPR_THREADS / G) + threadIdx.x / G;
     const int64_t gstride = (int64_t)a.light_blocks * (BPR_THREADS / G);
+    // OPT = 3 (gradient only, LightGCN): the light work items are the rows the batch TOUCHES, taken from the plan (user
+    // rows, then item rows; their entry ranges are the plan's offsets), not every row of the table
+    int64_t n_work = R;
+    PlanView tv{};
+    int64_t plan_L = 0;
+    if constexpr (OPT == 3) {
+        tv = plan_view(a.plan);
+        plan_L = a.plan[2];
+        n_work = (int64_t)tv.n_u + tv.n_i;
+    }
+    auto work_row = [&](int64_t w, int2& range_out) -> int64_t {
+        if constexpr (OPT == 3) {
+            if (w < tv.n_u) {
+                range_out = int2{tv.uptr[w], tv.uptr[w + 1]};
+                return tv.urow[w];
+            }
+            const int64_t wi = w - tv.n_u;
+            range_out = int2{(int)(plan_L + tv.iptr[wi]), (int)(plan_L + tv.iptr[wi + 1])};
+            return a.U + tv.irow[wi];
+        } else {
+            if (!(CRH_ABLATE(a.ablate) & 1)) range_out = a.range[w];
+            return w;
+        }
+    };
     // first round trip of the row chain, issued before the batch sums are reduced
     int2 rg = {0, 0};
     int mult = 0;
+    int64_t row0 = 0;
     f32x4 own = {0.f, 0.f, 0.f, 0.f}, m0 = own, v0 = own;
-    if (light && gid < R) {
-        if (!(CRH_ABLATE(a.ablate) & 1)) rg = a.range[gid];
-        if (a.mult2 && !(CRH_ABLATE(a.ablate) & 4)) mult = a.mult2[gid];
+    if (light && gid < n_work) {
+        row0 = work_row(gid, rg);
+        if (a.mult2 && !(CRH_ABLATE(a.ablate) & 4)) mult = a.mult2[row0];
         if (on) {
-            const int64_t o = gid * a.d + lig * 4;
+            const int64_t o = row0 * a.d + lig * 4;
             own = *reinterpret_cast<const f32x4*>(a.pin + o);
             if constexpr (OPT == 0) {
                 m0 = *reinterpret_cast<const f32x4*>(a.m + o);
@@ -1210,9 +1235,10 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
     }
     float su = 0.f, sp = 0.f, sn = 0.f, sl = 0.f;
     if (light) {
-        for (int64_t row = gid; row < R; row += gstride) {
-            if (row != gid) {                                      // tables beyond MF_MAX_LIGHT blocks of rows
-                rg = a.range[row];
+        for (int64_t w = gid; w < n_work; w += gstride) {
+            int64_t row = row0;
+            if (w != gid) {                                        // tables beyond MF_MAX_LIGHT blocks of rows
+                row = work_row(w, rg);
                 mult = a.mult2 ? a.mult2[row] : 0;
                 if (on) {
                     const int64_t o = row * a.d + lig * 4;
@@ -1731,6 +1757,16 @@ extern "C" void crh_adam_step_scalars_host(double lr, double beta1, double beta2
 
 
 // ---------------------------------------------------------------- MF step in one launch (see mf_step_kernel)
+// workgroups of crh_bpr_grad_rows_f32 for a batch of `batch` triples = entries (of 4 floats) of its part_out: the batch
+// touches at most 3 * batch rows (MF_ROWS per lane group), plus the heavy-row workgroups
+extern "C" int crh_bpr_grad_parts(int64_t batch, int d) {
+    if (batch <= 0 || d < 4 || d > 256 || d % 4) return 0;
+    const int64_t per_block = (BPR_THREADS / pick_group(d)) * MF_ROWS;
+    int64_t light = (3 * batch + per_block - 1) / per_block;
+    if (light > MF_MAX_LIGHT) light = MF_MAX_LIGHT;
+    return (int)light + MF_HEAVY_BLOCKS;
+}
+
 extern "C" int crh_mf_step_parts(int64_t n_rows, int d) {
     if (n_rows <= 0 || d < 4 || d > 256 || d % 4) return 0;
     // MF_ROWS table rows per lane group (the second through the grid-stride loop): all blocks of a MovieLens-sized
@@ -1813,14 +1849,15 @@ int mf_step_run(const char* who, int opt, const float* table_in, float* table_ou
     a.k = AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
     a.step_scalars = step_scalars;
     a.neg_lr = (float)(-lr);
-    const int parts = crh_mf_step_parts(user_rows + item_rows, d);
+    const int parts = opt == 3 ? crh_bpr_grad_parts(batch, d) : crh_mf_step_parts(user_rows + item_rows, d);
     a.light_blocks = parts - MF_HEAVY_BLOCKS;
     static const int ablate = CRH_PROFILE_ENV("CRH_MF_ABLATE");
     a.ablate = ablate;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dispatch_group(pick_group(d), [&](auto gc) -> int {
         constexpr int GG = decltype(gc)::value;
-        if (opt == 2) hipLaunchKernelGGL((mf_step_kernel<GG, 2>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        if (opt == 3) hipLaunchKernelGGL((mf_step_kernel<GG, 3>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        else if (opt == 2) hipLaunchKernelGGL((mf_step_kernel<GG, 2>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         else if (opt == 1) hipLaunchKernelGGL((mf_step_kernel<GG, 1>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         else hipLaunchKernelGGL((mf_step_kernel<GG, 0>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         CRH_HIP(hipGetLastError());
@@ -1858,13 +1895,14 @@ extern "C" int crh_mf_step_sgd_f32(const float* table_in, float* table_out, int6
 // recomputed from the gathered rows, so no forward pass over the batch exists any more: the three batch norms arrive as
 // partial sums from the launch that produced the table (crh_spmm_csr_norms_f32: norm_part / n_norm_parts), the previous
 // batch's loss sum from the previous call of this function (loss_part_prev / n_loss_parts_prev, or NULL / 0);
-// part_out[crh_mf_step_parts(rows, d)][4] receives this batch's loss sum in component 3.
+// part_out[crh_bpr_grad_parts(batch, d)][4] receives this batch's loss sum in component 3.  Work items are the rows the
+// batch touches (from the plan), heavy rows by a workgroup each.
 extern "C" int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows, int64_t item_rows, int d,
                                      int64_t batch, float reg, const int32_t* plan, const int32_t* range,
                                      const int32_t* entries, const float* norm_part, int n_norm_parts,
                                      const float* loss_part_prev, int n_loss_parts_prev, float* part_out,
                                      float* loss_prev_out, int64_t batch_prev, float* loss_out, void* stream) {
-    return mf_step_run("crh_bpr_grad_rows_f32", 2, table, grad_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
+    return mf_step_run("crh_bpr_grad_rows_f32", 3, table, grad_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
                        plan, range, entries, nullptr, norm_part, n_norm_parts, part_out, loss_prev_out, batch_prev, loss_out,
                        0.9, 0.999, 1e-8, nullptr, 0.0, stream, loss_part_prev, n_loss_parts_prev);
 }

@@ -370,6 +370,10 @@ def mf_step(table_in, table_out, m, v, user_rows: int, batch: int, reg: float, p
     _lib.check(rc, "crh_mf_step_f32")
 
 
+def bpr_grad_parts(batch: int, d: int) -> int:
+    return int(_lib.lib().crh_bpr_grad_parts(int(batch), int(d)))
+
+
 def bpr_grad_rows(table, grad_out, user_rows: int, batch: int, reg: float, plan, rng, entries, norm_part,
                   n_norm_parts: int, loss_part_prev, n_loss_parts_prev: int, part_out, loss_prev, batch_prev: int,
                   loss_out) -> None:

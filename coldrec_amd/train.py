@@ -477,23 +477,25 @@ class LGCNEngine(_TableState):
         N, d = self.E.shape
         self._n_norm = ops.spmm_norm_parts(N, d, self.sched)
         self._norm_part = torch.zeros(self._n_norm * 4, dtype=torch.float32, device=self.device)
-        self._gparts = ops.mf_step_parts(N, d)
-        self._loss_parts = [torch.zeros(self._gparts * 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._loss_parts = None          # two buffers of crh_bpr_grad_parts(batch, d) x 4 floats, sized by the first epoch
 
     def fused_epoch(self, u, i, j, steps, plans, tables, losses, scalars) -> None:
         rng, mult, ent = tables
-        prev_parts, prev = None, 0
+        gparts = [ops.bpr_grad_parts(hi - lo, self.d) for lo, hi in steps]
+        if self._loss_parts is None or self._loss_parts[0].numel() < 4 * max(gparts):
+            assert not torch.cuda.is_current_stream_capturing(), "size the loss partials before capturing the epoch"
+            self._loss_parts = [torch.zeros(4 * max(gparts), dtype=torch.float32, device=self.device) for _ in range(2)]
+        prev_parts, prev, n_prev = None, 0, 0
         for s, (lo, hi) in enumerate(steps):
             self._propagate(self.OUT, mult=mult[s])
             if not self._dout_clean:
                 self.dOUT.zero_()
             part_out = self._loss_parts[s & 1]
             ops.bpr_grad_rows(self.OUT, self.dOUT, self.user_num, hi - lo, self.reg, plans[s], rng[s], ent[s], self._norm_part,
-                              self._n_norm, prev_parts, self._gparts if prev_parts is not None else 0, part_out,
-                              losses[s - 1] if s else None, prev, losses[s])
+                              self._n_norm, prev_parts, n_prev, part_out, losses[s - 1] if s else None, prev, losses[s])
             self._backward(scalars[s])
-            prev_parts, prev = part_out, hi - lo
-        ops.mf_step_finish(prev_parts, self._gparts, prev, losses[len(steps) - 1])
+            prev_parts, prev, n_prev = part_out, hi - lo, gparts[s]
+        ops.mf_step_finish(prev_parts, n_prev, prev, losses[len(steps) - 1])
         self.loss.copy_(losses[len(steps) - 1])
 
     def forward(self):
@@ -578,9 +580,9 @@ class EpochRunner:
         self.tables = None
         if fused is None:
             # BPR-MF: the one-launch step is the default.  LightGCN: the step without a forward pass over the batch is built
-            # and tested but OFF by default -- its row-gradient kernel walks the whole table (it is the BPR-MF step minus the
-            # optimiser) where the plan-based one walks the touched rows only: 137.1 us per step against 127.8 on the same
-            # box (CiteULike shape; profiles/r03_lgcn_fold.log).  CRH_LGCN_FUSED_LOSS=1 switches it on.
+            # and tested but OFF by default -- recomputing a score difference costs two cross-lane dot products per entry on the
+            # row's dependent chain, more than the forward kernel it removes: 133.6 - 135.0 us per step against 128.3 - 128.6
+            # on the same box (CiteULike shape; profiles/r03_lgcn_fold.log).  CRH_LGCN_FUSED_LOSS=1 switches it on.
             fused = (os.environ.get("CRH_MF_FUSED", "1") != "0") if isinstance(engine, MFEngine) else \
                 (os.environ.get("CRH_LGCN_FUSED_LOSS", "0") == "1")
         if fused and isinstance(engine, (MFEngine, LGCNEngine)) and engine.can_fuse(len(self.steps), self.B):

@@ -358,9 +358,10 @@ int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v,
  * row by row into grad_out (rows the batch does not touch are not written: keep them zero), score differences recomputed
  * from the gathered rows -- no forward pass over the batch.  The batch norms arrive as partial sums from the launch that
  * produced `table` (crh_spmm_csr_norms_f32), the previous batch's loss sum from the previous call (or NULL / 0);
- * part_out[crh_mf_step_parts(rows, d)][4] receives this batch's loss sum (component 3); loss_out[1] = l2 now,
+ * part_out[crh_bpr_grad_parts(batch, d)][4] receives this batch's loss sum (component 3); loss_out[1] = l2 now,
  * loss_prev_out[0] = the previous batch's bpr loss; the last batch's by crh_mf_step_finish(part_out, ...).
  */
+int crh_bpr_grad_parts(int64_t batch, int d);
 int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows, int64_t item_rows, int d,
                           int64_t batch, float reg, const int32_t* plan, const int32_t* range,
                           const int32_t* entries, const float* norm_part, int n_norm_parts,
