@@ -193,6 +193,38 @@ __device__ __forceinline__ void row_edges(const SpmmArgs& a, int64_t e0, int64_t
 // Light path: work item = one row (no schedule) or one single-segment row; a lane group of G lanes owns the
 // row's 16*G-byte column slice and finishes it (bit-identical to the oracle's edge-order chain).
 // Heavy path (rows with several segments): one wave per (row, slice).
+// The same for lane groups narrower than 8 lanes (the column cuts of a giant row: 4 or 2 lanes per group): a lane holds
+// 8 / G entries of an 8-edge chunk, so a group still keeps 8 gathers in flight per round trip -- with one entry per lane a
+// 4-lane group walked its chunk of a 2 950-edge row in twice as many dependent round trips as the uncut row needed.
+template <int G>
+__device__ __forceinline__ void row_edges_narrow(const SpmmArgs& a, int64_t e0, int64_t e1, int c, bool on, int lig,
+                                                 f32x4& acc) {
+    static_assert(G >= 1 && G < 8 && 8 % G == 0, "narrow lane groups only");
+    constexpr int EPL = 8 / G;
+    for (int64_t base = e0; base < e1; base += 8) {
+        int my_col[EPL];
+        float my_val[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const int64_t e = base + s * G + lig;
+            my_col[s] = e < e1 ? a.col[e] : 0;
+            my_val[s] = e < e1 ? a.val[e] : 0.f;
+        }
+        f32x4 x[8];
+        float vv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cc = __shfl(my_col[q / G], q % G, G);
+            vv[q] = __shfl(my_val[q / G], q % G, G);
+            x[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (on && base + q < e1) x[q] = reinterpret_cast<const f32x4*>(a.X + (int64_t)cc * a.d)[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (base + q < e1) fma4(acc, vv[q], x[q]);
+    }
+}
+
 // ---- record stream ("slab") light path, round 3 --------------------------------------------------------------------
 // One lane group = one record (see crh_spmm_sched::slab).  A lane holds ONE pair of each unit; pair q of a unit is
 // broadcast to the lane group by shuffles; the fma chain runs in edge order, so the row's bits are those of the
@@ -291,7 +323,10 @@ __device__ __forceinline__ void heavy_row(const SpmmArgs& a, int64_t row, int c0
         chunk = (chunk + 7) & ~(int64_t)7;
         const int64_t e0 = r0 + (int64_t)gg * chunk;
         const int64_t e1 = e0 + chunk < r1 ? e0 + chunk : r1;
-        if (e0 < r1) row_edges<GG>(a, e0, e1, c, on, lig, acc);
+        if (e0 < r1) {
+            if constexpr (GG < 8) row_edges_narrow<GG>(a, e0, e1, c, on, lig, acc);
+            else row_edges<GG>(a, e0, e1, c, on, lig, acc);
+        }
     }
 #pragma unroll
     for (int off = GG; off < 64; off <<= 1) {
