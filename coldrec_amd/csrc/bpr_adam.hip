@@ -438,24 +438,96 @@ struct PlanKey<uint32_t> {
     __device__ static int32_t entry(uint32_t k) { return (int32_t)((k & 0x1fffu) | (((k >> 13) & 1u) << 30)); }
 };
 
+// Bitonic sort of P keys (a power of two) in LDS by one workgroup.  A thread takes the 2^NB keys whose indices differ
+// in NB consecutive bit positions, runs those NB sub-stages on them in registers and writes them back: a stage of
+// log2(k) sub-stages costs ceil(log2(k) / 3) passes over LDS (one barrier each) instead of log2(k), and the stages
+// k = 2, 4, 8 are one pass.  P = 8192: 33 passes instead of 91.
+template <typename K>
+__device__ __forceinline__ void bitonic_cx(K& x, K& y, bool asc) {
+    const K lo = x < y ? x : y, hi = x < y ? y : x;
+    x = asc ? lo : hi;
+    y = asc ? hi : lo;
+}
+
+// sub-stages with strides 2^b, 2^(b-1) .. 2^(b-NB+1) of stage k
+template <typename K, int NB>
+__device__ __forceinline__ void bitonic_pass(K* keys, int P, int k, int b) {
+    constexpr int N = 1 << NB;
+    const int lowbit = b - NB + 1;
+    for (int t = threadIdx.x; t < (P >> NB); t += PLAN_THREADS) {
+        const int base = ((t >> lowbit) << (b + 1)) | (t & ((1 << lowbit) - 1));
+        const bool asc = (base & k) == 0;          // bit log2(k) lies above b: the same for the whole group
+        K v[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = keys[base + (c << lowbit)];
+#pragma unroll
+        for (int s = NB - 1; s >= 0; --s) {
+#pragma unroll
+            for (int c = 0; c < N; ++c)
+                if (!(c & (1 << s))) bitonic_cx(v[c], v[c | (1 << s)], asc);
+        }
+#pragma unroll
+        for (int c = 0; c < N; ++c) keys[base + (c << lowbit)] = v[c];
+    }
+    __syncthreads();
+}
+
 template <typename K>
 __device__ inline void bitonic_sort_lds(K* keys, int P) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += PLAN_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool asc = (i & k) == 0;
-                    const K x = keys[i], y = keys[ixj];
-                    if ((x > y) == asc) {
-                        keys[i] = y;
-                        keys[ixj] = x;
-                    }
+    if (P >= 8) {                                  // stages k = 2, 4, 8 on eight consecutive keys, in registers
+        for (int t = threadIdx.x; t < (P >> 3); t += PLAN_THREADS) {
+            K v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = keys[t * 8 + c];
+#pragma unroll
+            for (int m = 1; m <= 3; ++m) {
+#pragma unroll
+                for (int s = m - 1; s >= 0; --s) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (!(c & (1 << s))) bitonic_cx(v[c], v[c | (1 << s)], (((t * 8 + c) >> m) & 1) == 0);
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) keys[t * 8 + c] = v[c];
+        }
+        __syncthreads();
+    }
+    int m = P >= 8 ? 4 : 1;
+    for (int k = 1 << m; k <= P; k <<= 1, ++m) {
+        int b = m - 1;                             // sub-stage strides 2^(m-1) .. 1
+        while (b >= 0) {
+            // the last pass of a stage takes three sub-stages (contiguous keys), the first one what is left over
+            const int nb = (b + 1) % 3 ? (b + 1) % 3 : 3;
+            if (nb == 3) bitonic_pass<K, 3>(keys, P, k, b);
+            else if (nb == 2) bitonic_pass<K, 2>(keys, P, k, b);
+            else bitonic_pass<K, 1>(keys, P, k, b);
+            b -= nb;
         }
     }
+}
+
+// Exclusive prefix sum of one int per thread over the workgroup (wave scans + PLAN_THREADS / 64 wave totals in LDS).
+__device__ inline int plan_block_scan(int v, int* scr, int& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) scr[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < PLAN_THREADS / 64; ++i) {
+        const int c = scr[i];
+        base += i < w ? c : 0;
+        tot += c;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
 }
 
 // keys[0..P) sorted, invalid = ~0.  Writes rows[], ptr[], list[] and returns the segment count.
@@ -470,22 +542,9 @@ __device__ inline int plan_emit(const K* keys, int P, int32_t* rows, int32_t* pt
         ++valid;
         if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[e - 1])) ++starts;
     }
-    scan[threadIdx.x] = starts;
-    scan[PLAN_THREADS + threadIdx.x] = valid;
-    __syncthreads();
-    if (threadIdx.x == 0) {                       // PLAN_THREADS-entry serial scan: negligible next to the sort
-        int acc = 0, tv = 0;
-        for (int i = 0; i < PLAN_THREADS; ++i) {
-            const int c = scan[i];
-            scan[i] = acc;
-            acc += c;
-            tv += scan[PLAN_THREADS + i];
-        }
-        scan[2 * PLAN_THREADS] = acc;
-        scan[2 * PLAN_THREADS + 1] = tv;
-    }
-    __syncthreads();
-    int rank = scan[threadIdx.x];
+    int nseg, nvalid;
+    int rank = plan_block_scan(starts, scan, nseg);
+    plan_block_scan(valid, scan, nvalid);
     for (int e = e0; e < e1; ++e) {
         const K kx = keys[e];
         if (kx == PlanKey<K>::INVALID) break;
@@ -496,7 +555,6 @@ __device__ inline int plan_emit(const K* keys, int P, int32_t* rows, int32_t* pt
         }
         list[e] = PlanKey<K>::entry(kx);
     }
-    const int nseg = scan[2 * PLAN_THREADS], nvalid = scan[2 * PLAN_THREADS + 1];
     if (threadIdx.x == 0) ptr[nseg] = nvalid;
     __syncthreads();
     return nseg;
@@ -537,22 +595,14 @@ __device__ inline void plan_emit_heavy(int32_t* pl, int64_t L, int nu, int ni, c
     for (int r = r0; r < r1; ++r)
         nh += (r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY;
     __syncthreads();
-    scan[threadIdx.x] = nh;
-    __syncthreads();
+    int n_heavy;
+    int w = plan_block_scan(nh, scan, n_heavy);
     if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int i = 0; i < PLAN_THREADS; ++i) {
-            const int c = scan[i];
-            scan[i] = acc;
-            acc += c;
-        }
         pl[0] = nu;
         pl[1] = ni;
         pl[2] = (int32_t)L;
-        hv[0] = acc;
+        hv[0] = n_heavy;
     }
-    __syncthreads();
-    int w = scan[threadIdx.x];
     for (int r = r0; r < r1; ++r)
         if ((r < nu ? uptr[r + 1] - uptr[r] : iptr[r - nu + 1] - iptr[r - nu]) > BPR_HEAVY) hv[1 + w++] = r;
 }

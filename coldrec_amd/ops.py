@@ -543,9 +543,10 @@ class SpmmSchedule:
         # first wave of workgroups).  Rows above GIANT edges are cut into 2 (4 above 4 * GIANT) column ranges of the slice,
         # one workgroup each with half (a quarter) of the lanes per lane group: multi_count = n_sub | sub << 8.
         giant = int(os.environ.get("CRH_SPMM_GIANT", "1024"))
+        giant4 = int(os.environ.get("CRH_SPMM_GIANT4", str(4 * giant)))
         hrows = np.nonzero(heavy)[0]
         hrows = hrows[np.argsort(-deg[hrows], kind="stable")]
-        n_sub = np.where(deg[hrows] > 4 * giant, 4, np.where(deg[hrows] > giant, 2, 1)) if giant > 0 else np.ones(len(hrows), np.int64)
+        n_sub = np.where(deg[hrows] > giant4, 4, np.where(deg[hrows] > giant, 2, 1)) if giant > 0 else np.ones(len(hrows), np.int64)
         multi_row = np.repeat(hrows, n_sub).astype(np.int32)
         sub = (np.arange(len(multi_row)) - np.repeat(np.cumsum(n_sub) - n_sub, n_sub)).astype(np.int64)
         multi_count = (np.repeat(n_sub, n_sub) | (sub << 8)).astype(np.int32)
