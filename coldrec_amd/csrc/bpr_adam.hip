@@ -438,36 +438,59 @@ struct PlanKey<uint32_t> {
     __device__ static int32_t entry(uint32_t k) { return (int32_t)((k & 0x1fffu) | (((k >> 13) & 1u) << 30)); }
 };
 
-// Bitonic sort of P keys (a power of two) in LDS by one workgroup.  A thread takes the 2^NB keys whose indices differ
-// in NB consecutive bit positions, runs those NB sub-stages on them in registers and writes them back: a stage of
-// log2(k) sub-stages costs ceil(log2(k) / 3) passes over LDS (one barrier each) instead of log2(k), and the stages
-// k = 2, 4, 8 are one pass.  P = 8192: 33 passes instead of 91.
+// LDS index of key i: eight keys of padding after every 64.  A pass whose eight keys per thread are 8 apart (threads
+// t, t+8, .. of a wave then sit 64 keys apart) would put eight lanes on every bank; with the padding the 64 lanes of a
+// read fall on 64 different banks for every stride the sort uses (1, 8, 64, 512, 4096), and a thread's eight
+// consecutive keys stay contiguous and 32-B aligned.
+__device__ __forceinline__ int plan_pk(int i) { return i + ((i >> 6) << 3); }
+__host__ __device__ constexpr size_t plan_padded_keys(size_t n) { return n + ((n + 63) / 64) * 8; }
+
+// Bitonic sort of P keys (a power of two) in LDS by one workgroup, ascending.  Written without direction bits: the
+// first sub-stage of stage k compares key i with key i ^ (k - 1) (the mirrored position in its block of k), the others i
+// with i ^ stride, and every compare puts the smaller key at the lower index -- two instructions (min, max) per
+// compare-exchange of 32-bit keys.  A thread takes the 2^NB keys whose indices differ in NB consecutive bit positions,
+// runs those NB sub-stages on them in registers and writes them back: a stage of log2(k) sub-stages costs
+// ceil(log2(k) / 3) passes over LDS (one barrier each) instead of log2(k), and the stages k = 2, 4, 8 are one pass.
+// P = 8192: 33 passes instead of 91.
 template <typename K>
-__device__ __forceinline__ void bitonic_cx(K& x, K& y, bool asc) {
-    const K lo = x < y ? x : y, hi = x < y ? y : x;
-    x = asc ? lo : hi;
-    y = asc ? hi : lo;
+__device__ __forceinline__ void bitonic_cx(K& x, K& y) {
+    const bool sw = y < x;
+    const K lo = sw ? y : x, hi = sw ? x : y;
+    x = lo;
+    y = hi;
+}
+template <>
+__device__ __forceinline__ void bitonic_cx<uint32_t>(uint32_t& x, uint32_t& y) {
+    const uint32_t lo = min(x, y), hi = max(x, y);
+    x = lo;
+    y = hi;
 }
 
-// sub-stages with strides 2^b, 2^(b-1) .. 2^(b-NB+1) of stage k
-template <typename K, int NB>
-__device__ __forceinline__ void bitonic_pass(K* keys, int P, int k, int b) {
+// Sub-stages with strides 2^b, 2^(b-1) .. 2^(b-NB+1).  FIRST: 2^b is the first sub-stage of its stage (k = 2^(b+1)):
+// the upper half of a thread's keys then comes from the mirrored low bits, so that register c pairs with register ~c.
+template <typename K, int NB, bool FIRST>
+__device__ __forceinline__ void bitonic_pass(K* keys, int P, int b) {
     constexpr int N = 1 << NB;
     const int lowbit = b - NB + 1;
+    const int lowmask = (1 << lowbit) - 1;
     for (int t = threadIdx.x; t < (P >> NB); t += PLAN_THREADS) {
-        const int base = ((t >> lowbit) << (b + 1)) | (t & ((1 << lowbit) - 1));
-        const bool asc = (base & k) == 0;          // bit log2(k) lies above b: the same for the whole group
+        const int hi = (t >> lowbit) << (b + 1), lo = t & lowmask;
+        const int lo_up = FIRST ? lowmask - lo : lo;
         K v[N];
 #pragma unroll
-        for (int c = 0; c < N; ++c) v[c] = keys[base + (c << lowbit)];
+        for (int c = 0; c < N; ++c) v[c] = keys[plan_pk(hi | (c << lowbit) | (c >> (NB - 1) ? lo_up : lo))];
+        if (FIRST) {
 #pragma unroll
-        for (int s = NB - 1; s >= 0; --s) {
-#pragma unroll
-            for (int c = 0; c < N; ++c)
-                if (!(c & (1 << s))) bitonic_cx(v[c], v[c | (1 << s)], asc);
+            for (int c = 0; c < N / 2; ++c) bitonic_cx(v[c], v[c ^ (N - 1)]);
         }
 #pragma unroll
-        for (int c = 0; c < N; ++c) keys[base + (c << lowbit)] = v[c];
+        for (int s = FIRST ? NB - 2 : NB - 1; s >= 0; --s) {
+#pragma unroll
+            for (int c = 0; c < N; ++c)
+                if (!(c & (1 << s))) bitonic_cx(v[c], v[c | (1 << s)]);
+        }
+#pragma unroll
+        for (int c = 0; c < N; ++c) keys[plan_pk(hi | (c << lowbit) | (c >> (NB - 1) ? lo_up : lo))] = v[c];
     }
     __syncthreads();
 }
@@ -478,32 +501,32 @@ __device__ inline void bitonic_sort_lds(K* keys, int P) {
         for (int t = threadIdx.x; t < (P >> 3); t += PLAN_THREADS) {
             K v[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = keys[t * 8 + c];
+            for (int c = 0; c < 8; ++c) v[c] = keys[plan_pk(t * 8) + c];
 #pragma unroll
             for (int m = 1; m <= 3; ++m) {
 #pragma unroll
-                for (int s = m - 1; s >= 0; --s) {
+                for (int c = 0; c < 8; ++c)
+                    if (!(c & (1 << (m - 1)))) bitonic_cx(v[c], v[c ^ ((1 << m) - 1)]);
+#pragma unroll
+                for (int s = m - 2; s >= 0; --s) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        if (!(c & (1 << s))) bitonic_cx(v[c], v[c | (1 << s)], (((t * 8 + c) >> m) & 1) == 0);
+                        if (!(c & (1 << s))) bitonic_cx(v[c], v[c | (1 << s)]);
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) keys[t * 8 + c] = v[c];
+            for (int c = 0; c < 8; ++c) keys[plan_pk(t * 8) + c] = v[c];
         }
         __syncthreads();
     }
-    int m = P >= 8 ? 4 : 1;
-    for (int k = 1 << m; k <= P; k <<= 1, ++m) {
-        int b = m - 1;                             // sub-stage strides 2^(m-1) .. 1
-        while (b >= 0) {
-            // the last pass of a stage takes three sub-stages (contiguous keys), the first one what is left over
-            const int nb = (b + 1) % 3 ? (b + 1) % 3 : 3;
-            if (nb == 3) bitonic_pass<K, 3>(keys, P, k, b);
-            else if (nb == 2) bitonic_pass<K, 2>(keys, P, k, b);
-            else bitonic_pass<K, 1>(keys, P, k, b);
-            b -= nb;
-        }
+    for (int m = P >= 8 ? 4 : 1; (1 << m) <= P; ++m) {
+        // sub-stage strides 2^(m-1) .. 1: the first pass takes what three-at-a-time leaves over, so that the last one
+        // works on eight consecutive keys
+        const int nb0 = m % 3 ? m % 3 : 3;
+        if (nb0 == 3) bitonic_pass<K, 3, true>(keys, P, m - 1);
+        else if (nb0 == 2) bitonic_pass<K, 2, true>(keys, P, m - 1);
+        else bitonic_pass<K, 1, true>(keys, P, m - 1);
+        for (int b = m - 1 - nb0; b >= 0; b -= 3) bitonic_pass<K, 3, false>(keys, P, b);
     }
 }
 
@@ -537,18 +560,18 @@ __device__ inline int plan_emit(const K* keys, int P, int32_t* rows, int32_t* pt
     const int e0 = threadIdx.x * chunk, e1 = min(e0 + chunk, P);
     int starts = 0, valid = 0;
     for (int e = e0; e < e1; ++e) {
-        const K kx = keys[e];
+        const K kx = keys[plan_pk(e)];
         if (kx == PlanKey<K>::INVALID) break;
         ++valid;
-        if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[e - 1])) ++starts;
+        if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[plan_pk(e - 1)])) ++starts;
     }
     int nseg, nvalid;
     int rank = plan_block_scan(starts, scan, nseg);
     plan_block_scan(valid, scan, nvalid);
     for (int e = e0; e < e1; ++e) {
-        const K kx = keys[e];
+        const K kx = keys[plan_pk(e)];
         if (kx == PlanKey<K>::INVALID) break;
-        if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[e - 1])) {
+        if (e == 0 || PlanKey<K>::row(kx) != PlanKey<K>::row(keys[plan_pk(e - 1)])) {
             rows[rank] = PlanKey<K>::row(kx);
             ptr[rank] = e;
             ++rank;
@@ -560,27 +583,38 @@ __device__ inline int plan_emit(const K* keys, int P, int32_t* rows, int32_t* pt
     return nseg;
 }
 
-// Both sides of one batch with keys of type K (LDS: P keys + the scan scratch).
+#ifdef CRH_PROFILE
+__device__ unsigned long long crh_plan_clk[16];   // phase stamps of workgroup 0 (s_memrealtime, 100 MHz), last launch
+#define PLAN_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) crh_plan_clk[8 * blockIdx.y + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PLAN_STAMP(i) do {} while (0)
+#endif
+
+// One side of one batch with keys of type K (LDS: P keys + the scan scratch); returns the side's row count.
+// side 0: the L user keys (P / 2 slots); side 1: the 2 L item keys, positives then negatives.
 template <typename K>
-__device__ inline void plan_sides(const int32_t* iu, const int32_t* ip, const int32_t* in_, int64_t lo, int cnt, int P,
-                                  char* smem, int32_t* urow, int32_t* uptr, int32_t* ulist, int32_t* irow, int32_t* iptr,
-                                  int32_t* ilist, int* scan, int& nu, int& ni) {
+__device__ inline int plan_side(int side, const int32_t* iu, const int32_t* ip, const int32_t* in_, int64_t lo, int cnt,
+                                int P, char* smem, int32_t* rows, int32_t* ptr, int32_t* list, int* scan) {
     K* keys = reinterpret_cast<K*>(smem);
-    const int Pu = P > 2 ? P >> 1 : P;            // the user side has half as many keys (P covers 2 L item keys)
-    for (int e = threadIdx.x; e < Pu; e += PLAN_THREADS)
-        keys[e] = e < cnt ? PlanKey<K>::make((uint32_t)iu[lo + e], (unsigned)e, 0u) : PlanKey<K>::INVALID;
-    __syncthreads();
-    bitonic_sort_lds(keys, Pu);
-    nu = plan_emit(keys, Pu, urow, uptr, ulist, scan);
-    for (int e = threadIdx.x; e < P; e += PLAN_THREADS) {
+    const int Ps = side == 0 && P > 2 ? P >> 1 : P;
+    for (int e = threadIdx.x; e < Ps; e += PLAN_THREADS) {
         K kx = PlanKey<K>::INVALID;
-        if (e < cnt) kx = PlanKey<K>::make((uint32_t)ip[lo + e], (unsigned)e, 0u);
-        else if (e < 2 * cnt) kx = PlanKey<K>::make((uint32_t)in_[lo + e - cnt], (unsigned)(e - cnt), 1u);
-        keys[e] = kx;
+        if (side == 0) {
+            if (e < cnt) kx = PlanKey<K>::make((uint32_t)iu[lo + e], (unsigned)e, 0u);
+        } else if (e < cnt) {
+            kx = PlanKey<K>::make((uint32_t)ip[lo + e], (unsigned)e, 0u);
+        } else if (e < 2 * cnt) {
+            kx = PlanKey<K>::make((uint32_t)in_[lo + e - cnt], (unsigned)(e - cnt), 1u);
+        }
+        keys[plan_pk(e)] = kx;
     }
     __syncthreads();
-    bitonic_sort_lds(keys, P);
-    ni = plan_emit(keys, P, irow, iptr, ilist, scan);
+    PLAN_STAMP(2);
+    bitonic_sort_lds(keys, Ps);
+    PLAN_STAMP(3);
+    const int n = plan_emit(keys, Ps, rows, ptr, list, scan);
+    PLAN_STAMP(4);
+    return n;
 }
 
 // Heavy rows of one plan, ascending (a fixed order: the one-launch MF step sums per-block partials, and which block
@@ -666,7 +700,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
                                                                 int L, int P, int32_t* __restrict__ plans,
                                                                 int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* scan = reinterpret_cast<int*>(smem + (size_t)P * 8);      // behind the key area (sized for 64-bit keys)
+    PLAN_STAMP(0);
+    int* scan = reinterpret_cast<int*>(smem + plan_padded_keys(P) * 8);      // behind the (padded) key area, sized for 64-bit keys
+    const int side = blockIdx.y;                   // 0: user rows, 1: item rows -- one workgroup each
     const int64_t lo = (int64_t)blockIdx.x * L;
     const int cnt = (int)((n_rec - lo) < L ? (n_rec - lo) : L);
     int32_t* pl = plans + (int64_t)blockIdx.x * stride;
@@ -677,24 +713,41 @@ __global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_kernel(const int32_t* _
     int32_t* iptr = irow + 2 * L;
     int32_t* ilist = iptr + (2 * L + 1);
 
-    // largest row id of the batch decides the key width (block maximum through LDS)
+    // largest row id of this side decides the key width (block maximum: wave maxima through LDS)
     int mx = 0;
-    for (int e = threadIdx.x; e < cnt; e += PLAN_THREADS) mx = max(mx, max(iu[lo + e], max(ip[lo + e], in_[lo + e])));
-    scan[threadIdx.x] = mx;
+    for (int e = threadIdx.x; e < cnt; e += PLAN_THREADS) mx = max(mx, side == 0 ? iu[lo + e] : max(ip[lo + e], in_[lo + e]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) scan[threadIdx.x >> 6] = mx;
     __syncthreads();
-    for (int off = PLAN_THREADS / 2; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) scan[threadIdx.x] = max(scan[threadIdx.x], scan[threadIdx.x + off]);
-        __syncthreads();
-    }
-    const bool narrow = scan[0] < (1 << 17) && L <= 8192;
+    mx = 0;
+#pragma unroll
+    for (int i = 0; i < PLAN_THREADS / 64; ++i) mx = max(mx, scan[i]);
+    const bool narrow = mx < (1 << 17) && L <= 8192;
     __syncthreads();
-    int nu, ni;
-    if (narrow)
-        plan_sides<uint32_t>(iu, ip, in_, lo, cnt, P, smem, urow, uptr, ulist, irow, iptr, ilist, scan, nu, ni);
-    else
-        plan_sides<unsigned long long>(iu, ip, in_, lo, cnt, P, smem, urow, uptr, ulist, irow, iptr, ilist, scan, nu, ni);
+    PLAN_STAMP(1);
+    int32_t* rows = side == 0 ? urow : irow;
+    int32_t* ptr = side == 0 ? uptr : iptr;
+    int32_t* list = side == 0 ? ulist : ilist;
+    const int n = narrow ? plan_side<uint32_t>(side, iu, ip, in_, lo, cnt, P, smem, rows, ptr, list, scan)
+                         : plan_side<unsigned long long>(side, iu, ip, in_, lo, cnt, P, smem, rows, ptr, list, scan);
+    if (threadIdx.x == 0) pl[side] = n;            // header: rows per side (the batch size follows in the heavy pass)
+}
+
+// Second launch of the device builder: header + heavy list of every plan, once both sides' rows are in place.
+__global__ __launch_bounds__(PLAN_THREADS) void bpr_plan_heavy_kernel(int L, int32_t* __restrict__ plans, int64_t stride) {
+    __shared__ int scan[PLAN_THREADS / 64];
+    int32_t* pl = plans + (int64_t)blockIdx.x * stride;
+    const int nu = pl[0], ni = pl[1];
+    const int32_t* uptr = pl + 3 + L;
+    const int32_t* iptr = pl + 3 + (3 * L + 1) + 2 * L;
     plan_emit_heavy(pl, L, nu, ni, uptr, iptr, scan);
 }
+#ifdef CRH_PROFILE
+extern "C" int crh_profile_plan_clocks(unsigned long long* out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(crh_plan_clk), sizeof(crh_plan_clk)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---------------------------------------------------------------- plan builder for batches beyond the LDS sort
 // Batches above 8 192 triples (S-TRAIN-XL: 65 536) do not fit one workgroup's LDS.  Same result, several workgroups
@@ -724,15 +777,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_chunk_sort_kernel(const int
                                                                         const int32_t* __restrict__ in_, int64_t n_rec,
                                                                         int64_t L, int item_side, int64_t P,
                                                                         lpkey* __restrict__ keys) {
-    __shared__ lpkey sk[LP_CHUNK];
+    __shared__ lpkey sk[plan_padded_keys(LP_CHUNK)];
     const int64_t lo = (int64_t)blockIdx.y * L;
     const int cnt = (int)((n_rec - lo) < L ? (n_rec - lo) : L);
     const int64_t c0 = (int64_t)blockIdx.x * LP_CHUNK;
-    for (int e = threadIdx.x; e < LP_CHUNK; e += PLAN_THREADS) sk[e] = lp_key(iu, ip, in_, lo, cnt, item_side, c0 + e);
+    for (int e = threadIdx.x; e < LP_CHUNK; e += PLAN_THREADS) sk[plan_pk(e)] = lp_key(iu, ip, in_, lo, cnt, item_side, c0 + e);
     __syncthreads();
     bitonic_sort_lds(sk, LP_CHUNK);
     lpkey* out = keys + (int64_t)blockIdx.y * P + c0;
-    for (int e = threadIdx.x; e < LP_CHUNK; e += PLAN_THREADS) out[e] = sk[e];
+    for (int e = threadIdx.x; e < LP_CHUNK; e += PLAN_THREADS) out[e] = sk[plan_pk(e)];
 }
 
 __global__ __launch_bounds__(256) void plan_merge_pass_kernel(const lpkey* __restrict__ src, lpkey* __restrict__ dst,
@@ -1500,14 +1553,17 @@ extern "C" int crh_bpr_plan_build(const int32_t* user_idx, const int32_t* pos_id
                   "(larger batches: crh_bpr_plan_build_large)", (long long)batch_size);
     int P = 2;
     while (P < 2 * batch_size) P <<= 1;
-    const size_t lds = (size_t)P * 8 + (2 * PLAN_THREADS + 2) * sizeof(int);
+    const size_t lds = plan_padded_keys(P) * 8 + (2 * PLAN_THREADS + 2) * sizeof(int);
     if (lds > 64 * 1024)
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bpr_plan_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t nb = (n_records + batch_size - 1) / batch_size;
-    hipLaunchKernelGGL(bpr_plan_kernel, dim3((unsigned)nb), dim3(PLAN_THREADS), lds,
+    hipLaunchKernelGGL(bpr_plan_kernel, dim3((unsigned)nb, 2), dim3(PLAN_THREADS), lds,
                        reinterpret_cast<hipStream_t>(stream), user_idx, pos_idx, neg_idx, n_records, (int)batch_size,
                        P, plans_out, plan_ints(batch_size));
+    CRH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bpr_plan_heavy_kernel, dim3((unsigned)nb), dim3(PLAN_THREADS), 0,
+                       reinterpret_cast<hipStream_t>(stream), (int)batch_size, plans_out, plan_ints(batch_size));
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
