@@ -230,6 +230,147 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ S, i
     }
 }
 
+// ------------------------------------------------------------------ dense mask + top-k, register-resident chunks
+// The streaming kernel above pays ~k (1 + ln(N / k)) wave-serial list insertions per row whatever N is: on the rows
+// the trainers rank every epoch (validation: 3 706 - 16 980 items; the seed prefix of the mid-size route: 4 096 -
+// 16 384) the insertions, not the bytes, are the cost.  Here a wave takes its row in chunks of 256 * NV items held in
+// registers (NV 16-byte loads per lane in flight), applies BOTH masks first -- the candidate bitmap's words of the
+// chunk and the user's rated ids are OR-ed into a per-wave bitmap in LDS (the rated list is ascending: one walk per
+// row) -- and only then looks for candidates: the k-th largest of the 64 lane maxima (a 32-step radix select on
+// ballots) is a lower bound of the chunk's k-th best score, because the k lanes at or above it hold k different items.
+// Items below it cannot be in the row's top k; what is left is ~k items per chunk instead of ~k ln(chunk / k), and
+// they go through the same list insertion (canonical order, exact ties).  Chunks whose raw maximum cannot beat the
+// list are skipped before any mask work, so a long row streams as before.  Read-only (write_back = 0), k <= 64.
+__device__ __forceinline__ unsigned order_key(float f) {
+    const unsigned b = __builtin_bit_cast(unsigned, f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float order_key_inv(unsigned k) {
+    return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __restrict__ S, int64_t n_users,
+                                                              int64_t n_items, int64_t stride,
+                                                              const int64_t* __restrict__ rated_rowptr,
+                                                              const int32_t* __restrict__ rated_col,
+                                                              const uint32_t* __restrict__ bitmap, int K,
+                                                              int64_t item_base, float* __restrict__ out_score,
+                                                              int32_t* __restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = 256 * NV, WORDS = 8 * NV;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* ls = reinterpret_cast<float*>(smem) + (size_t)wave * (2 * K + 4 + WORDS);
+    int* li = reinterpret_cast<int*>(ls + K);
+    int* cnt = li + K;
+    unsigned* bm = reinterpret_cast<unsigned*>(cnt + 4);
+    const bool have_masks = bitmap != nullptr || rated_rowptr != nullptr;
+    const int64_t last_word = bitmap ? (item_base + n_items - 1) >> 5 : 0;
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_users; row += (int64_t)gridDim.x * 4) {
+        if (lane == 0) *cnt = 0;
+        int64_t rp = 0, rhi = 0;                 // the part of the rated list not yet behind the stream
+        if (rated_rowptr) {
+            rp = rated_rowptr[row];
+            rhi = rated_rowptr[row + 1];
+        }
+        const float* srow = S + row * stride;
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(srow) & 15) == 0);
+        float tau = CRH_NEG_INF;                 // the list's k-th score once it is full (strict: later ids lose ties)
+        for (int64_t base = 0; base < n_items; base += CH) {
+            f32x4 v[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int64_t e0 = base + u * 256 + lane * 4;
+                if (vec_ok && e0 + 3 < n_items) {
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(srow + e0));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[u][c] = e0 + c < n_items ? srow[e0 + c] : CRH_NEG_INF;
+                }
+            }
+            float m = CRH_NEG_INF;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) m = fmaxf(m, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
+            // masking only lowers a score (to -1e9 <= a finite tau): a chunk whose raw maximum cannot beat the list is done
+            if (__ballot(m > tau) == 0ull) continue;
+            if (have_masks) {
+                const int64_t g0 = item_base + base;              // global id of the chunk's first item
+                for (int w = lane; w < WORDS; w += 64) {
+                    unsigned word = 0;
+                    if (bitmap) {
+                        const int64_t wi = (g0 >> 5) + w;
+                        const unsigned lo = wi <= last_word ? bitmap[wi] : 0u;
+                        const unsigned hi = wi + 1 <= last_word ? bitmap[wi + 1] : 0u;
+                        const int sh = (int)(g0 & 31);
+                        word = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                    }
+                    bm[w] = word;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (rp < rhi) {
+                    const int64_t g1 = g0 + CH;
+                    for (;;) {
+                        const int64_t e = rp + lane;
+                        const int64_t cid = e < rhi ? (int64_t)rated_col[e] : ((int64_t)1 << 62);   // past the end: never behind
+                        if (cid >= g0 && cid < g1) atomicOr(&bm[(cid - g0) >> 5], 1u << ((cid - g0) & 31));
+                        const int behind = __popcll(__ballot(cid < g1));
+                        rp += behind;
+                        if (behind < 64) break;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                m = CRH_NEG_INF;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const unsigned bits = (bm[u * 8 + (lane >> 3)] >> ((lane & 7) * 4)) & 0xfu;
+                    const int64_t e0 = base + u * 256 + lane * 4;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (((bits >> c) & 1u) && e0 + c < n_items) v[u][c] = CRH_MASKED_SCORE;
+                    m = fmaxf(m, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (__ballot(m > tau) == 0ull) continue;
+            }
+            // k-th largest lane maximum: most significant bit first, keep a bit if k lanes still reach the value
+            const unsigned mk = order_key(m);
+            unsigned cur = 0;
+#pragma unroll
+            for (int b = 31; b >= 0; --b) {
+                const unsigned t = cur | (1u << b);
+                if (__popcll(__ballot(mk >= t)) >= K) cur = t;
+            }
+            const float tau0 = order_key_inv(cur);
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int64_t e0 = base + u * 256 + lane * 4;
+                const float mu = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
+                if (__ballot(mu >= tau0 && mu > tau) == 0ull) continue;
+                const float vc[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned long long cand = __ballot(vc[c] >= tau0 && vc[c] > tau && e0 + c < n_items);
+                    while (cand) {
+                        const int L = __builtin_ctzll(cand);
+                        cand &= cand - 1;
+                        const float sc = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vc[c]), L));
+                        const int gi = (int)(item_base + base + u * 256 + L * 4 + c);
+                        const int n = __builtin_amdgcn_readfirstlane(*cnt);
+                        if (wave_list_rejects(ls, li, n, K, sc, gi)) continue;
+                        wave_list_insert(ls, li, cnt, K, sc, gi, lane);
+                    }
+                }
+                tau = wave_list_tau(ls, *cnt, K);
+            }
+        }
+        const int n = __builtin_amdgcn_readfirstlane(*cnt);
+        wave_list_store(ls, li, n, K, out_score + row * K, out_idx + row * K, lane);
+    }
+}
+
 }  // namespace
 
 extern "C" int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, int64_t n_users,
@@ -271,6 +412,19 @@ extern "C" int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items
 #define CRH_MASK_LAUNCH(W, B)                                                                                              \
     hipLaunchKernelGGL((mask_topk_kernel<W, 4>), dim3((unsigned)(B)), dim3(256), lds, st, scores, n_users, n_items, row_stride, \
                        rated_rowptr, rated_col, cand_bitmap, k, item_base, write_back, out_score, out_idx)
+    // rows short enough for the insertions to be the cost (and any row of a read-only call up to the limit): chunks in
+    // registers, masks first, lane-maximum threshold.  CRH_MASK_CHUNK_ITEMS = largest row that takes this kernel (0: off).
+    static const int64_t chunk_items = getenv("CRH_MASK_CHUNK_ITEMS") ? atoll(getenv("CRH_MASK_CHUNK_ITEMS")) : 65536;
+    if (!write_back && k <= 64 && n_items <= chunk_items && !(n_users < wpr_rows && n_items >= 8192)) {
+        constexpr int NV = 16;
+        const size_t lds_c = (size_t)4 * (2 * k + 4 + 8 * NV) * 4;
+        int64_t blocks = (n_users + 3) / 4;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL((mask_topk_chunk_kernel<NV>), dim3((unsigned)blocks), dim3(256), lds_c, st, scores, n_users, n_items,
+                           row_stride, rated_rowptr, rated_col, cand_bitmap, k, item_base, out_score, out_idx);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    }
     if (n_users < wpr_rows && n_items >= 8192) {    // few rows: four waves per row
         CRH_MASK_LAUNCH(4, n_users > 16384 ? 16384 : n_users);
     } else {

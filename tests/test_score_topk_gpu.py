@@ -212,6 +212,42 @@ def test_mask_topk_dense_block_variants(n_users, n_items, base):
         np.testing.assert_array_equal(tS.cpu().numpy(), S_ref if wb else S)
 
 
+@pytest.mark.parametrize("n_users,n_items,base,k,mask_frac", [
+    (300, 3706, 7, 20, 0.2),        # one chunk, shard offset that is not a multiple of 32
+    (70, 4097, 31, 20, 0.2),        # one item into the second chunk
+    (9, 50, 0, 20, 0.5),            # fewer unmasked items than k: masked (-1e9) entries fill the list
+    (130, 12289, 4096, 64, 0.2),    # k = 64 = one list entry per lane, four chunks
+    (41, 8192, 0, 1, 0.0),          # k = 1, no bitmap bits
+    (50, 5000, 3, 20, 0.999),       # almost everything masked: the lane-maximum bound sits at -1e9
+])
+def test_mask_topk_register_chunk_kernel(n_users, n_items, base, k, mask_frac):
+    """Read-only crh_mask_topk_f32 on short rows (mask_topk_chunk_kernel: chunks of 4096 items in registers, masks
+    through a per-wave LDS bitmap, lane-maximum threshold before the list insertions) against the oracle and against
+    the streaming kernel (write_back=True takes it) -- ties, unaligned rows, shard offsets, k up to 64."""
+    from coldrec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(n_users * 7 + n_items)
+    S = (rng.integers(-6, 7, (n_users, n_items)) / 4).astype(np.float32)
+    S[:, ::3] += rng.standard_normal((n_users, len(range(0, n_items, 3)))).astype(np.float32)
+    n_glob = base + n_items + 45
+    rated = [np.unique(rng.integers(max(base - 20, 0), base + n_items + 20, rng.integers(0, 200))) for _ in range(n_users)]
+    rated = [r[r < n_glob] for r in rated]                     # ids outside the shard on both sides are ignored
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64) if rowptr[-1] else np.zeros(0, np.int64)
+    bm = np.where(rng.random(n_glob) < mask_frac)[0]
+    srp, src = orc.sort_rated(rowptr, col)
+    ws, wi = orc.mask_topk(S.copy(), k, rowptr, col, orc.make_bitmap(n_glob, bm) if len(bm) else None, item_base=base,
+                           write_back=False)
+    args = (torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev), ops.make_bitmap(n_glob, bm, dev) if len(bm) else None)
+    tS = torch.from_numpy(S.copy()).to(dev)
+    ds, di = ops.mask_topk(tS, k, *args, item_base=base, write_back=False)
+    ds2, di2 = ops.mask_topk(tS.clone(), k, *args, item_base=base, write_back=True)
+    torch.cuda.synchronize()
+    _same((ds.cpu().numpy(), di.cpu().numpy()), (ws, wi))
+    _same((ds2.cpu().numpy(), di2.cpu().numpy()), (ws, wi))
+    np.testing.assert_array_equal(tS.cpu().numpy(), S)            # read-only call left the block alone
+
+
 def test_full_size_properties_eval_config():
     """BASELINE config 4 shape on one GPU, scaled to what a test may take: 4096 users x 1M items,
     d=128.  Size-independent properties: (1) independent of the item-range split count,
