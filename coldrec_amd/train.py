@@ -576,6 +576,9 @@ class EpochRunner:
         self.losses = torch.zeros((len(self.steps), 2), dtype=torch.float32, device=dev)
         self.use_graph, self.graph, self.epochs_done = use_graph and not getattr(engine, "lazy", False), None, 0
         self._sc_pinned = None
+        # epochs run eagerly before the capture (CRH_EAGER_EPOCHS): the first epoch makes the lazy allocations and uploads
+        # (LightGCN's record streams per lane-group width) that a stream capture does not allow
+        self.eager_epochs = max(int(os.environ.get("CRH_EAGER_EPOCHS", "1")), 0)
         # BPR-MF with cache-resident tables: the whole step is one launch (CRH_MF_FUSED=0 keeps the three-kernel step)
         self.tables = None
         if fused is None:
@@ -631,8 +634,10 @@ class EpochRunner:
         if self.graph is not None:
             self.graph.replay()
             eng.step_count += len(self.steps)
-        elif self.use_graph and self.epochs_done >= 1:
+        elif self.use_graph and self.epochs_done >= self.eager_epochs:
             count = eng.step_count
+            if hasattr(eng, "_ws"):
+                eng._ws(self.B)                         # the engine's scratch keeps its address: sized before the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

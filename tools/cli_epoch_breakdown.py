@@ -25,7 +25,11 @@ N = collections.defaultdict(int)
 FIRST = {}
 
 
+SYNC_ALL = os.environ.get("CLI_BREAKDOWN_SYNC", "0") == "1"      # synchronise after every wrapped call (first-call costs incl. the GPU's)
+
+
 def wrap(obj, name, label=None, sync=False):
+    sync = sync or SYNC_ALL
     f = getattr(obj, name)
     label = label or name
 
