@@ -78,6 +78,9 @@ SIGNATURES = {
     "crh_mf_step_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp,
                                _vp, _i32, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _vp, _vp]),
     "crh_mf_step_finish": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "crh_mf_epoch_blocks": (_i32, [_i64, _i32, _i32]),
+    "crh_mf_epoch_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                _f64, _f64, _f64, _vp, _i32, _f64, _vp, _vp]),
     "crh_mf_step_sgd_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i64, _vp, _f64, _vp]),
     "crh_sgd_dense_f32": (_i32, [_vp, _vp, _i64, _f64, _i32, _vp]),

@@ -390,6 +390,34 @@ def bpr_grad_rows(table, grad_out, user_rows: int, batch: int, reg: float, plan,
         _lib.current_stream()), "crh_bpr_grad_rows_f32")
 
 
+def mf_epoch_blocks(n_rows: int, d: int, sgd: bool = False) -> int:
+    """Workgroups of the one-launch epoch for a table of ``n_rows`` x ``d`` (0: the table does not fit one resident grid)."""
+    return int(_lib.lib().crh_mf_epoch_blocks(int(n_rows), int(d), 1 if sgd else 0))
+
+
+def mf_epoch(table0, table1, m, v, user_rows: int, batch: int, n_records: int, reg: float, rng, entries, mult, part0,
+             n_part0: int, parts, losses, step_scalars, sync, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+             sgd_lr: Optional[float] = None) -> None:
+    """All optimiser steps of one epoch of model/MF.py:17-27 in ONE launch (crh_mf_epoch_f32, include/coldrec_hip.h):
+    p, m, v of every row stay in registers between the steps.  ``rng`` / ``entries`` / ``mult``: mf_step_tables' outputs."""
+    _need_cuda(table0, table1, m, v, rng, entries, mult, part0, parts, losses, step_scalars, sync)
+    R, d = table0.shape
+    n_steps = -(-int(n_records) // int(batch))
+    for t in (table0, table1) + (() if sgd_lr is not None else (m, v)):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (R, d)
+    for t in (rng, entries, mult):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    assert rng.shape == (n_steps, R, 2) and mult.shape == (n_steps, R) and entries.shape == (n_steps, 3 * int(batch), 2)
+    assert losses.shape == (n_steps, 2) and losses.is_contiguous() and losses.dtype == torch.float32
+    assert sgd_lr is not None or (step_scalars.shape == (n_steps, 2) and step_scalars.is_contiguous())
+    assert sync.dtype == torch.int32 and sync.numel() >= 2048 and parts.numel() >= 8 * mf_epoch_blocks(R, d, sgd_lr is not None)
+    _lib.check(_lib.lib().crh_mf_epoch_f32(
+        _lib.ptr(table0), _lib.ptr(table1), _lib.ptr(m), _lib.ptr(v), int(user_rows), R - int(user_rows), d, int(batch),
+        int(n_records), float(reg), _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(mult), _lib.ptr(part0), int(n_part0),
+        _lib.ptr(parts), _lib.ptr(losses), beta1, beta2, eps, _lib.ptr(step_scalars), 1 if sgd_lr is not None else 0,
+        float(sgd_lr or 0.0), _lib.ptr(sync), _lib.current_stream()), "crh_mf_epoch_f32")
+
+
 def mf_step_finish(part_in, n_parts_in: int, batch: int, loss_out) -> None:
     _need_cuda(part_in, loss_out)
     _lib.check(_lib.lib().crh_mf_step_finish(_lib.ptr(part_in), int(n_parts_in), int(batch), _lib.ptr(loss_out),

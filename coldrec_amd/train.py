@@ -221,16 +221,41 @@ class MFEngine(_TableState):
         self._parts = [torch.zeros(self._nparts * 4, dtype=torch.float32, device=self.device) for _ in range(2)]
         self._fws, self._fws_cap = None, 0
         self._fsums = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # the whole epoch as ONE launch (crh_mf_epoch_f32: p, m, v stay in registers between the steps, a grid barrier
+        # instead of a kernel boundary) when every workgroup of the table fits on the chip at once.  Built, tested,
+        # OFF by default (CRH_MF_EPOCH=1 switches it on): 19.2 us per step against 18.0 for one launch per step at the
+        # MovieLens shape -- the median workgroup reaches the barrier after 9.9 us, the one that owns the batch's hottest
+        # items after 15.7 (profiles/r03_mf_epoch.log)
+        self._eblocks = 0
+        if os.environ.get("CRH_MF_EPOCH", "0") == "1" and hasattr(ops, "mf_epoch"):
+            self._eblocks = ops.mf_epoch_blocks(self.E.shape[0], self.d, self._sgd_lr is not None)
+        if self._eblocks:
+            self._eparts = torch.zeros(2 * self._eblocks * 4, dtype=torch.float32, device=self.device)
+            self._esync = torch.zeros(2048, dtype=torch.int32, device=self.device)
+            self._echecked = False
 
     def fused_epoch(self, u, i, j, steps, plans, tables, losses, scalars) -> None:
-        """All optimiser steps of one epoch (``steps`` = [(lo, hi)] into the triple arrays), one launch each; the
-        Frobenius norms of the first batch come from a forward pass, those of batch s+1 from launch s."""
+        """All optimiser steps of one epoch (``steps`` = [(lo, hi)] into the triple arrays), one launch each -- or one
+        launch for all of them (``_eblocks``); the Frobenius norms of the first batch come from a forward pass, those of
+        batch s+1 from step s."""
         U, (lo, hi) = self.user_num, steps[0]
         if self._fws is None or self._fws_cap < hi - lo:
             self._fws_cap = hi - lo
             self._fws = ops.bpr_workspace(self._fws_cap, self.device)
         ops.bpr_fwd(self.E[:U], self.E[U:], self.E[U:], u[lo:hi], i[lo:hi], j[lo:hi], self._fsums, self._fws)
         part_in, n_in = self._fws.view(torch.float32), ops.bpr_fwd_parts(hi - lo, self.d)
+        if self._eblocks:
+            rng, mult, ent = tables
+            ops.mf_epoch(self.E, self.E2, self.M, self.V, U, ent.shape[1] // 3, steps[-1][1], self.reg, rng, ent, mult,
+                         part_in, n_in, self._eparts, losses, scalars, self._esync, sgd_lr=self._sgd_lr)
+            self.loss.copy_(losses[len(steps) - 1])
+            self.step_count += len(steps)
+            if not self._echecked and not torch.cuda.is_current_stream_capturing():
+                self._echecked = True                 # once, on the eager first epoch: did every barrier complete?
+                if int(self._esync[2].item()) != 0:
+                    raise RuntimeError("crh_mf_epoch_f32: a grid barrier timed out (not every workgroup was resident); "
+                                       "set CRH_MF_EPOCH=0 to run the steps one by one")
+            return
         src, dst, prev = self.E, self.E2, 0
         rng, mult, ent = tables
         for s, (lo, hi) in enumerate(steps):

@@ -368,6 +368,28 @@ int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows
                           const float* loss_part_prev, int n_loss_parts_prev, float* part_out,
                           float* loss_prev_out, int64_t batch_prev, float* loss_out, void* stream);
 int crh_mf_step_finish(const float* part_in, int n_parts_in, int64_t batch, float* loss_out, void* stream);
+/*
+ * One EPOCH of BPR-MF optimiser steps in ONE launch (the loop of model/MF.py:17-27 over next_batch_pairwise, util/utils.py
+ * :99-127): the steps crh_mf_step_f32 (optimizer 0, torch.optim.Adam) / crh_mf_step_sgd_f32 (optimizer 1, plain SGD)
+ * would run one by one over the same crh_mf_step_tables outputs, with every row's p, m, v held in registers from the first
+ * step to the last and a grid-wide barrier instead of a kernel boundary between steps.
+ *   crh_mf_epoch_blocks(rows, d, optimizer): workgroups of the launch = [4]-float partial sums per parity, or 0 when the
+ *             table is too large for every workgroup to be resident at once (they meet at the barrier): use the per-step
+ *             entry points then
+ *   table0    (user_rows + item_rows, d): parameters in, parameters out; table1: scratch of the same size
+ *   range / entries / mult: crh_mf_step_tables' outputs for the epoch, n_steps = ceil(n_records / batch)
+ *   part0     crh_bpr_fwd_f32's partial sums over batch 0 (n_part0 = crh_bpr_fwd_parts(batch 0, d))
+ *   parts     2 x crh_mf_epoch_blocks x 4 floats of scratch;  losses [n_steps][2] = (bpr, l2) of every step
+ *   step_scalars [n_steps][2] (crh_adam_step_scalars; NULL for SGD), lr: SGD only
+ *   sync      2048 zero-initialised uint32 kept by the caller between launches; sync[2] != 0 afterwards = a barrier timed out
+ *             (some workgroup was not resident), the launch ran out without hanging and its results are invalid
+ */
+int crh_mf_epoch_blocks(int64_t n_rows, int d, int optimizer);
+int crh_mf_epoch_f32(float* table0, float* table1, float* m, float* v, int64_t user_rows, int64_t item_rows, int d,
+                     int64_t batch, int64_t n_records, float reg, const int32_t* range, const int32_t* entries,
+                     const int32_t* mult, const float* part0, int n_part0, float* parts, float* losses, double beta1,
+                     double beta2, double eps, const float* step_scalars, int optimizer, double lr, uint32_t* sync,
+                     void* stream);
 
 /*
  * north_star's "BPR loss + SGD update": torch.optim.SGD(lr) defaults (no momentum, no weight decay) in place of

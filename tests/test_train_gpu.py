@@ -593,12 +593,15 @@ def test_lazy_adam_replay_is_bitwise_dense_adam(d, B):
 @pytest.mark.parametrize("d,n_rec,B,n_u,n_i", [(128, 3 * 512 + 77, 512, 300, 500), (64, 4 * 300, 300, 300, 500),
                                                (200, 700, 256, 300, 500), (8, 5000, 4096, 300, 500),
                                                (128, 2 * 2048 + 9, 2048, 12000, 9000)])   # rows > 2048 blocks x 8: stride loop
-def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B, n_u, n_i):
+@pytest.mark.parametrize("launches", ["epoch", "steps"])
+def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B, n_u, n_i, launches, monkeypatch):
     """crh_mf_step_f32 (one launch per step: recomputed score differences, Adam in registers, norms of the next
-    batch from the updated rows) against forward + plan backward + dense Adam: same losses and tables up to the
-    fp32 summation order of the three norms; bit-reproducible; hot items exercise the heavy-row blocks; odd and
-    even step counts exercise the ping-pong copy-back; the last batch is short."""
+    batch from the updated rows) and crh_mf_epoch_f32 (one launch per EPOCH: the rows stay in registers, grid barrier
+    between the steps; tables whose workgroups are all resident) against forward + plan backward + dense Adam: same
+    losses and tables up to the fp32 summation order of the three norms; bit-reproducible; hot items exercise the
+    heavy-row paths; odd and even step counts exercise the ping-pong copy-back; the last batch is short."""
     from coldrec_amd.train import EpochRunner, MFEngine
+    monkeypatch.setenv("CRH_MF_EPOCH", "1" if launches == "epoch" else "0")
     rng = np.random.default_rng(d + B)
     U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
     V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
@@ -615,8 +618,12 @@ def test_fused_mf_step_matches_three_kernel_step(d, n_rec, B, n_u, n_i):
         eng = MFEngine(U0, V0, 1e-2, 1e-3, DEV)
         runner = EpochRunner(eng, n_rec, B, fused=fused)
         assert eng.fused == fused
+        if fused:       # one launch per epoch iff asked for AND the table's workgroups fit the chip (12 288 rows at d = 128)
+            assert (eng._eblocks > 0) == (launches == "epoch" and n_u + n_i <= 12000)
         losses = [runner.run(*ep).clone() for ep in epochs]           # eager, captured + replayed, replayed
         torch.cuda.synchronize()
+        if fused and eng._eblocks:
+            assert not eng._esync.cpu().any()         # counters back at zero, no barrier timed out
         runs[tag] = (torch.cat(losses).cpu().numpy(), eng.E.cpu().numpy(), eng.M.cpu().numpy(), eng.V.cpu().numpy(),
                      eng.step_count)
     for a, b in zip(runs["fused"][:4], runs["fused2"][:4]):
