@@ -123,11 +123,29 @@ __device__ __forceinline__ void batch_totals(const BprArgs& a, float* tot, float
     if (a.totals) {
         if (threadIdx.x < 4) tot[threadIdx.x] = a.totals[threadIdx.x];
     } else {
-        for (int q = 0; q < 4; ++q) {
-            float s = 0.f;
-            for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) s += a.partials[(size_t)i * 4 + q];
-            s = block_sum(s, red);
-            if (threadIdx.x == 0) tot[q] = s;
+        // the four sums in ONE pass over the partials (16-byte loads) and one reduction: component by component the
+        // arithmetic of block_sum over a thread-strided sum, i.e. the same bits as four separate passes -- which were four
+        // dependent memory round trips at the head of every backward launch
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int i = threadIdx.x; i < a.nblocks_fwd; i += BPR_THREADS) {
+            const f32x4 x = reinterpret_cast<const f32x4*>(a.partials)[i];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s.x += __shfl_xor(s.x, off); s.y += __shfl_xor(s.y, off);
+            s.z += __shfl_xor(s.z, off); s.w += __shfl_xor(s.w, off);
+        }
+        __shared__ f32x4 red4[4];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const f32x4 t0 = red4[0], t1 = red4[1], t2 = red4[2], t3 = red4[3];
+            tot[0] = (t0.x + t1.x) + (t2.x + t3.x);
+            tot[1] = (t0.y + t1.y) + (t2.y + t3.y);
+            tot[2] = (t0.z + t1.z) + (t2.z + t3.z);
+            tot[3] = (t0.w + t1.w) + (t2.w + t3.w);
         }
     }
     __syncthreads();
@@ -349,9 +367,10 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a, in
     __shared__ float red[4];
     __shared__ float tot[4];
     __shared__ f32x4 wsum[4][G];
+    // the plan's header and (heavy workgroups) its heavy count are in flight while the batch sums are reduced
     const PlanView pv = plan_view(a.plan);
-    if ((int)blockIdx.x >= light_blocks && (int)blockIdx.x - light_blocks >= pv.n_heavy) return;   // surplus block
     batch_totals(a, tot, red);
+    if ((int)blockIdx.x >= light_blocks && (int)blockIdx.x - light_blocks >= pv.n_heavy) return;   // surplus block
     const BwdCoef k = bwd_coef(a, tot);
     const int lig = threadIdx.x % G;
     const int nvec = a.d >> 2;
@@ -2041,6 +2060,7 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
         crh_set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, crh_bpr_workspace_bytes(batch));
         return CRH_ERR_WS;
     }
+    CRH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "%s: the workspace must be 16-byte aligned", who);
     BprArgs a;
     a.tu = user_table; a.tp = pos_table; a.tn = neg_table;
     a.iu = user_idx; a.ip = pos_idx; a.in_ = neg_idx;
