@@ -167,6 +167,8 @@ def case_fused(rng):
         j = np.where(j == i, (j + 1) % n_i, j).astype(np.int32)
         epochs.append((u, i, j))
     res = []
+    # half of the cases run the epoch as ONE launch (crh_mf_epoch_f32; the product default is one launch per step)
+    os.environ["CRH_MF_EPOCH"] = "1" if rng.random() < 0.5 else "0"
     for fused in (True, True, False):
         eng = MFEngine(U0, V0, 1e-2, 1e-3, DEV)
         runner = EpochRunner(eng, n_rec, B, fused=fused)
