@@ -238,8 +238,9 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* __restrict__ S, i
 // chunk and the user's rated ids are OR-ed into a per-wave bitmap in LDS (the rated list is ascending: one walk per
 // row) -- and only then looks for candidates: the k-th largest of the 64 lane maxima (a 32-step radix select on
 // ballots) is a lower bound of the chunk's k-th best score, because the k lanes at or above it hold k different items.
-// Items below it cannot be in the row's top k; what is left is ~k items per chunk instead of ~k ln(chunk / k), and
-// they go through the same list insertion (canonical order, exact ties).  Chunks whose raw maximum cannot beat the
+// Items below it cannot be in the row's top k; what is left is ~k items per chunk instead of ~k ln(chunk / k); they
+// and the list are merged by a rank sort across the lanes (or, when they outnumber the lanes, go through the same list
+// insertion as above) -- canonical order, exact ties either way.  Chunks whose raw maximum cannot beat the
 // list are skipped before any mask work, so a long row streams as before.  Read-only (write_back = 0), k <= 64.
 __device__ __forceinline__ unsigned order_key(float f) {
     const unsigned b = __builtin_bit_cast(unsigned, f);
@@ -261,10 +262,12 @@ __global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __res
     constexpr int CH = 256 * NV, WORDS = 8 * NV;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float* ls = reinterpret_cast<float*>(smem) + (size_t)wave * (2 * K + 4 + WORDS);
+    float* ls = reinterpret_cast<float*>(smem) + (size_t)wave * (2 * K + 4 + WORDS + 128);
     int* li = reinterpret_cast<int*>(ls + K);
     int* cnt = li + K;
     unsigned* bm = reinterpret_cast<unsigned*>(cnt + 4);
+    float* cs = reinterpret_cast<float*>(bm + WORDS);          // candidates of a chunk: 64 scores, 64 ids
+    int* ci = reinterpret_cast<int*>(cs + 64);
     const bool have_masks = bitmap != nullptr || rated_rowptr != nullptr;
     const int64_t last_word = bitmap ? (item_base + n_items - 1) >> 5 : 0;
 
@@ -343,6 +346,65 @@ __global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __res
                 if (__popcll(__ballot(mk >= t)) >= K) cur = t;
             }
             const float tau0 = order_key_inv(cur);
+            // The chunk's candidates (>= tau0, and > the list's k-th score: list entries come from earlier chunks, i.e. lower
+            // ids) are compacted into LDS; if they and the list fit one entry per lane, the new list is a RANK SORT of the
+            // union -- every lane counts the entries that beat its own (canonical order, ids are distinct) and stores it at
+            // that rank -- instead of one wave-serial insertion per candidate.
+            {
+                int nc = 0;
+                const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int64_t e0 = base + u * 256 + lane * 4;
+                    const float mu = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
+                    if (__ballot(mu >= tau0 && mu > tau) == 0ull) continue;
+                    const float vc[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool pr = vc[c] >= tau0 && vc[c] > tau && e0 + c < n_items;
+                        const unsigned long long bal = __ballot(pr);
+                        if (pr) {
+                            const int pos = nc + __popcll(bal & lt);
+                            if (pos < 64) {
+                                cs[pos] = vc[c];
+                                ci[pos] = (int)(item_base + e0 + c);
+                            }
+                        }
+                        nc += __popcll(bal);
+                    }
+                }
+                if (nc == 0) continue;
+                const int n = __builtin_amdgcn_readfirstlane(*cnt);
+                if (n + nc <= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int tot_n = n + nc;
+                    float ms = CRH_NEG_INF;
+                    int mi = CRH_PAD_IDX;
+                    if (lane < n) {
+                        ms = ls[lane];
+                        mi = li[lane];
+                    } else if (lane < tot_n) {
+                        ms = cs[lane - n];
+                        mi = ci[lane - n];
+                    }
+                    int rank = 0;
+                    for (int j = 0; j < tot_n; ++j) {
+                        const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), j));
+                        const int ij = __builtin_amdgcn_readlane(mi, j);
+                        rank += crh_better(sj, ij, ms, mi) ? 1 : 0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < tot_n && rank < K) {
+                        ls[rank] = ms;
+                        li[rank] = mi;
+                    }
+                    if (lane == 0) *cnt = tot_n < K ? tot_n : K;
+                    __builtin_amdgcn_wave_barrier();
+                    tau = wave_list_tau(ls, *cnt, K);
+                    continue;
+                }
+            }
+            // (more candidates than lanes: one by one)
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int64_t e0 = base + u * 256 + lane * 4;
@@ -417,7 +479,7 @@ extern "C" int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items
     static const int64_t chunk_items = getenv("CRH_MASK_CHUNK_ITEMS") ? atoll(getenv("CRH_MASK_CHUNK_ITEMS")) : 65536;
     if (!write_back && k <= 64 && n_items <= chunk_items && !(n_users < wpr_rows && n_items >= 8192)) {
         constexpr int NV = 16;
-        const size_t lds_c = (size_t)4 * (2 * k + 4 + 8 * NV) * 4;
+        const size_t lds_c = (size_t)4 * (2 * k + 4 + 8 * NV + 128) * 4;
         int64_t blocks = (n_users + 3) / 4;
         if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL((mask_topk_chunk_kernel<NV>), dim3((unsigned)blocks), dim3(256), lds_c, st, scores, n_users, n_items,
