@@ -1102,6 +1102,12 @@ int dispatch_group(int g, F&& f) {
 #ifndef MF_ROWS_N
 #define MF_ROWS_N 2
 #endif
+#ifndef MF_NQ_N
+#define MF_NQ_N 2          // entries whose gathered rows are in flight together in the one-launch step (2 or 4)
+#endif
+#ifndef MF_OCC_N
+#define MF_OCC_N 4         // waves per SIMD the one-launch step is compiled for
+#endif
 constexpr int MF_MAX_LIGHT = 2048, MF_HEAVY_BLOCKS = MF_HEAVY_BLOCKS_N, MF_ROWS = MF_ROWS_N;     // (tuning builds: -D..._N)
 
 struct MfStepArgs {
@@ -1313,7 +1319,7 @@ __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, 
 // OPT = 0: torch.optim.Adam (m, v in place); OPT = 1: plain SGD -- no optimiser state at all, a row costs one read and
 // one write of p (8 B per element instead of 24)
 template <int G, int OPT>
-__global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
+__global__ __launch_bounds__(BPR_THREADS, MF_OCC_N) void mf_step_kernel(MfStepArgs a) {
     __shared__ f32x4 red4[4];
     __shared__ float red[4];
     __shared__ f32x4 wsum[4][G];
@@ -1430,7 +1436,7 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
             if (rg.y - rg.x > BPR_HEAVY) continue;                // a heavy block does this row, Adam included
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float loss = 0.f;
-            if (rg.y > rg.x) mf_row_entries<G>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
+            if (rg.y > rg.x) mf_row_entries<G, false, MF_NQ_N>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
             if (lig == 0) sl += loss;
             mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn, rg.y > rg.x);
         }
@@ -1451,7 +1457,7 @@ __global__ __launch_bounds__(BPR_THREADS, 4) void mf_step_kernel(MfStepArgs a) {
             own = acc;
             if (on) own = reinterpret_cast<const f32x4*>(a.pin + row * a.d)[lig];
             float loss = 0.f;
-            if (e0 < hr.y) mf_row_entries<G>(a, k, user_side, e0, e1, on, lig, own, acc, loss);
+            if (e0 < hr.y) mf_row_entries<G, false, MF_NQ_N>(a, k, user_side, e0, e1, on, lig, own, acc, loss);
             if (lig == 0) sl += loss;
 #pragma unroll
             for (int off = G; off < 64; off <<= 1) {
