@@ -148,6 +148,9 @@ def case_adam(rng):
             fail("lazy adam", what=name, d=d, B=B)
 
 
+FORCE = {}      # --force '{"d": 200, "B": 1000, ...}': pins case_fused's shape (reproducing a reported case's class)
+
+
 def case_fused(rng):
     from coldrec_amd.train import EpochRunner
     d = int(rng.choice([4, 16, 64, 128, 200, 256]))
@@ -159,8 +162,14 @@ def case_fused(rng):
     U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
     V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
     hot_frac = float(rng.choice([0.0, 0.3, 0.95]))
+    n_epochs = int(rng.integers(1, 4))
+    if FORCE:
+        d, n_u, n_i, B, n_rec = (int(FORCE.get(k, v)) for k, v in (("d", d), ("n_u", n_u), ("n_i", n_i), ("B", B), ("n_rec", n_rec)))
+        hot_frac, n_epochs = float(FORCE.get("hot", hot_frac)), int(FORCE.get("epochs", n_epochs))
+        U0 = (rng.standard_normal((n_u, d)) * 0.1).astype(np.float32)
+        V0 = (rng.standard_normal((n_i, d)) * 0.1).astype(np.float32)
     epochs = []
-    for _ in range(int(rng.integers(1, 4))):
+    for _ in range(n_epochs):
         u = rng.integers(0, n_u, n_rec).astype(np.int32)
         i = np.where(rng.random(n_rec) < hot_frac, rng.integers(0, min(3, n_i), n_rec), rng.integers(0, n_i, n_rec)).astype(np.int32)
         j = rng.integers(0, n_i, n_rec).astype(np.int32)
@@ -169,6 +178,8 @@ def case_fused(rng):
     res = []
     # half of the cases run the epoch as ONE launch (crh_mf_epoch_f32; the product default is one launch per step)
     os.environ["CRH_MF_EPOCH"] = "1" if rng.random() < 0.5 else "0"
+    if "epoch_launch" in FORCE:
+        os.environ["CRH_MF_EPOCH"] = str(int(FORCE["epoch_launch"]))
     for fused in (True, True, False):
         eng = MFEngine(U0, V0, 1e-2, 1e-3, DEV)
         runner = EpochRunner(eng, n_rec, B, fused=fused)
@@ -195,6 +206,8 @@ def case_fused(rng):
             step, eps32 = 0, float(np.finfo(np.float32).eps)
             a_max = np.zeros((n_u + n_i, d))
             noisy = np.zeros((n_u + n_i, d), bool)
+            cond = np.full((n_u + n_i, d), np.inf)        # smallest |g| / (eps32 * A) an element saw in any step
+            tainted = np.zeros((n_u + n_i, d), bool)      # noisy elements + same-column elements downstream of them
             for (eu, ei, ej) in epochs:
                 for lo in range(0, n_rec, B):
                     sl = slice(lo, min(lo + B, n_rec))
@@ -204,7 +217,18 @@ def case_fused(rng):
                     np.add.at(A, n_u + ei[sl].astype(np.int64), np.abs(tp))
                     np.add.at(A, n_u + ej[sl].astype(np.int64), np.abs(tn))
                     g = np.concatenate([gU, gV])
+                    # information flow: this step's gradient of u_c is sum g_b (p_c - n_c) (+ reg), that of p_c is g_b u_c: an
+                    # element that was noise in an EARLIER step has, by now, moved its row by something in [-lr, lr] per
+                    # step, and the same column of every row it shares a triple with inherits a (much smaller) share of that
+                    pu, pp, pn = eu[sl].astype(np.int64), n_u + ei[sl].astype(np.int64), n_u + ej[sl].astype(np.int64)
+                    t_u, t_p, t_n = tainted[pu], tainted[pp], tainted[pn]
+                    np.logical_or.at(tainted, pu, t_p | t_n)
+                    np.logical_or.at(tainted, pp, t_u)
+                    np.logical_or.at(tainted, pn, t_u)
                     noisy |= (A > 0) & (np.abs(g) <= 4.0 * d * eps32 * A)
+                    tainted |= noisy
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        cond = np.minimum(cond, np.where(A > 0, np.abs(g) / (eps32 * A), np.inf))
                     a_max = np.maximum(a_max, A)
                     step += 1
                     E, M, V = orc.adam_dense(E, g.astype(np.float32), M, V, step, lr=1e-2)
@@ -213,6 +237,11 @@ def case_fused(rng):
             ea, eb = float(np.abs(a - ref).max()), float(np.abs(b - ref).max())
             print("rows with differences:", rows[:10], "of", n_u, "+", n_i, "| fused vs oracle", ea, "| plain vs oracle", eb,
                   "| noise-floor elements among them:", int((bad & noisy).sum()), "of", int(bad.sum()), flush=True)
+            idx = np.argwhere(bad & ~tainted)[:16]
+            print("  downstream (tainted) elements among them:", int((bad & tainted & ~noisy).sum()), flush=True)
+            print("  elements beyond the noise rule (row, col, smallest |g|/(eps A) seen, |fused-ref|, |plain-ref|, |fused-plain|):",
+                  [(int(r), int(c), float("%.3g" % cond[r, c]), float("%.2g" % abs(a[r, c] - ref[r, c])),
+                    float("%.2g" % abs(b[r, c] - ref[r, c])), float("%.2g" % abs(a[r, c] - b[r, c]))) for r, c in idx], flush=True)
             if name == "M":
                 # m is linear in the gradients: an ABSOLUTE bound for each form on its own (a convex combination of the
                 # steps' gradients, each good to ~d * eps32 * A) -- the one-launch step gets no credit for the
@@ -220,11 +249,14 @@ def case_fused(rng):
                 tol = 8.0 * d * eps32 * a_max + 1e-12
                 if (np.abs(a - ref) <= tol).all() and (np.abs(b - ref) <= tol).all():
                     continue
-            elif not (bad & ~noisy).any():
+            elif not (bad & ~tainted).any() and np.abs(a - b)[tainted & ~noisy].max(initial=0.0) <= 0.02 * 1e-2 * n_steps:
                 # E and V are not linear in g; the only elements excused are those whose gradient sat on its own noise
-                # floor in some step (seed 42 of round 2: 9 of 85 504 elements on a 50 x 284 table)
+                # floor in some step (seed 42 of round 2: 9 of 85 504 elements on a 50 x 284 table) and, to 2 % of what the
+                # steps can move an element, the same column of the rows such an element reaches through later triples
+                # (seed 52 of round 3: ONE noise-floor element of a hot item's row -- 950 of 1 000 positives on 3 items --
+                # and column 99 of 13 users who rated that item, 1e-5 apart; per-step launch and three-kernel step)
                 continue
-            fail("fused tables", table=name, d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
+            fail("fused tables", table=name, epoch_launch=os.environ["CRH_MF_EPOCH"], d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
                  err=float(np.abs(a - b).max()), scale=float(np.abs(b).max()), nbad=int(bad.sum()))
 
 
@@ -232,12 +264,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="", help="run only this kind of case (bpr / spmm / adam / fused)")
+    ap.add_argument("--force", default="", help="JSON: pin the shape of the fused case (d, n_u, n_i, B, n_rec, hot, epochs, epoch_launch)")
     args = ap.parse_args()
+    if args.force:
+        import json
+        FORCE.update(json.loads(args.force))
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.minutes * 60
     counts = {"bpr": 0, "spmm": 0, "adam": 0, "fused": 0}
     while time.time() < t_end:
-        which = str(rng.choice(["bpr", "spmm", "adam", "fused"]))
+        which = args.only or str(rng.choice(["bpr", "spmm", "adam", "fused"]))
         {"bpr": case_bpr, "spmm": case_spmm, "adam": case_adam, "fused": case_fused}[which](rng)
         counts[which] += 1
     print(f"fuzz ok: {counts} random cases within parity, seed {args.seed}")
