@@ -1018,8 +1018,9 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 
 // esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
 // Route of a call (n_splits == 0; a caller that names a split count gets the plain fused selection):
-//   seeded  : users that do not fill the chip on their own (the unseeded picker would cut the item range) and a catalogue of
-//             >= 65 536 items: rank a prefix by the dense route, then the fused selection over the rest, lists seeded;
+//   seeded  : a catalogue of >= 65 536 items and either users that do not fill the chip on their own (the unseeded picker
+//             would cut the item range) or, fp32, at most 2^20 items: rank a prefix by the dense route, then the fused
+//             selection over the rest, lists seeded;
 //   dense   : small catalogues (score block + wave-per-user ranking);
 //   fused   : everything else (the headline).
 int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
@@ -1035,10 +1036,16 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
         const int upw = users_per_wave(esz, d);
         const int64_t n_ug = (n_users + upw - 1) / upw;
         const bool cuts = pick_splits(n_ug, n_items, 2) > 1;          // the users alone do not fill the wave slots
+        // ... and fp32 catalogues up to 2^20 items whatever the user count: the warm-up insertions of the fused selection
+        // (three quarters of k (1 + ln(N / k)) fall into the first 20 000 items) are a visible share of a user's work while
+        // N is small -- 131 072 x 262 144: 0.749 -> 0.781 of the fp32-MFMA peak, x 1 048 576: 0.842 -> 0.852; at 1.25 M
+        // items the prefix stage costs more than it saves (0.850 -> 0.838).  CRH_SCORE_SEED_MAX_ITEMS moves the limit.
+        const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
+        const bool small_cat = esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1 << 20);
         const size_t sb = seed_bytes(n_users, k);
         const size_t stage1 = dense_block_bytes(n_users, P) + packed_bytes(P, d, esz);
         const size_t stage2 = lists_bytes(n_users, k) + packed_bytes(n_items - P, d, esz);
-        if ((cuts || seed_mode == 2) && dense_block_bytes(n_users, P) > 0 && workspace_bytes >= sb + std::max(stage1, stage2)) {
+        if ((cuts || small_cat || seed_mode == 2) && dense_block_bytes(n_users, P) > 0 && workspace_bytes >= sb + std::max(stage1, stage2)) {
             float* seed_s = reinterpret_cast<float*>(workspace);
             int32_t* seed_i = reinterpret_cast<int32_t*>(seed_s + (size_t)n_users * k);
             void* ws2 = reinterpret_cast<char*>(workspace) + sb;
