@@ -576,3 +576,39 @@ def test_seeded_route_is_what_the_dispatcher_picks_for_few_users_on_a_large_cata
     ws, wi = orc.score_topk(U.cpu().numpy(), pick.astype(np.int64), V.cpu().numpy(), k, sub_rp, sub_col,
                             orc.make_bitmap(n_items, cold))
     assert np.array_equal(i0.cpu().numpy()[pick], wi) and np.array_equal(s0.cpu().numpy()[pick].view(np.uint32), ws.view(np.uint32))
+
+
+def test_seeded_route_for_users_that_fill_the_chip_on_a_catalogue_below_2_20_items(monkeypatch):
+    """131 072 users x 70 001 items: no item-range cut is needed, but fp32 catalogues of 65 536 .. 2^20 items are seeded
+    whatever the user count (score_topk_any).  The dispatcher's choice must equal the plain fused selection
+    (CRH_SCORE_SEED=0) bit for bit for EVERY user -- rated lists of 0 .. 30 ids, 20 % bitmap, quantised tables (exact
+    ties across the prefix boundary) -- and sampled users equal the oracle."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(18)
+    n_users, n_items, d, k = 131072, 70001, 8, 20
+    DEV = _dev()
+    U = torch.from_numpy((rng.integers(-4, 5, (n_users, d)) / 4).astype(np.float32)).to(DEV)
+    V = torch.from_numpy((rng.integers(-4, 5, (n_items, d)) / 4).astype(np.float32)).to(DEV)
+    lens = rng.integers(0, 31, n_users)
+    flat = rng.integers(0, n_items, int(lens.sum()))
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rated = [np.unique(flat[rowptr[u]:rowptr[u + 1]]) for u in range(n_users)]
+    rp, rc = ops.rated_csr(rated, DEV)
+    cold = np.where(rng.random(n_items) < 0.2)[0]
+    bm = ops.make_bitmap(n_items, cold, DEV)
+    monkeypatch.delenv("CRH_SCORE_SEED", raising=False)
+    s0, i0 = ops.score_topk(U, None, V, k, rp, rc, bm)                      # dispatcher: seeded (prefix 4 375 -> 4 096 .. items)
+    monkeypatch.setenv("CRH_SCORE_SEED", "0")
+    s1, i1 = ops.score_topk(U, None, V, k, rp, rc, bm)                      # plain fused selection
+    monkeypatch.setenv("CRH_SCORE_SEED_MAX_ITEMS", "1000")
+    monkeypatch.delenv("CRH_SCORE_SEED", raising=False)
+    s2, i2 = ops.score_topk(U, None, V, k, rp, rc, bm)                      # the limit switch takes the route away again
+    torch.cuda.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    assert torch.equal(i2, i1) and torch.equal(s2.view(torch.int32), s1.view(torch.int32))
+    pick = np.array([0, 63, 64, 65535, 65536, 100001, n_users - 1])
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    ws, wi = orc.score_topk(U.cpu().numpy(), pick.astype(np.int64), V.cpu().numpy(), k, sub_rp, sub_col,
+                            orc.make_bitmap(n_items, cold))
+    assert np.array_equal(i0.cpu().numpy()[pick], wi) and np.array_equal(s0.cpu().numpy()[pick].view(np.uint32), ws.view(np.uint32))
