@@ -1019,8 +1019,8 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 // esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
 // Route of a call (n_splits == 0; a caller that names a split count gets the plain fused selection):
 //   seeded  : a catalogue of >= 65 536 items and either users that do not fill the chip on their own (the unseeded picker
-//             would cut the item range) or, fp32, at most 2^20 items: rank a prefix by the dense route, then the fused
-//             selection over the rest, lists seeded;
+//             would cut the item range; prefix 1/16 of the catalogue, 4 096 .. 16 384 items) or, fp32, fewer than 2 M items
+//             (prefix 4 096 items): rank the prefix by the dense route, then the fused selection over the rest, lists seeded;
 //   dense   : small catalogues (score block + wave-per-user ranking);
 //   fused   : everything else (the headline).
 int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
@@ -1030,18 +1030,21 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
                    void* ev_kernel_stop, const char* who) {
     const char* sm = getenv("CRH_SCORE_SEED");                       // read per call: 0 never, 1 auto (default), 2 whenever possible
     const int seed_mode = sm ? atoi(sm) : 1;
-    const int64_t P = seed_prefix_items(n_items);
+    int64_t P = seed_prefix_items(n_items);
     if (seed_mode && n_splits == 0 && P > 0 && user_emb && item_emb && out_score && out_idx && n_users > 0 && k >= 1 &&
         k <= CRH_MAX_K && workspace) {
         const int upw = users_per_wave(esz, d);
         const int64_t n_ug = (n_users + upw - 1) / upw;
         const bool cuts = pick_splits(n_ug, n_items, 2) > 1;          // the users alone do not fill the wave slots
-        // ... and fp32 catalogues up to 2^20 items whatever the user count: the warm-up insertions of the fused selection
-        // (three quarters of k (1 + ln(N / k)) fall into the first 20 000 items) are a visible share of a user's work while
-        // N is small -- 131 072 x 262 144: 0.749 -> 0.781 of the fp32-MFMA peak, x 1 048 576: 0.842 -> 0.852; at 1.25 M
-        // items the prefix stage costs more than it saves (0.850 -> 0.838).  CRH_SCORE_SEED_MAX_ITEMS moves the limit.
+        // ... and fp32 catalogues the per-wave kernel ranks (below 2 M items) whatever the user count: the warm-up insertions
+        // of the fused selection (three quarters of k (1 + ln(N / k)) fall into the first 20 000 items) are a visible share of
+        // a user's work.  With MANY users the prefix stage is what costs (users x prefix scores written and ranked), and
+        // modest seeds do: a 4 096-item prefix -- 131 072 x 262 144: 0.749 -> 0.799 of the fp32-MFMA peak (16 384-item
+        // prefix: 0.783), x 1 048 576: 0.842 -> 0.859, x 1 250 000 (one rank's shard of the 8-GPU split): 0.853 -> 0.863
+        // (16 384: 0.838).  CRH_SCORE_SEED_MAX_ITEMS moves the limit, CRH_SCORE_SEED_ITEMS fixes the prefix for both cases.
         const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
-        const bool small_cat = esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1 << 20);
+        const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1999999);
+        if (small_cat && !getenv("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
         const size_t sb = seed_bytes(n_users, k);
         const size_t stage1 = dense_block_bytes(n_users, P) + packed_bytes(P, d, esz);
         const size_t stage2 = lists_bytes(n_users, k) + packed_bytes(n_items - P, d, esz);
