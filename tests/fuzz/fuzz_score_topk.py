@@ -27,7 +27,7 @@ def main():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.minutes * 60
-    n_cases = n_big = 0
+    n_cases = n_big = n_seeded = n_many = 0
     while time.time() < t_end:
         half = rng.random() < 0.35
         d = int(rng.choice([16, 32, 64, 128, 256] if half else [8, 16, 32, 64, 128, 256, 24, 100]))
@@ -35,6 +35,16 @@ def main():
         big = rng.random() < 0.15                       # workgroup-kernel territory
         n_users = int(rng.integers(32768, 34000)) if big else int(rng.integers(1, 700))
         n_items = int(rng.integers(1, 3000)) if big else int(rng.integers(1, 40000))
+        # seeded-route territory (catalogues of >= 65 536 items: score_topk_any ranks a prefix by the dense route and seeds the
+        # fused selection with it): few users (the item range is cut; prefix = 1/16 of the catalogue) or, fp32, users that fill
+        # the chip on their own (no cuts; 4 096-item prefix)
+        seeded = (not big) and rng.random() < 0.05
+        many = seeded and rng.random() < 0.4
+        if seeded:
+            n_items = int(rng.integers(65536, 80000))
+            if many:
+                half, n_users = False, 131072 + int(rng.integers(0, 200))
+            d = 16 if half else int(rng.choice([8, 16]))
         quant = half or rng.random() < 0.5              # exact arithmetic / heavy ties
         if quant:
             q = int(rng.choice([2, 4, 8]))
@@ -46,15 +56,19 @@ def main():
         base = int(rng.choice([0, 0, 31, 4096, 100003]))
         n_glob = base + n_items + int(rng.integers(0, 100))
         mean_r = int(rng.choice([0, 3, 30, 200]))
+        if many:
+            mean_r = min(mean_r, 3)
         rated = [np.unique(rng.integers(base, base + n_items, rng.poisson(mean_r))) if mean_r else np.zeros(0, np.int64)
                  for _ in range(n_users)]
         rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
         col = np.concatenate(rated).astype(np.int64) if rowptr[-1] else np.zeros(0, np.int64)
         frac = float(rng.choice([0.0, 0.05, 0.2, 0.9, 1.0]))
         bm_ids = np.where(rng.random(n_glob) < frac)[0] if frac else None
-        use_idx = rng.random() < 0.5 and not big
+        use_idx = rng.random() < 0.5 and not big and not many
         users = rng.permutation(n_users)[: max(1, n_users // 2)].astype(np.int64) if use_idx else None
         splits = int(rng.choice([0, 0, 1, 2, 7]))
+        if seeded:
+            splits = 0                                   # a caller that names a split count gets the plain fused selection
         # fp32 launches take the workgroup kernel from 2 M items only; CRH_SCORE_WG=2 (read per call) forces it here
         if big and rng.random() < 0.6:
             os.environ["CRH_SCORE_WG"] = "2"
@@ -90,13 +104,16 @@ def main():
         gs, gi = s.cpu().numpy()[pick], i.cpu().numpy()[pick]
         ok = np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
         if not ok:
-            print("MISMATCH", dict(half=half, d=d, k=k, n_users=n_users, n_items=n_items, quant=quant, base=base,
+            print("MISMATCH", dict(half=half, d=d, k=k, n_users=n_users, n_items=n_items, quant=quant, base=base, seeded=seeded,
                                    mean_r=mean_r, frac=frac, use_idx=use_idx, splits=splits, pack=pack, seed=args.seed,
                                    case=n_cases), flush=True)
             sys.exit(1)
         n_cases += 1
         n_big += big
-    print(f"fuzz ok: {n_cases} random cases ({n_big} in workgroup-kernel territory) bit-exact vs the oracle, seed {args.seed}")
+        n_seeded += seeded
+        n_many += many
+    print(f"fuzz ok: {n_cases} random cases ({n_big} in workgroup-kernel territory, {n_seeded} in seeded-route territory of which "
+          f"{n_many} with users that fill the chip) bit-exact vs the oracle, seed {args.seed}")
 
 
 if __name__ == "__main__":
