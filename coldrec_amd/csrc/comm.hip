@@ -133,13 +133,56 @@ extern "C" int crh_comm_allreduce_f32(crh_comm* c, float* buf, int64_t n, void* 
 
 // Exchange step of the item-row-sharded evaluation: every rank contributes its shard's (n_users, k) scores and global
 // ids; gathered_* are laid out [rank][user][k] -- exactly crh_merge_topk's input with n_lists = world.
+// ONE collective: the rank's lists are packed into (n_users, 2k) 32-bit words (k score bit patterns, then k ids, per
+// user -- the layout coldrec_amd/eval.py sends through torch.distributed), one ncclAllGather of int32 moves them, and the
+// gathered words are split back into the two arrays.  xGMI is point-to-point: a second collective would pay the
+// launch + ring latency twice for a payload (8 k bytes per user) that is latency-bound to begin with.
+namespace {
+
+__global__ void pack_topk_kernel(const float* __restrict__ score, const int32_t* __restrict__ idx, int64_t n, int k,
+                                 int32_t* __restrict__ packed) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one (user, slot) word pair
+    if (t >= n * k) return;
+    const int64_t u = t / k;
+    const int j = (int)(t - u * k);
+    packed[u * 2 * k + j] = __float_as_int(score[t]);
+    packed[u * 2 * k + k + j] = idx[t];
+}
+
+__global__ void unpack_topk_kernel(const int32_t* __restrict__ gathered, int64_t rows, int k, float* __restrict__ score,
+                                   int32_t* __restrict__ idx) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // rows = world * n_users
+    if (t >= rows * k) return;
+    const int64_t r = t / k;
+    const int j = (int)(t - r * k);
+    score[t] = __int_as_float(gathered[r * 2 * k + j]);
+    idx[t] = gathered[r * 2 * k + k + j];
+}
+
+}  // namespace
+
+extern "C" size_t crh_comm_allgather_topk_workspace_bytes(int world, int64_t n_users, int k) {
+    if (world < 1 || n_users < 0 || k < 1) return 0;
+    return (size_t)(world + 1) * (size_t)n_users * 2 * (size_t)k * sizeof(int32_t);
+}
+
 extern "C" int crh_comm_allgather_topk(crh_comm* c, const float* score, const int32_t* idx, int64_t n_users, int k,
-                                       float* gathered_score, int32_t* gathered_idx, void* stream) {
+                                       float* gathered_score, int32_t* gathered_idx, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     CRH_CHECK_ARG(c && score && idx && gathered_score && gathered_idx && n_users > 0 && k >= 1 && k <= CRH_MAX_K,
                   "crh_comm_allgather_topk: bad arguments");
+    CRH_CHECK_ARG(workspace && workspace_bytes >= crh_comm_allgather_topk_workspace_bytes(c->world, n_users, k),
+                  "crh_comm_allgather_topk: workspace smaller than crh_comm_allgather_topk_workspace_bytes()");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t n = (size_t)n_users * k;
-    CRH_NCCL(g_rccl.AllGather(score, gathered_score, n, ncclFloat32, c->comm, st), "crh_comm_allgather_topk");
-    CRH_NCCL(g_rccl.AllGather(idx, gathered_idx, n, ncclInt32, c->comm, st), "crh_comm_allgather_topk");
+    const int64_t n = n_users * k;
+    int32_t* mine = static_cast<int32_t*>(workspace);                       // (n_users, 2k)
+    int32_t* all = mine + 2 * n;                                            // (world, n_users, 2k)
+    hipLaunchKernelGGL(pack_topk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, score, idx, n_users, k, mine);
+    CRH_HIP(hipGetLastError());
+    CRH_NCCL(g_rccl.AllGather(mine, all, (size_t)(2 * n), ncclInt32, c->comm, st), "crh_comm_allgather_topk");
+    const int64_t rows = n_users * c->world;
+    hipLaunchKernelGGL(unpack_topk_kernel, dim3((unsigned)((rows * k + 255) / 256)), dim3(256), 0, st, all, rows, k,
+                       gathered_score, gathered_idx);
+    CRH_HIP(hipGetLastError());
     return CRH_OK;
 }

@@ -1016,6 +1016,33 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
                     void* workspace, size_t workspace_bytes, void* stream, int n_splits, void* ev_kernel_start,
                     void* ev_kernel_stop, const char* who, const float* seed_score, const int32_t* seed_idx);
 
+// Does a call of this shape take the seeded route (n_splits == 0), and with which prefix?  0 = no.  ONE predicate for the
+// dispatcher (score_topk_any) and for the workspace query (full_workspace_bytes): a shape that never seeds must not be
+// charged the prefix's dense block (131 072 x 262 144 asked for 8.6 GB instead of 1.5 GB).
+//   cuts      : the users alone do not fill the wave slots (the unseeded picker would cut the item range);
+//   small_cat : fp32 catalogues the per-wave kernel ranks (below 2 M items) whatever the user count: the warm-up insertions
+//               of the fused selection (three quarters of k (1 + ln(N / k)) fall into the first 20 000 items) are a visible
+//               share of a user's work.  With MANY users the prefix stage is what costs (users x prefix scores written and
+//               ranked), and modest seeds do: a 4 096-item prefix -- 131 072 x 262 144: 0.749 -> 0.799 of the fp32-MFMA
+//               peak (16 384-item prefix: 0.783), x 1 048 576: 0.842 -> 0.859, x 1 250 000 (one rank's shard of the 8-GPU
+//               split): 0.853 -> 0.863 (16 384: 0.838).
+// CRH_SCORE_SEED (read per call): 0 never, 1 auto (default), 2 whenever possible; CRH_SCORE_SEED_MAX_ITEMS moves the
+// small_cat limit, CRH_SCORE_SEED_ITEMS fixes the prefix for both cases.
+int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
+    const char* sm = getenv("CRH_SCORE_SEED");
+    const int seed_mode = sm ? atoi(sm) : 1;
+    int64_t P = seed_prefix_items(n_items);
+    if (!seed_mode || P <= 0 || n_users <= 0) return 0;
+    const int upw = users_per_wave(esz, d);
+    const int64_t n_ug = (n_users + upw - 1) / upw;
+    const bool cuts = pick_splits(n_ug, n_items, 2) > 1;
+    const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
+    const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1999999);
+    if (small_cat && !getenv("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
+    if (!(cuts || small_cat || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
+    return P;
+}
+
 // esz = 4: fp32 tables, exact fp32 MFMA (canonical fma chain).  esz = 2: fp16 tables, fp32 accumulate.
 // Route of a call (n_splits == 0; a caller that names a split count gets the plain fused selection):
 //   seeded  : a catalogue of >= 65 536 items and either users that do not fill the chip on their own (the unseeded picker
@@ -1028,27 +1055,13 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
                    const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
                    void* workspace, size_t workspace_bytes, void* stream, int n_splits, void* ev_kernel_start,
                    void* ev_kernel_stop, const char* who) {
-    const char* sm = getenv("CRH_SCORE_SEED");                       // read per call: 0 never, 1 auto (default), 2 whenever possible
-    const int seed_mode = sm ? atoi(sm) : 1;
-    int64_t P = seed_prefix_items(n_items);
-    if (seed_mode && n_splits == 0 && P > 0 && user_emb && item_emb && out_score && out_idx && n_users > 0 && k >= 1 &&
-        k <= CRH_MAX_K && workspace) {
-        const int upw = users_per_wave(esz, d);
-        const int64_t n_ug = (n_users + upw - 1) / upw;
-        const bool cuts = pick_splits(n_ug, n_items, 2) > 1;          // the users alone do not fill the wave slots
-        // ... and fp32 catalogues the per-wave kernel ranks (below 2 M items) whatever the user count: the warm-up insertions
-        // of the fused selection (three quarters of k (1 + ln(N / k)) fall into the first 20 000 items) are a visible share of
-        // a user's work.  With MANY users the prefix stage is what costs (users x prefix scores written and ranked), and
-        // modest seeds do: a 4 096-item prefix -- 131 072 x 262 144: 0.749 -> 0.799 of the fp32-MFMA peak (16 384-item
-        // prefix: 0.783), x 1 048 576: 0.842 -> 0.859, x 1 250 000 (one rank's shard of the 8-GPU split): 0.853 -> 0.863
-        // (16 384: 0.838).  CRH_SCORE_SEED_MAX_ITEMS moves the limit, CRH_SCORE_SEED_ITEMS fixes the prefix for both cases.
-        const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
-        const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1999999);
-        if (small_cat && !getenv("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
+    // the seeded route's own predicate and prefix (shared with the workspace query: seed_route)
+    const int64_t P = n_splits == 0 ? seed_route(esz, n_users, n_items, d) : 0;
+    if (P > 0 && user_emb && item_emb && out_score && out_idx && n_users > 0 && k >= 1 && k <= CRH_MAX_K && workspace) {
         const size_t sb = seed_bytes(n_users, k);
         const size_t stage1 = dense_block_bytes(n_users, P) + packed_bytes(P, d, esz);
         const size_t stage2 = lists_bytes(n_users, k) + packed_bytes(n_items - P, d, esz);
-        if ((cuts || small_cat || seed_mode == 2) && dense_block_bytes(n_users, P) > 0 && workspace_bytes >= sb + std::max(stage1, stage2)) {
+        if (workspace_bytes >= sb + std::max(stage1, stage2)) {
             float* seed_s = reinterpret_cast<float*>(workspace);
             int32_t* seed_i = reinterpret_cast<int32_t*>(seed_s + (size_t)n_users * k);
             void* ws2 = reinterpret_cast<char*>(workspace) + sb;
@@ -1299,8 +1312,8 @@ size_t full_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k, int 
     if (n_users <= 0 || k <= 0) return 0;
     const size_t tail = dim_ok && n_items > 0 ? packed_bytes(n_items, d, esz) + sync_bytes(n_items) : 0;
     size_t need = std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) + tail;
-    const int64_t P = seed_prefix_items(n_items);
-    if (P > 0 && dim_ok)
+    const int64_t P = dim_ok ? seed_route(esz, n_users, n_items, d) : 0;      // only shapes that DO seed pay for the prefix
+    if (P > 0)
         need = std::max(need, std::max(dense_block_bytes(n_users, P) + packed_bytes(P, d, esz), lists_bytes(n_users, k) + tail)) +
                seed_bytes(n_users, k);
     return need;

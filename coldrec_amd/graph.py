@@ -17,23 +17,39 @@ import torch
 from . import ops
 
 
+def _pad4(x: torch.Tensor) -> torch.Tensor:
+    """The kernels move 16 bytes per lane: a width that is not a multiple of 4 (the reference accepts any --emb_size)
+    gets zero columns up to the next one.  A zero column of the dense operand gives a zero column of the product (every
+    term is val * 0 = 0 added to 0), so the real columns are bit for bit what the unpadded product would be -- the same
+    rule the built-in engines apply to their tables (train._TableState)."""
+    x = x.contiguous().float()
+    d = x.shape[1]
+    if d % 4 == 0:
+        return x
+    out = torch.zeros((x.shape[0], (d + 3) // 4 * 4), dtype=torch.float32, device=x.device)
+    out[:, :d] = x
+    return out
+
+
 class _SpmmFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, adj: "HipSparseAdj", dense: torch.Tensor):
         ctx.adj = adj
-        x = dense.contiguous().float()
+        d = dense.shape[1]
+        x = _pad4(dense)
         y = torch.empty((adj.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         rp, col, val, heavy = adj.csr(x.device)
         ops.spmm_csr(rp, col, val, x, y=y, sched=heavy)
-        return y
+        return y if x.shape[1] == d else y[:, :d].contiguous()
 
     @staticmethod
     def backward(ctx, grad_out):
-        g = grad_out.contiguous().float()
+        d = grad_out.shape[1]
+        g = _pad4(grad_out)
         rp, col, val, heavy = ctx.adj.csr(g.device, transposed=True)
         gx = torch.empty((ctx.adj.shape[1], g.shape[1]), dtype=torch.float32, device=g.device)
         ops.spmm_csr(rp, col, val, g, y=gx, sched=heavy)
-        return None, gx
+        return None, (gx if g.shape[1] == d else gx[:, :d].contiguous())
 
 
 _KEEP_WRAPPED = (torch.Tensor.to, torch.Tensor.cuda, torch.Tensor.cpu, torch.Tensor.float, torch.Tensor.detach,
@@ -72,8 +88,9 @@ class HipSparseAdj(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         if func is torch.sparse.mm and len(args) == 2 and isinstance(args[0], HipSparseAdj) \
-                and isinstance(args[1], torch.Tensor) and args[1].is_cuda and args[1].shape[1] % 4 == 0:
-            return _SpmmFn.apply(args[0], args[1])
+                and isinstance(args[1], torch.Tensor) and args[1].is_cuda and args[1].dim() == 2 \
+                and args[1].layout == torch.strided:
+            return _SpmmFn.apply(args[0], args[1])             # ANY width: _pad4 (no silent hipSPARSE route)
         if func in _KEEP_WRAPPED and isinstance(args[0], HipSparseAdj):
             # device moves, and what nn.Module._apply does to a registered buffer (model/FSGNN.py:249-272)
             moved = func(args[0]._coo, *args[1:], **kwargs)

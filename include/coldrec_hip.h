@@ -430,7 +430,10 @@ int crh_l2_reg_bwd_f32(const float* x, int64_t n, int64_t rows, float reg, const
  * communicator per process / GPU.  crh_comm_unique_id (rank 0; 128 bytes, hand them to the other ranks out of band)
  * -> crh_comm_init on every rank (collective) -> the two collectives below, asynchronous on `stream` -> destroy.
  *   crh_comm_allgather_topk  every rank's (n_users, k) shard lists -> gathered_* laid out [rank][user][k], which is
- *                            crh_merge_topk's input with n_lists = world (eval over a row-sharded item table)
+ *                            crh_merge_topk's input with n_lists = world (eval over a row-sharded item table).  ONE
+ *                            collective: scores and ids travel packed as (n_users, 2k) 32-bit words (the layout
+ *                            coldrec_amd/eval.py sends through torch.distributed) through the caller's device
+ *                            `workspace` of crh_comm_allgather_topk_workspace_bytes(world, n_users, k) bytes
  *   crh_comm_allreduce_f32   in-place sum of n floats: the 4 batch sums of crh_bpr_fwd_f32, the dense gradient table
  * librccl.so is dlopen'ed on first use (an already loaded copy is reused); single-GPU callers never load it.
  * coldrec_amd's Python host layer issues the same collectives through torch.distributed ("nccl" = RCCL).
@@ -442,8 +445,10 @@ int crh_comm_destroy(crh_comm* c);
 int crh_comm_rank(const crh_comm* c);
 int crh_comm_world(const crh_comm* c);
 int crh_comm_allreduce_f32(crh_comm* c, float* buf, int64_t n, void* stream);
+size_t crh_comm_allgather_topk_workspace_bytes(int world, int64_t n_users, int k);
 int crh_comm_allgather_topk(crh_comm* c, const float* score, const int32_t* idx, int64_t n_users, int k,
-                            float* gathered_score, int32_t* gathered_idx, void* stream);
+                            float* gathered_score, int32_t* gathered_idx, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /*
  * HOST-side negative sampler reproducing util/utils.py:123-157 (next_batch_pairwise) and NumPy's

@@ -24,6 +24,9 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g10_samplers.npz util/utils.py:160-336   next_batch_pairwise_LARA / _CLCRec / _CCFCRec / next_batch_cgrc, 2 epochs each
   g11_lgcn_e2e.*   model/LightGCN.py:14-51 + BaseRecommender.py:353-370  LightGCN.run() L=3, d=64, 3 epochs: losses,
                    metrics, best-epoch snapshot tables, final top-20 lists of the three test settings
+  g12_*_real_size.npz  model/MF.py:12-46 / model/LightGCN.py:14-47  trainer.train() at the BASELINE config sizes
+                   (MovieLens shape d=128 B=4096; CiteULike shape L=3 d=128), 2 whole epochs each: every batch's loss terms,
+                   table norms every 10 steps, sampled rows per epoch, the per-epoch validation metrics
   g8_lists.npz / g9_lists.npz  model/BaseRecommender.py:153-188  the final top-20 lists of the g8 / g9 runs (re-run,
                    tables asserted equal to the stored ones) with the eval inputs needed to re-derive rank margins
 """
@@ -548,7 +551,117 @@ def g11_lgcn_e2e(split):
                         E0_item=enc.embedding_dict["item_emb"].detach().numpy(), **_final_lists(trainer, data))
 
 
+def _crc(*arrays):
+    import zlib
+    c = 0
+    for a in arrays:
+        c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
+    return c
+
+
+def g12_real_size(which):
+    """the reference's OWN training loops at the BASELINE config sizes, whole epochs.
+      mf    model/MF.py:12-46        on the MovieLens-shaped split (6 040 x 3 706, ~6.4e5 triples), d=128, B=4096
+      lgcn  model/LightGCN.py:14-47  on the CiteULike-shaped split (5 551 x 16 980, ~1.3e5 triples), L=3, d=128, B=4096
+    ``trainer.train()`` itself runs (2 epochs: the product's first epoch is eager, its second is captured into a hipGraph and
+    replayed -- both are pinned), observed from outside: util.utils.bpr_loss / l2_reg_loss as the trainer's module sees them
+    are wrapped to record every batch's two loss terms, next_batch_pairwise to checksum the triples, and a global optimizer
+    post-step hook records the Frobenius norms of both tables every 10 steps, at the end of each epoch, and 256 sampled
+    rows of each table at the end of each epoch.  The per-epoch validation (fast_evaluation, model/BaseRecommender.py:
+    268-351) runs as in the reference and its metric lines are kept.  Stored: small arrays only (< 1 MB per config); the
+    triples are NOT stored -- the product's sampler reproduces the NumPy stream bit for bit (G1) and the test checks the
+    checksum before it trains."""
+    import contextlib
+    import importlib
+    import io
+    import time
+    shape, cls_name, layers, seed = {"mf": ("movielens", "MF", 0, 1), "lgcn": ("citeulike", "LightGCN", 3, 2)}[which]
+    split = make_dataset(shape, "item", seed=seed, with_content=False)
+    data = ref_builder(split)
+    d, B, epochs = 128, 4096, 2
+    cfg = ref_config(data, dataset=shape, model=cls_name, layers=layers or 2, emb_size=d, epochs=epochs, bs=B)
+    set_seed(2024, False)
+    mod = importlib.import_module("model." + cls_name)
+    trainer = getattr(mod, cls_name)(cfg)
+    params = dict(trainer.model.embedding_dict.items())
+    U0, V0 = params["user_emb"].detach().clone().numpy(), params["item_emb"].detach().clone().numpy()
+    n_steps_epoch = -(-len(data.training_data) // B)
+    rows_u = np.sort(np.random.default_rng(12).choice(U0.shape[0], 256, replace=False))
+    rows_v = np.sort(np.random.default_rng(13).choice(V0.shape[0], 256, replace=False))
+    rec = dict(bpr=[], l2=[], sizes=[], crc=0, norm_step=[], norm_U=[], norm_V=[], end_U=[], end_V=[], end_norm=[])
+    real_bpr, real_l2, real_next = mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise
+
+    def bpr_spy(*a):
+        out_ = real_bpr(*a)
+        rec["bpr"].append(float(out_.item()))
+        return out_
+
+    def l2_spy(*a):
+        out_ = real_l2(*a)
+        rec["l2"].append(float(out_.item()))
+        return out_
+
+    def next_spy(*a, **kw):
+        for bu, bi, bj in real_next(*a, **kw):
+            rec["crc"] = _crc(np.array(bu, np.int32), np.array(bi, np.int32), np.array(bj, np.int32)) ^ (rec["crc"] * 31 & 0xFFFFFFFF)
+            rec["sizes"].append(len(bu))
+            yield bu, bi, bj
+
+    def post_step(opt, args, kwargs):
+        step = len(rec["sizes"])                       # batches drawn so far == optimiser steps done
+        U, V = params["user_emb"].detach(), params["item_emb"].detach()
+        if step % 10 == 0 or step % n_steps_epoch == 0:
+            rec["norm_step"].append(step)
+            rec["norm_U"].append(float(torch.linalg.norm(U.double())))
+            rec["norm_V"].append(float(torch.linalg.norm(V.double())))
+        if step % n_steps_epoch == 0:
+            rec["end_U"].append(U[rows_u].clone().numpy())
+            rec["end_V"].append(V[rows_v].clone().numpy())
+            rec["end_norm"].append([float(torch.linalg.norm(U.double())), float(torch.linalg.norm(V.double()))])
+
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise = bpr_spy, l2_spy, next_spy
+    handle = register_optimizer_step_post_hook(post_step)
+    buf = io.StringIO()
+    t0 = time.time()
+    try:
+        with contextlib.redirect_stdout(buf):
+            trainer.train()
+    finally:
+        handle.remove()
+        mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise = real_bpr, real_l2, real_next
+    secs = time.time() - t0
+    log = buf.getvalue().splitlines()
+    assert len(rec["bpr"]) == len(rec["l2"]) == len(rec["sizes"]) == epochs * n_steps_epoch, (len(rec["bpr"]), n_steps_epoch)
+    if layers:                                         # what the trainer ranks with: the propagated tables of the best epoch
+        fin_U, fin_V = trainer.user_emb.detach().numpy(), trainer.item_emb.detach().numpy()
+    else:
+        fin_U, fin_V = None, None
+    res = dict(
+        which=which, shape=shape, d=d, batch_size=B, epochs=epochs, layers=layers, lr=cfg.args.lr, reg=cfg.args.reg, seed=2024,
+        data_seed=seed, user_num=data.user_num, item_num=data.item_num, n_train=len(data.training_data),
+        steps_per_epoch=n_steps_epoch, U0_crc=_crc(U0), V0_crc=_crc(V0), U0_norm=float(np.linalg.norm(U0.astype(np.float64))),
+        V0_norm=float(np.linalg.norm(V0.astype(np.float64))), triples_crc=rec["crc"], sizes=np.array(rec["sizes"], np.int32),
+        bpr=np.array(rec["bpr"], np.float64), l2=np.array(rec["l2"], np.float64),
+        norm_step=np.array(rec["norm_step"], np.int32), norm_U=np.array(rec["norm_U"], np.float64),
+        norm_V=np.array(rec["norm_V"], np.float64), rows_u=rows_u, rows_v=rows_v,
+        end_U=np.stack(rec["end_U"]), end_V=np.stack(rec["end_V"]), end_norm=np.array(rec["end_norm"], np.float64),
+        best_epoch=trainer.bestPerformance[0], best_metrics=json.dumps(trainer.bestPerformance[1]),
+        valid_lines=json.dumps([ln for ln in log if "Valid" in ln or "valid" in ln or "NDCG" in ln][:40]),
+        reference_seconds=secs, torch_version=torch.__version__)
+    if layers:
+        res.update(final_out_U=fin_U[rows_u], final_out_V=fin_V[rows_v],
+                   final_out_norm=np.array([np.linalg.norm(fin_U.astype(np.float64)), np.linalg.norm(fin_V.astype(np.float64))]))
+    np.savez_compressed(out("g12_%s_real_size.npz" % which), **res)
+    print("g12 %s: %d steps of the reference in %.1f s; last losses bpr %.6f l2 %.3e; best %s"
+          % (which, len(rec["bpr"]), secs, rec["bpr"][-1], rec["l2"][-1], trainer.bestPerformance))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":         # round 4: real-size whole-epoch fixtures (minutes of CPU)
+        for which in (sys.argv[2:] or ["mf", "lgcn"]):
+            g12_real_size(which)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":         # add the round-3 fixtures without redoing G1-G10
         split = make_dataset("toy", "item", seed=1)
         g8_lists(split)
@@ -583,6 +696,8 @@ def main():
     g8_lists(split_i)
     g9_lists(split_i)
     g11_lgcn_e2e(split_i)
+    g12_real_size("mf")
+    g12_real_size("lgcn")
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

@@ -44,3 +44,29 @@ def test_default_command_line_and_legs():
     # the XL SpMM's traffic comes from a profile of its own instantiation
     tr = bench.measured_traffic("spmm_csr_kernel<32>", None)
     assert tr is not None and tr[1].startswith("r03_") and 1.5e11 < tr[0] < 3e11
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """``python bench.py --gpus N`` with WORLD_SIZE unset launches ``torch.distributed.run`` itself, as
+    a CHILD process, before anything touches the GPU, and relays the child's exit code.  Here (no GPU) the dry hook shows
+    the command; the real launch reaches both ranks' "needs an MI355X" exit and the parent returns non-zero."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    dry = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                         env=dict(env, CRH_BENCH_DRY_LAUNCH="1"), capture_output=True, text=True, timeout=300)
+    assert dry.returncode == 0, dry.stderr[-2000:]
+    cmd = json.loads(dry.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    # the source decides before the first torch.cuda call of main()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert body.index("self_launch(") < body.index("torch.cuda.")
+    assert "os.exec" not in src
+    import torch
+    if not torch.cuda.is_available():
+        real = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                              env=env, capture_output=True, text=True, timeout=600)
+        assert real.returncode != 0                              # relayed from the launcher (both ranks refuse a CPU box)
+        assert "needs an MI355X" in real.stderr + real.stdout    # ... i.e. the ranks DID start and parse their flags

@@ -193,6 +193,64 @@ def test_stock_style_plugin_hits_hip_spmm_and_bpr_autograd():
         np.testing.assert_allclose(loss.item(), g5["train_loss"][s], rtol=1e-5)
 
 
+def test_stock_style_plugin_odd_width_stays_on_the_hip_path(monkeypatch):
+    """--emb_size 50 (not a multiple of 4) through the hook an unmodified model/*.py uses.  HipSparseAdj
+    zero-pads the dense operand (exact) instead of falling through to torch.sparse.mm / hipSPARSE: every torch.sparse.mm
+    of the run -- forward AND autograd's backward -- must reach crh_spmm_csr_f32, and losses, gradient and tables follow
+    oracle.ref_port.LGCNPort (the reference's own calls on the CPU) on the same triples."""
+    from coldrec_amd import ops
+    from coldrec_amd.graph import HipSparseAdj
+    from coldrec_amd.util.databuilder import TorchGraphInterface
+    from coldrec_amd.util.utils import bpr_loss, l2_reg_loss
+    from oracle import ref_port
+    g5 = load_golden("g5_lgcn.npz")
+    _, data = builder()
+    d, L = 50, 3
+    rng = np.random.default_rng(50)
+    U0 = (rng.standard_normal((data.user_num, d)) * 0.1).astype(np.float32)
+    V0 = (rng.standard_normal((data.item_num, d)) * 0.1).astype(np.float32)
+    calls = {"hip": 0}
+    real = ops.spmm_csr
+
+    def counted(*a, **kw):
+        calls["hip"] += 1
+        return real(*a, **kw)
+
+    monkeypatch.setattr(ops, "spmm_csr", counted)
+    adj = TorchGraphInterface.convert_sparse_mat_to_tensor(data.norm_adj).to(DEV)
+    assert isinstance(adj, HipSparseAdj)
+    Up, Vp = nn.Parameter(torch.from_numpy(U0.copy()).to(DEV)), nn.Parameter(torch.from_numpy(V0.copy()).to(DEV))
+    opt = torch.optim.Adam([Up, Vp], lr=float(g5["lr"]))
+    csr = data.norm_adj.tocsr()
+    csr.sort_indices()
+    port = ref_port.LGCNPort(U0, V0, ref_port.coo_adj(csr.indptr, csr.indices, csr.data), L, float(g5["lr"]), float(g5["reg"]))
+    off = np.concatenate([[0], np.cumsum(g5["train_sizes"])])
+    for s in range(6):
+        sl = slice(int(off[s]), int(off[s + 1]))
+        ui, pi, ni = g5["train_u"][sl].tolist(), g5["train_i"][sl].tolist(), g5["train_j"][sl].tolist()
+        ego = torch.cat([Up, Vp], 0)                       # model/LightGCN.py:86-96, as a plugin writes it
+        outs = [ego]
+        for _ in range(L):
+            ego = torch.sparse.mm(adj, ego)
+            outs.append(ego)
+        out = torch.mean(torch.stack(outs, dim=1), dim=1)
+        ua, ia = out[: data.user_num], out[data.user_num:]
+        assert ua.shape[1] == d
+        ue, pe, ne = ua[ui], ia[pi], ia[ni]
+        loss = bpr_loss(ue, pe, ne) + l2_reg_loss(float(g5["reg"]), ue, pe, ne)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want = port.step(ui, pi, ni)
+        np.testing.assert_allclose(loss.item(), want, rtol=1e-5)
+    assert calls["hip"] == 6 * 2 * L                       # L forward + L backward products per step, none elsewhere
+    for got, ref in ((Up, port.U), (Vp, port.V)):
+        ref = ref.detach().numpy()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+        rel = abs(float(got.detach().norm()) - np.linalg.norm(ref)) / np.linalg.norm(ref)
+        assert rel <= 1e-5                                 # north_star: embedding norms to 1e-5
+
+
 def test_dense_batch_predict_path_equals_fused_path():
     from coldrec_amd.model.BaseRecommender import BaseColdStartTrainer
     g = load_golden("g6_eval_item_cont.npz")

@@ -1,0 +1,181 @@
+"""G12: BASELINE configs[1] and [2] pinned to the REFERENCE ITSELF at their own size, over whole epochs.
+
+tests/golden/g12_{mf,lgcn}_real_size.npz hold what /root/reference's own ``MF.train()`` (model/MF.py:12-46) and
+``LightGCN.train()`` (model/LightGCN.py:14-47) produced on the MovieLens- / CiteULike-shaped splits, d=128, B=4096, 2 epochs
+(318 / 64 dependent Adam steps): every batch's bpr and l2 loss terms, both tables' Frobenius norms every 10 steps, 256
+sampled rows of each table at the end of each epoch and the per-epoch validation metrics (tests/golden/make_golden.py g12).
+The product's trainers run the same epochs on the GPU -- epoch 1 eagerly, epoch 2 captured into a hipGraph and replayed --
+and must agree with the north_star tolerance: losses and embedding norms to 1e-5 relative, sampled rows to 2e-4 of the
+table's scale."""
+import argparse
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+RTOL = 1e-5                       # north_star: "within 1e-5 relative for BPR loss and embedding norms"
+
+
+def real_size_data(g):
+    from coldrec_amd.data.synth import make_dataset
+    from coldrec_amd.util.databuilder import ColdStartDataBuilder
+    split = make_dataset(str(g["shape"]), "item", seed=int(g["data_seed"]), with_content=False)
+    info = split.info
+    data = ColdStartDataBuilder(split.warm_train, split.warm_val, split.cold_val, split.overall_val, split.warm_test,
+                                split.cold_test, split.overall_test, info["user_num"], info["item_num"], info["warm_user"],
+                                info["warm_item"], info["cold_user"], info["cold_item"], None, None)
+    assert data.user_num == int(g["user_num"]) and data.item_num == int(g["item_num"])
+    return data
+
+
+def _cfg(data, g, **kw):
+    a = dict(dataset=str(g["shape"]), model="MF", epochs=int(g["epochs"]), layers=int(g["layers"]) or 2, topN="10,20",
+             bs=int(g["batch_size"]), emb_size=int(g["d"]), lr=float(g["lr"]), reg=float(g["reg"]), runs=1, seed=2024,
+             use_gpu=True, save_emb=False, gpu_id=0, cold_object="item", backbone="MF", early_stop=10, eval_every=1)
+    a.update(kw)
+    return types.SimpleNamespace(args=argparse.Namespace(**a), data=data, device=DEV)
+
+
+def crc_fold(crc, bu, bi, bj):
+    import zlib
+    c = 0
+    for a in (bu, bi, bj):
+        c = zlib.crc32(np.ascontiguousarray(a, dtype=np.int32).tobytes(), c)
+    return c ^ (crc * 31 & 0xFFFFFFFF)
+
+
+def _run_trainer(g, model, monkeypatch, env=None):
+    """The product's trainer.train() on the fixture's split; every epoch's per-step [bpr, l2] losses, the tables' norms and
+    the sampled rows at the end of each epoch, and the triples' checksum are collected by a recording EpochRunner."""
+    import coldrec_amd.model.MF as mf_mod
+    from coldrec_amd.model import AVAILABLE_MODELS
+    from coldrec_amd.train import EpochRunner
+    from coldrec_amd.util.utils import set_seed
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    rec = dict(losses=[], end_U=[], end_V=[], end_norm=[], crc=0, graph=[])
+    B = int(g["batch_size"])
+
+    class Recording(EpochRunner):
+        def run(self, u, i, j):
+            losses = super().run(u, i, j)
+            torch.cuda.synchronize()
+            uu, ii, jj = (self.u.cpu().numpy(), self.i.cpu().numpy(), self.j.cpu().numpy())
+            for lo in range(0, len(uu), B):
+                rec["crc"] = crc_fold(rec["crc"], uu[lo:lo + B], ii[lo:lo + B], jj[lo:lo + B])
+            rec["losses"].append(losses.detach().cpu().numpy().astype(np.float64).copy())
+            E, U = self.eng.E, self.eng.user_num
+            rec["end_U"].append(E[:U][torch.from_numpy(g["rows_u"]).to(DEV)].cpu().numpy())
+            rec["end_V"].append(E[U:][torch.from_numpy(g["rows_v"]).to(DEV)].cpu().numpy())
+            rec["end_norm"].append([float(torch.linalg.norm(E[:U].double())), float(torch.linalg.norm(E[U:].double()))])
+            rec["graph"].append(self.graph is not None)
+            return losses
+
+    monkeypatch.setattr(mf_mod, "EpochRunner", Recording)
+    data = real_size_data(g)
+    set_seed(2024, True)
+    tr = AVAILABLE_MODELS[model](_cfg(data, g, model=model))
+    import zlib
+    assert zlib.crc32(tr.model.item0.numpy().tobytes(), 0) == int(g["V0_crc"]) and \
+        zlib.crc32(tr.model.user0.numpy().tobytes(), 0) == int(g["U0_crc"]), "initial xavier tables differ from the reference's"
+    tr.train()
+    return tr, rec
+
+
+def _check_against_reference(g, tr, rec, what):
+    n_ep, spe = int(g["epochs"]), int(g["steps_per_epoch"])
+    assert rec["crc"] == int(g["triples_crc"]), what + ": the sampler's triples differ from the reference's NumPy stream"
+    got = np.concatenate(rec["losses"])
+    assert got.shape == (n_ep * spe, 2)
+    np.testing.assert_allclose(got[:, 0], g["bpr"], rtol=RTOL, atol=0, err_msg=what + ": bpr loss per step")
+    np.testing.assert_allclose(got[:, 0] + got[:, 1], g["bpr"] + g["l2"], rtol=RTOL, atol=0, err_msg=what + ": batch loss")
+    np.testing.assert_allclose(got[:, 1], g["l2"], rtol=1e-4, atol=0, err_msg=what + ": l2 term")      # 1e-5 of the loss it is part of
+    np.testing.assert_allclose(np.array(rec["end_norm"]), g["end_norm"], rtol=RTOL, err_msg=what + ": table norms per epoch")
+    for e in range(n_ep):
+        for key, ref in (("end_U", g["end_U"][e]), ("end_V", g["end_V"][e])):
+            err = np.abs(rec[key][e] - ref).max()
+            assert err <= 2e-4 * np.abs(ref).max(), (what, key, e, err, np.abs(ref).max())
+    assert rec["graph"] == [False] + [True] * (n_ep - 1), rec["graph"]          # epoch 2 WAS a hipGraph replay
+    best = json.loads(str(g["best_metrics"]))
+    assert tr.bestPerformance[0] == int(g["best_epoch"])
+    for k, v in best.items():                                                   # validation ranking + metrics at real size
+        assert abs(tr.bestPerformance[1][k] - v) <= 2e-4, (what, k, tr.bestPerformance[1][k], v)
+    worst = float(np.max(np.abs(got[:, 0] - g["bpr"]) / np.abs(g["bpr"])))
+    print("%s: %d steps, worst relative bpr-loss error %.2e, norms %.2e" % (
+        what, len(got), worst, float(np.max(np.abs(np.array(rec["end_norm"]) - g["end_norm"]) / g["end_norm"]))))
+
+
+def test_g12_mf_fused_step_and_graph_replay(monkeypatch):
+    """configs[1]: one-launch BPR-MF step (the default), epoch 2 as a hipGraph replay."""
+    g = load_golden("g12_mf_real_size.npz")
+    tr, rec = _run_trainer(g, "MF", monkeypatch)
+    assert tr.engine.fused
+    _check_against_reference(g, tr, rec, "g12 mf fused")
+
+
+def test_g12_mf_three_kernel_step_and_graph_replay(monkeypatch):
+    """configs[1] with CRH_MF_FUSED=0: forward partials, row gradients, dense Adam as three launches."""
+    g = load_golden("g12_mf_real_size.npz")
+    tr, rec = _run_trainer(g, "MF", monkeypatch, env={"CRH_MF_FUSED": "0"})
+    assert not tr.engine.fused
+    _check_against_reference(g, tr, rec, "g12 mf three-kernel")
+
+
+def test_g12_lightgcn_and_graph_replay(monkeypatch):
+    """configs[2]: LightGCN L=3 on the CiteULike shape, Adam in the last backward SpMM's epilogue, epoch 2 replayed; also
+    the PROPAGATED tables the trainer ranks with (forward() of the best epoch) against the reference's."""
+    g = load_golden("g12_lgcn_real_size.npz")
+    tr, rec = _run_trainer(g, "LightGCN", monkeypatch)
+    _check_against_reference(g, tr, rec, "g12 lightgcn")
+    U, V = tr.user_emb.detach().float().cpu().numpy(), tr.item_emb.detach().float().cpu().numpy()
+    np.testing.assert_allclose([np.linalg.norm(U.astype(np.float64)), np.linalg.norm(V.astype(np.float64))],
+                               g["final_out_norm"], rtol=RTOL)
+    for got, ref in ((U[g["rows_u"]], g["final_out_U"]), (V[g["rows_v"]], g["final_out_V"])):
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("which", ["mf", "lgcn"])
+def test_g12_norms_every_ten_steps_eager(which):
+    """The same epochs stepped one batch at a time (eager three-kernel step, no runner): both tables' Frobenius norms at
+    every 10th step of the reference's record -- where drift would show before the end of an epoch."""
+    from coldrec_amd import ops
+    from coldrec_amd.train import LGCNEngine, MFEngine
+    from coldrec_amd.util.utils import epoch_triples, set_seed
+    g = load_golden("g12_%s_real_size.npz" % which)
+    data = real_size_data(g)
+    set_seed(2024, True)
+    init = torch.nn.init.xavier_uniform_
+    U0, V0 = init(torch.empty(data.user_num, int(g["d"]))), init(torch.empty(data.item_num, int(g["d"])))
+    if which == "mf":
+        eng = MFEngine(U0, V0, float(g["lr"]), float(g["reg"]), DEV)
+    else:
+        rowptr, col, val = data.norm_adj_csr()
+        eng = LGCNEngine(U0, V0, rowptr, col, val, int(g["layers"]), float(g["lr"]), float(g["reg"]), DEV)
+    B, step, crc = int(g["batch_size"]), 0, 0
+    want = dict(zip(g["norm_step"].tolist(), zip(g["norm_U"].tolist(), g["norm_V"].tolist())))
+    worst = 0.0
+    for _ in range(int(g["epochs"])):
+        u, i, j = epoch_triples(data, B)
+        tu, ti, tj = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(DEV) for x in (u, i, j))
+        plans = ops.build_plans_device(tu, ti, tj, B)
+        for s, lo in enumerate(range(0, len(u), B)):
+            crc = crc_fold(crc, u[lo:lo + B], i[lo:lo + B], j[lo:lo + B])
+            eng.step(tu[lo:lo + B], ti[lo:lo + B], tj[lo:lo + B], plan=plans[s])
+            bpr, l2 = eng.loss.cpu().numpy().astype(np.float64)
+            assert abs(bpr - g["bpr"][step]) <= RTOL * abs(g["bpr"][step]), (which, step, bpr, g["bpr"][step])
+            step += 1
+            if step in want:
+                nu = float(torch.linalg.norm(eng.user_emb.double()))
+                nv = float(torch.linalg.norm(eng.item_emb.double()))
+                worst = max(worst, abs(nu - want[step][0]) / want[step][0], abs(nv - want[step][1]) / want[step][1])
+                assert abs(nu - want[step][0]) <= RTOL * want[step][0] and abs(nv - want[step][1]) <= RTOL * want[step][1], \
+                    (which, step, nu, nv, want[step])
+    assert crc == int(g["triples_crc"]) and step == len(g["bpr"])
+    print("g12 %s eager: %d norm check points, worst relative error %.2e" % (which, len(want), worst))

@@ -411,8 +411,13 @@ lo, hi = rank * n_items // world, (rank + 1) * n_items // world
 s, i = ops.score_topk(U, None, V[lo:hi].contiguous(), k, item_base=lo)
 gs = torch.empty((world, n_users, k), device=dev)
 gi = torch.empty((world, n_users, k), dtype=torch.int32, device=dev)
-_lib.check(L.crh_comm_allgather_topk(comm, s.data_ptr(), i.data_ptr(), n_users, k, gs.data_ptr(), gi.data_ptr(), st),
-           "crh_comm_allgather_topk")
+ws_bytes = L.crh_comm_allgather_topk_workspace_bytes(world, n_users, k)
+assert ws_bytes == (world + 1) * n_users * 2 * k * 4
+ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+assert L.crh_comm_allgather_topk(comm, s.data_ptr(), i.data_ptr(), n_users, k, gs.data_ptr(), gi.data_ptr(),
+                                 ws.data_ptr(), ws_bytes - 1, st) != 0          # a short workspace is refused, not overrun
+_lib.check(L.crh_comm_allgather_topk(comm, s.data_ptr(), i.data_ptr(), n_users, k, gs.data_ptr(), gi.data_ptr(),
+                                     ws.data_ptr(), ws_bytes, st), "crh_comm_allgather_topk")
 ms, mi = ops.merge_topk(gs, gi, k)
 ws, wi = ops.score_topk(U, None, V, k)
 x = torch.full((1000,), float(rank + 1), device=dev)
@@ -444,6 +449,18 @@ def test_comm_c_abi_two_ranks(tmp_path):
         pytest.skip("one GPU: RCCL refuses two ranks on one device -- " + text.strip().splitlines()[0][:200])
     assert all(p.returncode == 0 for p in procs), (text[-2000:], outs[0][1][-3000:], outs[1][1][-3000:])
     assert "COMM_OK 0 2" in text and "COMM_OK 1 2" in text
+
+
+def test_comm_c_abi_one_rank_packed_allgather(tmp_path):
+    """The same worker as ONE rank: what a one-GPU box can run of the C-ABI exchange on real hardware -- RCCL
+    communicator of world 1, the pack kernel, ONE ncclAllGather of the packed (n_users, 2k) words, the unpack kernel,
+    crh_merge_topk over the single gathered list == the direct ranking, bit for bit; the short-workspace refusal."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(_COMM_WORKER)
+    env = dict(os.environ, CR_ROOT=ROOT, OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, str(script), "0", "1", str(tmp_path / "uid.bin")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "COMM_OK 0 1" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
 def test_private_workspace_survives_bigger_calls_between_graph_replays():
