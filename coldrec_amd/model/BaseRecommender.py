@@ -29,6 +29,12 @@ from ..eval import ShardedTopK, shard_bounds
 from ..train import dp_from_env
 from ..util.evaluator import format_measure, ranking_metrics, truth_csr, truth_dense
 
+
+def _truth_pairs(data_set: Dict) -> int:
+    fast = getattr(data_set, 'n_pairs', None)         # array-backed ground truths (bench.py's S-EVAL leg) know their size
+    return int(fast) if fast is not None else sum(map(len, data_set.values()))
+
+
 _STOCK_PREDICT = re.compile(
     r"score=torch\.matmul\(self\.user_emb\[users\],self\.item_emb\.transpose\(0,1\)\)returnscore$")
 
@@ -44,6 +50,8 @@ def _is_stock_batch_predict(fn) -> bool:
 
 class BaseColdStartTrainer(ABC):
     fused_eval = None     # subclasses may force True / False; None = detect from batch_predict's source
+    EVAL_USER_BLOCK = 131072   # users per fused scoring call (see _topk_device)
+    eval_timing = None    # a dict here makes _metrics record its phases (synchronising at each boundary): bench.py's eval_e2e
 
     def __init__(self, config):
         self.config = config
@@ -106,7 +114,10 @@ class BaseColdStartTrainer(ABC):
     def _get_eval_cache(self, data_set: Dict, data_type: str) -> Dict[str, Any]:
         key = (id(data_set), data_type, str(self.device), self.args.cold_object)
         hit = self._eval_cache.get(key)
-        if hit is not None:
+        # the reference caches the user list and the masks per dataset object but reads the ground truth from the dict at
+        # every evaluation (util/evaluator.py:153-187): a dict a plugin changed in place must not be scored against the
+        # arrays of its old contents -- the entry stands while user and pair counts are unchanged
+        if hit is not None and hit['fingerprint'] == (len(data_set), _truth_pairs(data_set)):
             return hit
         d = self.data
         cached = d.truth_csr_cached(data_set) if hasattr(d, 'truth_csr_cached') else None
@@ -126,10 +137,10 @@ class BaseColdStartTrainer(ABC):
         dev = self.device
         hit = {
             'users': users, 'users_int': torch.from_numpy(uint.astype(np.int32)).to(dev),
-            'rated_rowptr': torch.from_numpy(rowptr).to(dev) if rowptr[-1] else None,
+            'rated_rowptr': torch.from_numpy(rowptr).to(dev) if rowptr[-1] else None, 'rated_rowptr_host': rowptr,
             'rated_col': torch.from_numpy(np.ascontiguousarray(col)).to(dev) if rowptr[-1] else None,
             'bitmap': ops.make_bitmap(d.item_num, masked, dev),
-            'gt_rowptr': gt_rowptr, 'gt_items': gt_items,
+            'gt_rowptr': gt_rowptr, 'gt_items': gt_items, 'fingerprint': (len(users), int(gt_rowptr[-1])),
             'gt_dense': truth_dense(gt_rowptr, gt_items, len(d.item)),
         }
         self._eval_cache[key] = hit
@@ -157,12 +168,33 @@ class BaseColdStartTrainer(ABC):
             tdt = torch.float16 if getattr(self.args, 'score_dtype', 'fp32') == 'fp16' else torch.float32
             ue, ie = ue.detach().to(tdt), ie.detach().to(tdt)
             if dp is None:
-                s, i = ops.score_topk(ue, c['users_int'], ie, self.max_N, c['rated_rowptr'], c['rated_col'],
-                                      c['bitmap'])
+                def rank(users, rp, rc, out=None):
+                    return ops.score_topk(ue, users, ie, self.max_N, rp, rc, c['bitmap'], out=out)
             else:                     # item rows sharded over the ranks, all-gather + canonical merge
                 lo, hi = shard_bounds(ie.shape[0], dp.world, dp.rank)
                 eng = ShardedTopK(ie[lo:hi].contiguous(), lo, ie.shape[0], self.max_N, dp.world, dp.rank)
-                s, i = eng.topk(ue, c['users_int'], c['rated_rowptr'], c['rated_col'], c['bitmap'])
+
+                def rank(users, rp, rc, out=None):
+                    return eng.topk(ue, users, rp, rc, c['bitmap'])
+            n, blk = len(c['users']), self.EVAL_USER_BLOCK
+            if n <= blk:
+                s, i = rank(c['users_int'], c['rated_rowptr'], c['rated_col'])
+            else:
+                # catalogue-scale evaluations (S-EVAL: 1e6 users) go in blocks of EVAL_USER_BLOCK users: the kernel's
+                # partial-list workspace is 64 x users x k x 8 bytes (10 GB for 1e6 users at once), and 2048 groups of 64
+                # users already fill the chip -- one block is one launch at the headline's shape
+                s = torch.empty((n, self.max_N), dtype=torch.float32, device=ue.device)
+                i = torch.empty((n, self.max_N), dtype=torch.int32, device=ue.device)
+                rp_all, rc_all, rp_host = c['rated_rowptr'], c['rated_col'], c['rated_rowptr_host']
+                for b0 in range(0, n, blk):
+                    b1 = min(n, b0 + blk)
+                    rp = rc = None
+                    if rp_all is not None:
+                        rp = (rp_all[b0:b1 + 1] - rp_all[b0]).contiguous()
+                        rc = rc_all[int(rp_host[b0]):int(rp_host[b1])]
+                    bs_, bi_ = rank(c['users_int'][b0:b1], rp, rc, out=(s[b0:b1], i[b0:b1]))
+                    if bs_.data_ptr() != s[b0:b1].data_ptr():          # the sharded engine returns its own (merged) block
+                        s[b0:b1], i[b0:b1] = bs_, bi_
         else:
             parts_s, parts_i = [], []
             for lo in range(0, len(c['users']), self.batch_size):
@@ -180,9 +212,15 @@ class BaseColdStartTrainer(ABC):
         return c, s, i
 
     def _evaluate(self, data_set: Dict, data_type: str = 'all') -> Dict[Any, List[Tuple[Any, float]]]:
+        t0 = self._tick('_before', time.perf_counter())
         c, s, i = self._topk_arrays(data_set, data_type)
-        names = self.data.item_keys[np.minimum(i, len(self.data.item_keys) - 1)]
-        return {u: list(zip(names[r].tolist(), s[r])) for r, u in enumerate(c['users'])}
+        t0 = self._tick('evaluate_rank_s', t0)
+        # {user: [(original item id, np.float32 score), ...]} as model/BaseRecommender.py:185-187 builds it: the ids in bulk
+        # (one gather + one tolist), the pairing row by row
+        names = self.data.item_keys[np.minimum(i, len(self.data.item_keys) - 1)].tolist()
+        out = {u: list(zip(nr, sr)) for u, nr, sr in zip(c['users'], names, s)}
+        self._tick('evaluate_dict_s', t0)
+        return out
 
     def valid(self, valid_type: str = 'all'):
         return self._evaluate(self._sets('valid', valid_type), valid_type)
@@ -190,40 +228,73 @@ class BaseColdStartTrainer(ABC):
     def test(self, test_type: str = 'all'):
         return self._evaluate(self._sets('test', test_type), test_type)
 
+    def _tick(self, name: str, t0: float) -> float:
+        """eval_timing hook: seconds since t0 under ``name`` (device drained first); no-op without the hook."""
+        if self.eval_timing is None:
+            return t0
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.eval_timing[name] = self.eval_timing.get(name, 0.0) + now - t0
+        return now
+
     def _metrics(self, data_set: Dict, data_type: str, topn):
+        t0 = self._tick('_before', time.perf_counter())
+        c = self._get_eval_cache(data_set, data_type)
+        t0 = self._tick('cache_s', t0)
         c, _s, i = self._topk_device(data_set, data_type)
+        t0 = self._tick('rank_s', t0)
+        if self.eval_timing is not None:
+            self.eval_timing['last_topk'] = (_s, i)
+        try:
+            return self._metrics_of(c, i, topn)
+        finally:
+            self._tick('metrics_s', t0)
+
+    def _metrics_of(self, c, i, topn):
         if i is None:
             return ranking_metrics(c['gt_rowptr'], c['gt_items'], np.zeros((0, self.max_N), np.int32), topn)
+        t0 = time.perf_counter()
+        hit = self._membership(c, i)
+        t0 = self._tick('membership_s', t0)
+        try:
+            return ranking_metrics(c['gt_rowptr'], c['gt_items'], None, topn, hit=hit)
+        finally:
+            self._tick('host_metrics_s', t0)
+
+    def _membership(self, c, i) -> np.ndarray:
+        """bool (users, k) on the host: is prediction (r, q) in the ground truth of user r -- tested on the GPU, one bit per
+        prediction comes back instead of scores + ids and a host gather (the host part of a MovieLens-size validation was
+        5-6 ms per epoch, twice the epoch's training time)."""
         if c['gt_dense'] is not None:
-            # membership of every prediction in its user's ground truth, tested on the GPU against the device copy of the
-            # dense truth table: one bit per prediction comes back instead of scores + ids and a host gather (the host
-            # part of a MovieLens-size validation was 5-6 ms per epoch, twice the epoch's training time)
+            # small catalogues: a dense (users, items) truth table on the device, one gather
             if c.get('gt_dense_dev') is None:
                 c['gt_dense_dev'] = torch.from_numpy(c['gt_dense']).to(i.device)
                 c['row_ids_dev'] = torch.arange(c['gt_dense'].shape[0], device=i.device).unsqueeze(1)
             idx = i.long()
             ok = (idx >= 0) & (idx < c['gt_dense_dev'].shape[1])
-            hit = (c['gt_dense_dev'][c['row_ids_dev'], idx.clamp(0, c['gt_dense_dev'].shape[1] - 1)] & ok).cpu().numpy()
-            return ranking_metrics(c['gt_rowptr'], c['gt_items'], None, topn, hit=hit)
-        # ground truth too large for a dense table: sorted (row, item) keys on the device, one binary search per prediction
+            return (c['gt_dense_dev'][c['row_ids_dev'], idx.clamp(0, c['gt_dense_dev'].shape[1] - 1)] & ok).cpu().numpy()
+        # ground truth too large for a dense table (S-EVAL: 1e6 users x 1e7 items): sorted (row, item) keys on the device,
+        # one binary search per prediction, in blocks of users (the int64 key arrays of 2e7 predictions at once are 0.5 GB)
         if c.get('gt_keys_dev') is None:
             n_items = len(self.data.item)
             rows = np.repeat(np.arange(len(c['users']), dtype=np.int64), np.diff(c['gt_rowptr']))
-            keys = rows * n_items + np.clip(np.asarray(c['gt_items'], np.int64), 0, n_items - 1)
-            keys = keys[np.asarray(c['gt_items']) < n_items]
+            gi = np.asarray(c['gt_items'], np.int64)
+            keys = (rows * n_items + np.clip(gi, 0, n_items - 1))[gi < n_items]
             c['gt_keys_dev'] = torch.sort(torch.from_numpy(keys).to(i.device))[0]
-            c['row_ids_dev'] = torch.arange(len(c['users']), device=i.device).unsqueeze(1)
             c['gt_base'] = n_items
         keys, base = c['gt_keys_dev'], c['gt_base']
-        idx = i.long()
-        ok = (idx >= 0) & (idx < base)
-        if keys.numel() == 0:
-            hit = torch.zeros_like(ok)
-        else:
-            pk = (c['row_ids_dev'] * base + idx.clamp(0, base - 1)).reshape(-1)
-            pos = torch.searchsorted(keys, pk).clamp(max=keys.numel() - 1)
-            hit = (keys[pos] == pk).reshape(idx.shape) & ok
-        return ranking_metrics(c['gt_rowptr'], c['gt_items'], None, topn, hit=hit.cpu().numpy())
+        n = i.shape[0]
+        hit = torch.zeros(i.shape, dtype=torch.bool, device=i.device)
+        if keys.numel():
+            blk = 1 << 18
+            for lo in range(0, n, blk):
+                idx = i[lo:lo + blk].long()
+                ok = (idx >= 0) & (idx < base)
+                rows = torch.arange(lo, lo + idx.shape[0], device=i.device).unsqueeze(1)
+                pk = (rows * base + idx.clamp(0, base - 1)).reshape(-1)
+                pos = torch.searchsorted(keys, pk).clamp_(max=keys.numel() - 1)
+                hit[lo:lo + blk] = (keys[pos] == pk).reshape(idx.shape) & ok
+        return hit.cpu().numpy()
 
     def _metrics_from_rec_list(self, data_set: Dict, data_type: str, rec_list: Dict, topn):
         """Metrics of a caller-supplied ``{user: [(item, score), ...]}`` (what ``test()`` returns, possibly

@@ -45,6 +45,11 @@ def _nested(pairs: np.ndarray) -> Dict[int, Dict[int, float]]:
     return out
 
 
+def truth_pairs(data_set: Dict) -> int:
+    """(user, item) pairs of a ground-truth dict {user: {item: 1.0}} -- the cheap fingerprint the caches are checked with."""
+    return sum(map(len, data_set.values()))
+
+
 class ColdStartDataBuilder(object):
     def __init__(self, training_data, warm_valid_data, cold_valid_data, overall_valid_data,
                  warm_test_data, cold_test_data, overall_test_data, user_num, item_num,
@@ -76,7 +81,9 @@ class ColdStartDataBuilder(object):
             # the same ground truth as arrays (users in dict order, CSR of internal item ids), built here -- vectorised --
             # instead of walking the nested dict inside the first timed validation (evaluator.truth_csr: 30 ms at
             # MovieLens size); keyed by the dict object the trainers pass around
-            self._truth_csr[id(getattr(self, name + "_set"))] = self._pairs_truth_csr(p)
+            dset = getattr(self, name + "_set")
+            csr = self._pairs_truth_csr(p)
+            self._truth_csr[id(dset)] = (dset, csr, int(csr[1][-1]))     # the dict itself is kept: ids can be reused
 
         # array views for the HIP path
         self.train_u = self.map_users(train[:, 0]).astype(np.int32)
@@ -134,7 +141,14 @@ class ColdStartDataBuilder(object):
 
     def truth_csr_cached(self, data_set):
         """(users, rowptr, internal item ids) of one of this builder's own valid / test sets, or None for any other dict."""
-        return self._truth_csr.get(id(data_set))
+        hit = self._truth_csr.get(id(data_set))
+        if hit is None or hit[0] is not data_set:
+            return None
+        # a plugin may have filtered or extended the dict in place since: the arrays stand only while the user count and
+        # the (user, item) pair count are what they were (ADVICE r3); otherwise the caller walks the dict it was given
+        if len(data_set) != len(hit[1][0]) or truth_pairs(data_set) != hit[2]:
+            return None
+        return hit[1]
 
     # ------------------------------------------------------------------ id mapping
     def _map(self, table: Dict[int, int], ids, what: str) -> np.ndarray:

@@ -70,9 +70,9 @@ def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None, 
     if hit is None:
         hit = hit_matrix(gt_rowptr, np.asarray(gt_items), np.asarray(pred), dense)
     out = []
+    hit_t = np.ascontiguousarray(np.asarray(hit, bool).T)     # (k, users): every rank's column is one contiguous pass
     for n in topn:
-        h = hit[:, :n]
-        hits = h.sum(1)
+        hits = hit_t[:n].sum(0, dtype=np.int64)
         total_truth = int(tlen.sum())
         hr = round(int(hits.sum()) / total_truth, 5) if total_truth else 0.0
         prec = round(int(hits.sum()) / (n_user * n), 5) if n_user and n else 0.0
@@ -81,8 +81,8 @@ def ranking_metrics(gt_rowptr, gt_items, pred, topn: Sequence[int], dense=None, 
         w = np.array([1.0 / math.log(q + 2, 2) for q in range(n)])
         cw = np.concatenate([[0.0], np.cumsum(w)])
         dcg = np.zeros(n_user)
-        for q in range(n):                               # rank-ascending accumulation, as the reference
-            dcg = dcg + np.where(h[:, q], w[q], 0.0)
+        for q in range(n):                               # rank-ascending accumulation, as the reference (x + 0.0 == x:
+            np.add(dcg, w[q], out=dcg, where=hit_t[q])   # adding only where the rank hit gives the same bits)
         idcg = cw[np.minimum(tlen, n)]
         ok = idcg > 0
         ndcg = round(_seq_sum(dcg[ok] / idcg[ok]) / int(ok.sum()), 5) if ok.any() else 0.0

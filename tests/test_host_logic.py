@@ -275,6 +275,18 @@ def test_builder_truth_csr_equals_the_dict_walk(name):
         cu, crp, ci = d.truth_csr_cached(s)
         assert cu == users and np.array_equal(crp, rp) and np.array_equal(ci, items), key
     assert d.truth_csr_cached({}) is None
+    # a dict a plugin changed IN PLACE must not be answered from the arrays of its old contents
+    s = d.overall_test_set
+    u0 = next(iter(s))
+    dropped = s.pop(u0)
+    assert d.truth_csr_cached(s) is None                       # a user filtered out
+    s[u0] = dropped
+    assert d.truth_csr_cached(s) is not None                   # restored: same counts again
+    it0 = next(iter(s[u0]))
+    s[u0][-12345] = 1.0
+    assert d.truth_csr_cached(s) is None                       # an item added to one user's truth
+    del s[u0][-12345]
+    assert s[u0].get(it0) == 1.0 and d.truth_csr_cached(s) is not None
     # duplicates and interleaved users
     p = np.array([[5, 9], [3, 9], [5, 7], [5, 9], [3, 1], [5, 7], [4, 9]], np.int64)
     import types

@@ -241,8 +241,10 @@ def test_crh_comm_single_rank_roundtrip():
         s = t(-np.sort(-rng.standard_normal((77, 20)).astype(np.float32), axis=1))
         i = t(rng.permutation(77 * 20).astype(np.int32).reshape(77, 20))
         gs, gi = torch.empty((1, 77, 20), device=DEV), torch.empty((1, 77, 20), dtype=torch.int32, device=DEV)
-        _lib.check(L.crh_comm_allgather_topk(comm, s.data_ptr(), i.data_ptr(), 77, 20, gs.data_ptr(), gi.data_ptr(), st),
-                   "crh_comm_allgather_topk")
+        ws_bytes = L.crh_comm_allgather_topk_workspace_bytes(1, 77, 20)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        _lib.check(L.crh_comm_allgather_topk(comm, s.data_ptr(), i.data_ptr(), 77, 20, gs.data_ptr(), gi.data_ptr(),
+                                             ws.data_ptr(), ws_bytes, st), "crh_comm_allgather_topk")
         ms, mi = ops.merge_topk(gs, gi, 20)
         torch.cuda.synchronize()
         assert torch.equal(x, want) and torch.equal(gs[0], s) and torch.equal(gi[0], i)
