@@ -63,11 +63,6 @@ SIGNATURES = {
     "crh_adam_step_scalars_range_host": (None, [_f64, _f64, _f64, _i64, _i64, _vp]),
     "crh_spmm_segment_edges": (_i32, []),
     "crh_spmm_lane_group": (_i32, [_i64, _i32, _i64]),
-    "crh_spmm_csr_norms_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _i64, _vp, _vp]),
-    "crh_spmm_norm_parts": (_i64, [_i64, _i32, _vp]),
-    "crh_bpr_grad_parts": (_i32, [_i64, _i32]),
-    "crh_bpr_grad_rows_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp,
-                                     _i64, _vp, _vp]),
     "crh_spmm_workspace_bytes": (_sz, [_vp, _i32]),
     "crh_spmm_csr_adam_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _f32, _vp, _f32, _vp, _vp, _vp, _vp,
                                      _f64, _f64, _f64, _f64, _i64, _vp, _i32, _vp]),
@@ -78,9 +73,6 @@ SIGNATURES = {
     "crh_mf_step_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp,
                                _vp, _i32, _vp, _vp, _i64, _vp, _f64, _f64, _f64, _vp, _vp]),
     "crh_mf_step_finish": (_i32, [_vp, _i32, _i64, _vp, _vp]),
-    "crh_mf_epoch_blocks": (_i32, [_i64, _i32, _i32]),
-    "crh_mf_epoch_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
-                                _f64, _f64, _f64, _vp, _i32, _f64, _vp, _vp]),
     "crh_mf_step_sgd_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i64, _vp, _f64, _vp]),
     "crh_sgd_dense_f32": (_i32, [_vp, _vp, _i64, _f64, _i32, _vp]),
@@ -131,7 +123,10 @@ class SpmmSched(ctypes.Structure):
                 ("multi_row", _vp), ("multi_first", _vp), ("multi_count", _vp), ("n_multi", _i32),
                 ("n_partial", _i64), ("nnz", _i64), ("seg_desc", _vp),
                 ("slab", _vp), ("slab_lanes", _i32), ("slab_buckets", _i32), ("n_slab", _i64),
-                ("slab_first", _i32 * 12), ("slab_units", _i32 * 12), ("slab_base", _i64 * 12)]
+                ("slab_first", _i32 * 12), ("slab_units", _i32 * 12), ("slab_base", _i64 * 12), ("version", _i32)]
+
+
+SPMM_SCHED_VERSION = 4       # CRH_SPMM_SCHED_VERSION of include/coldrec_hip.h
 
 
 class DSamplerIO(ctypes.Structure):

@@ -1125,8 +1125,6 @@ struct MfStepArgs {
     const int32_t* mult2;  // (U + I) multiplicities in the NEXT batch: user rows count, item rows pos | neg << 16; or NULL
     const float* part_in;  // [n_in][4]: norms^2 of THIS batch (u, p, n) and the loss sum of the PREVIOUS one
     int n_in;
-    const float* part_in2; // optional second source, summed with the first (gradient-only variant: the norms come from the
-    int n_in2;             // last forward SpMM's workgroups, the previous batch's loss from the previous gradient launch)
     float* part_out;       // [gridDim.x][4]: norms^2 of the NEXT batch, loss sum of THIS one
     float* loss_prev;      // [2] of the previous step (its bpr is known only now) or NULL
     float inv_b_prev;
@@ -1142,32 +1140,6 @@ struct MfStepArgs {
 __device__ unsigned long long crh_mf_clk[2 * 4096];   // [block]{start, end} of s_memrealtime (100 MHz), last launch
 #endif
 
-// Device-coherent 16-byte accesses for data that crosses workgroups INSIDE a launch (mf_epoch_kernel): the eight L2s
-// are not coherent with each other, so a plain load may hit a line cached before another XCD rewrote the row.  sc1 =
-// agent scope: the load is served from the coherent level, the store is written through to it -- no L2 write-back /
-// invalidate is needed at the grid barrier then.  Inline asm because the compiler only emits scoped accesses for
-// <= 8-byte atomics (four instructions per row slice) or `volatile` (one at a time: no gathers in flight).  The loads
-// of a batch and the wait for them are ONE asm statement: the compiler does not know that the destination registers
-// are being written until the wait, and between two statements it is free to spill or reuse them.
-__device__ __forceinline__ f32x4 mf_ld_coh(const float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void mf_ld_coh2(const float* p0, const float* p1, f32x4& v0, f32x4& v1) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
-}
-__device__ __forceinline__ void mf_ld_coh4(const float* p0, const float* p1, const float* p2, const float* p3, f32x4& v0,
-                                           f32x4& v1, f32x4& v2, f32x4& v3) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-}
-__device__ __forceinline__ void mf_st_coh(float* p, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 #pragma clang fp contract(off)      // the same bits wherever a score difference is recomputed
     return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w;
@@ -1176,7 +1148,7 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 // NQ consecutive entries (lanes t .. t+NQ-1 of the group hold their metadata) of one row: acc += d(loss)/d(row)
 // contributions, loss += -log(1e-5 + sigmoid(x)) on the user side.
 //   user row (own = u): entry rows (p, n);  item row as positive (own = p): (u, n);  as negative (own = n): (u, p)
-template <int G, int NQ, bool COH = false>
+template <int G, int NQ>
 __device__ __forceinline__ void mf_entries_chunk(const MfStepArgs& a, const BwdCoef& k, bool user_side, const int2& en, int t,
                                                  bool on, int lig, const f32x4& own, f32x4& acc, float& loss) {
     int aa[NQ], bb[NQ];
@@ -1190,33 +1162,9 @@ __device__ __forceinline__ void mf_entries_chunk(const MfStepArgs& a, const BwdC
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         xa[q] = xb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (!COH) {
-            if (on) {
-                xa[q] = reinterpret_cast<const f32x4*>(a.pin + (int64_t)(aa[q] & 0x3fffffff) * a.d)[lig];
-                xb[q] = reinterpret_cast<const f32x4*>(a.pin + (int64_t)bb[q] * a.d)[lig];
-            }
-        }
-    }
-    if constexpr (COH) {
-        // every lane loads (lanes beyond the row's width read column slice 0 and drop it): one asm statement per batch
-        const int col = on ? lig * 4 : 0;
-        const float *pa[NQ], *pb[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            pa[q] = a.pin + (int64_t)(aa[q] & 0x3fffffff) * a.d + col;
-            pb[q] = a.pin + (int64_t)bb[q] * a.d + col;
-        }
-        if constexpr (NQ == 4) {
-            mf_ld_coh4(pa[0], pb[0], pa[1], pb[1], xa[0], xb[0], xa[1], xb[1]);
-            mf_ld_coh4(pa[2], pb[2], pa[3], pb[3], xa[2], xb[2], xa[3], xb[3]);
-        } else if constexpr (NQ == 2) {
-            mf_ld_coh4(pa[0], pb[0], pa[1], pb[1], xa[0], xb[0], xa[1], xb[1]);
-        } else {
-            mf_ld_coh2(pa[0], pb[0], xa[0], xb[0]);
-        }
-        if (!on) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) xa[q] = xb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (on) {
+            xa[q] = reinterpret_cast<const f32x4*>(a.pin + (int64_t)(aa[q] & 0x3fffffff) * a.d)[lig];
+            xb[q] = reinterpret_cast<const f32x4*>(a.pin + (int64_t)bb[q] * a.d)[lig];
         }
     }
 #pragma unroll
@@ -1263,23 +1211,19 @@ __device__ __forceinline__ void mf_entries_chunk(const MfStepArgs& a, const BwdC
 
 // Entries [e0, e1) of one row, in list order: metadata one entry per lane, rows fetched 2 entries at a time (most rows
 // of a batch have one or two entries; 4 at a time costs the registers of a fourth wave per SIMD).
-// (COH: the gathered rows are read with device-scope loads, mf_epoch_kernel.  en0: the metadata of entries e0 + lig,
-// fetched by the caller ahead of time -- the step tables never change during an epoch.)
-template <int G, bool COH = false, int NQM = 2>
+template <int G, int NQM = 2>
 __device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoef& k, bool user_side, int e0, int e1,
-                                               bool on, int lig, const f32x4& own, f32x4& acc, float& loss,
-                                               const int2* en0 = nullptr) {
+                                               bool on, int lig, const f32x4& own, f32x4& acc, float& loss) {
     for (int base = e0; base < e1; base += G) {
         const int e = base + lig;
         int2 en = {0, 0};
-        if (en0 && base == e0) en = *en0;
-        else if (e < e1) en = a.entries[e];
+        if (e < e1) en = a.entries[e];
         const int cnt = (e1 - base) < G ? (e1 - base) : G;
         int t = 0;
-        if constexpr (NQM >= 4 && G >= 4)      // (heavy rows of the epoch kernel: eight gathered rows in flight)
-            for (; t + 4 <= cnt; t += 4) mf_entries_chunk<G, 4, COH>(a, k, user_side, en, t, on, lig, own, acc, loss);
-        for (; t + 2 <= cnt; t += 2) mf_entries_chunk<G, 2, COH>(a, k, user_side, en, t, on, lig, own, acc, loss);
-        if (t < cnt) mf_entries_chunk<G, 1, COH>(a, k, user_side, en, t, on, lig, own, acc, loss);
+        if constexpr (NQM >= 4 && G >= 4)
+            for (; t + 4 <= cnt; t += 4) mf_entries_chunk<G, 4>(a, k, user_side, en, t, on, lig, own, acc, loss);
+        for (; t + 2 <= cnt; t += 2) mf_entries_chunk<G, 2>(a, k, user_side, en, t, on, lig, own, acc, loss);
+        if (t < cnt) mf_entries_chunk<G, 1>(a, k, user_side, en, t, on, lig, own, acc, loss);
     }
 }
 
@@ -1287,12 +1231,8 @@ __device__ __forceinline__ void mf_row_entries(const MfStepArgs& a, const BwdCoe
 template <int G, int OPT>
 __device__ __forceinline__ void mf_row_update(const MfStepArgs& a, int64_t row, bool on, int lig, f32x4 p, f32x4 m, f32x4 v,
                                               const f32x4& grad, int mult, float bc2_sqrt, float nss, float& su, float& sp,
-                                              float& sn, bool touched = true) {
+                                              float& sn) {
     const int64_t o = row * a.d + lig * 4;
-    if constexpr (OPT >= 2) {          // gradient only: the row of d(loss)/d(table) goes to `pout`; untouched rows stay as they are
-        if (on && touched) *reinterpret_cast<f32x4*>(a.pout + o) = grad;
-        return;
-    }
     if (on) {
         if constexpr (OPT == 0) adam_elem4(p, m, v, grad, a.k, bc2_sqrt, nss);
         else sgd_elem4(p, grad, a.neg_lr);
@@ -1334,29 +1274,10 @@ __global__ __launch_bounds__(BPR_THREADS, MF_OCC_N) void mf_step_kernel(MfStepAr
     const bool light = (int)blockIdx.x >= heavy_blocks;
     const int64_t gid = (int64_t)((int)blockIdx.x - heavy_blocks) * (BPR_THREADS / G) + threadIdx.x / G;
     const int64_t gstride = (int64_t)a.light_blocks * (BPR_THREADS / G);
-    // OPT = 3 (gradient only, LightGCN): the light work items are the rows the batch TOUCHES, taken from the plan (user
-    // rows, then item rows; their entry ranges are the plan's offsets), not every row of the table
-    int64_t n_work = R;
-    PlanView tv{};
-    int64_t plan_L = 0;
-    if constexpr (OPT == 3) {
-        tv = plan_view(a.plan);
-        plan_L = a.plan[2];
-        n_work = (int64_t)tv.n_u + tv.n_i;
-    }
+    const int64_t n_work = R;                                      // the light work items are the rows of the table
     auto work_row = [&](int64_t w, int2& range_out) -> int64_t {
-        if constexpr (OPT == 3) {
-            if (w < tv.n_u) {
-                range_out = int2{tv.uptr[w], tv.uptr[w + 1]};
-                return tv.urow[w];
-            }
-            const int64_t wi = w - tv.n_u;
-            range_out = int2{(int)(plan_L + tv.iptr[wi]), (int)(plan_L + tv.iptr[wi + 1])};
-            return a.U + tv.irow[wi];
-        } else {
-            if (!(CRH_ABLATE(a.ablate) & 1)) range_out = a.range[w];
-            return w;
-        }
+        if (!(CRH_ABLATE(a.ablate) & 1)) range_out = a.range[w];
+        return w;
     };
     // first round trip of the row chain, issued before the batch sums are reduced
     int2 rg = {0, 0};
@@ -1381,10 +1302,6 @@ __global__ __launch_bounds__(BPR_THREADS, MF_OCC_N) void mf_step_kernel(MfStepAr
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int i = threadIdx.x; i < ((CRH_ABLATE(a.ablate) & 2) ? 1 : a.n_in); i += BPR_THREADS) {
             const f32x4 x = reinterpret_cast<const f32x4*>(a.part_in)[i];
-            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
-        }
-        for (int i = threadIdx.x; i < a.n_in2; i += BPR_THREADS) {
-            const f32x4 x = reinterpret_cast<const f32x4*>(a.part_in2)[i];
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
 #pragma unroll
@@ -1436,9 +1353,9 @@ __global__ __launch_bounds__(BPR_THREADS, MF_OCC_N) void mf_step_kernel(MfStepAr
             if (rg.y - rg.x > BPR_HEAVY) continue;                // a heavy block does this row, Adam included
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float loss = 0.f;
-            if (rg.y > rg.x) mf_row_entries<G, false, MF_NQ_N>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
+            if (rg.y > rg.x) mf_row_entries<G, MF_NQ_N>(a, k, row < a.U, rg.x, rg.y, on, lig, own, acc, loss);
             if (lig == 0) sl += loss;
-            mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn, rg.y > rg.x);
+            mf_row_update<G, OPT>(a, row, on, lig, own, m0, v0, acc, mult, bc2_sqrt, nss, su, sp, sn);
         }
     } else {
         const PlanView pv = plan_view(a.plan);
@@ -1457,7 +1374,7 @@ __global__ __launch_bounds__(BPR_THREADS, MF_OCC_N) void mf_step_kernel(MfStepAr
             own = acc;
             if (on) own = reinterpret_cast<const f32x4*>(a.pin + row * a.d)[lig];
             float loss = 0.f;
-            if (e0 < hr.y) mf_row_entries<G, false, MF_NQ_N>(a, k, user_side, e0, e1, on, lig, own, acc, loss);
+            if (e0 < hr.y) mf_row_entries<G, MF_NQ_N>(a, k, user_side, e0, e1, on, lig, own, acc, loss);
             if (lig == 0) sl += loss;
 #pragma unroll
             for (int off = G; off < 64; off <<= 1) {
@@ -1504,329 +1421,6 @@ extern "C" int crh_profile_mf_clocks(unsigned long long* out_host, int n_blocks)
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(crh_mf_clk), (size_t)n_blocks * 16) == hipSuccess ? 0 : -1;
 }
 #endif
-
-// ---------------------------------------------------------------- the whole EPOCH of BPR-MF steps in one launch
-// mf_step_kernel re-reads p, m, v of every row from the fabric each step: the 8 L2s are not coherent with each other, a
-// kernel boundary writes them back and invalidates them, so nothing a step wrote is still on chip when the next one
-// starts (PMC: 24 MB read + 15 MB written per launch -- everything).  A lane group owns the SAME rows in every step,
-// though: here it keeps their p, m, v in REGISTERS for the whole epoch, and the steps are separated by a grid-wide
-// barrier instead of a kernel boundary.  What still crosses the fabric per step is what other workgroups need: the
-// updated p rows (gathered by the next step's entries) and the [4]-float partial sums.  Every workgroup must be
-// resident (the barrier spins): the grid is sized by crh_mf_epoch_blocks from the kernel's occupancy, and the spin is
-// bounded -- a barrier that does not complete in ~1 s sets sync[2] and lets the launch run out instead of hanging.
-// Heavy rows (more than BPR_HEAVY entries in a batch) are summed by the whole workgroup of their owner -- the same
-// split over lane groups and the same combine order as mf_step_kernel's heavy workgroups -- in a fixed order.
-struct MfEpochArgs {
-    float* p0;             // (U + I, d): the table; step s reads buffer s & 1 and writes the other; the result ends in p0
-    float* p1;
-    float* m;
-    float* v;
-    int64_t U, I;
-    int d;
-    int64_t L;             // batch size (the last batch may be shorter: n_records)
-    int64_t n_records;
-    int n_steps;
-    float reg;
-    const int2* range;     // [n_steps][U + I]
-    const int2* entries;   // [n_steps][3 L]
-    const int32_t* mult;   // [n_steps][U + I]: multiplicities of batch s
-    const float* part0;    // [n_part0][4]: norms^2 of batch 0 (crh_bpr_fwd_f32's partial sums)
-    int n_part0;
-    float* parts;          // [2][gridDim.x][4]
-    float* losses;         // [n_steps][2]
-    const float* scalars;  // [n_steps][2] (Adam)
-    AdamK k;
-    float neg_lr;          // SGD
-    unsigned* sync;        // 2048 words: barrier counters, exits (all back to 0 when the launch ends), [2] sticky error flag
-};
-
-// Grid barrier number `round` (1, 2, ...) of a launch whose workgroups are all resident.  Arrivals are counted per XCD
-// (workgroup b runs on XCD b % 8: eight counters on eight cache lines instead of one address every workgroup hits), the
-// last arrival of an XCD bumps the global word everybody polls.  No cache maintenance: everything that crosses
-// workgroups inside the launch (parameter rows, partial sums) is written and read with device-scope accesses
-// (mf_st_coh / mf_ld_coh), which are complete when the waves pass the workgroup barrier (vmcnt 0) -- a write-back of
-// the L2 per workgroup (what a release fence does) cost 30 us per step, an invalidate per workgroup 15; the counters
-// and the poll are relaxed device-scope atomics.
-// sync words (2048 of them; every counter on its own 256-byte stretch): [0] XCD groups that completed a round, [1] exits,
-// [2] error, [64 (x + 1)] arrivals of XCD x, [1024 + 64 x] the round XCD x's workgroups may leave (polled).
-__device__ __forceinline__ void mf_grid_barrier(unsigned* sync, unsigned round) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
-        const unsigned x = blockIdx.x % 8u;
-        const unsigned mine = (gridDim.x - x + 7u) / 8u;                      // workgroups on this XCD
-        const unsigned old = __hip_atomic_fetch_add(&sync[64 * (x + 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == round * mine) {
-            const unsigned g = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g + 1u == round * groups)                                     // the last XCD in: release everybody
-                for (unsigned y = 0; y < groups; ++y)
-                    __hip_atomic_store(&sync[1024 + 64 * y], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned spins = 0;
-        while (__hip_atomic_load(&sync[1024 + 64 * x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 21)) {      // not every workgroup is running: give up instead of hanging the device
-                __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-template <int G, int OPT, int NR>
-__global__ __launch_bounds__(BPR_THREADS, 3) void mf_epoch_kernel(MfEpochArgs a) {
-    constexpr int NGB = BPR_THREADS / G;
-    __shared__ f32x4 red4[4];
-    __shared__ float red[4];
-    __shared__ f32x4 wsum[4][G];
-    __shared__ int hflag[NGB * NR];
-    const int lig = threadIdx.x % G, gg = threadIdx.x / G;
-    const bool on = lig < (a.d >> 2);
-    const int64_t R = a.U + a.I;
-    // slot q = gg + j NGB of workgroup b owns row q gridDim.x + b: CONSECUTIVE rows go to consecutive workgroups, so a run
-    // of popular items (ids are often assigned by popularity) is spread over the grid instead of landing in one workgroup
-    const int64_t gid = (int64_t)gg * gridDim.x + blockIdx.x, gstride = (int64_t)gridDim.x * NGB;
-    f32x4 p[NR], m[NR], v[NR];
-    bool have[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int64_t row = gid + j * gstride;
-        have[j] = row < R;
-        p[j] = m[j] = v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (have[j] && on) {
-            const int64_t o = row * a.d + lig * 4;
-            p[j] = *reinterpret_cast<const f32x4*>(a.p0 + o);
-            if constexpr (OPT == 0) {
-                m[j] = *reinterpret_cast<const f32x4*>(a.m + o);
-                v[j] = *reinterpret_cast<const f32x4*>(a.v + o);
-            }
-        }
-    }
-    MfStepArgs sa{};
-    sa.d = a.d;
-    sa.U = a.U;
-    sa.I = a.I;
-#ifdef CRH_PROFILE
-#define MF_EPOCH_STAMP(i) do { if (s == 10 && threadIdx.x == 0 && blockIdx.x < 1024) crh_mf_clk[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define MF_EPOCH_STAMP(i) do {} while (0)
-#endif
-    // per-step metadata of the owned rows: entry range, multiplicity in the NEXT batch, the first entries' metadata
-    int2 rg[NR], en0[NR];
-    int mu[NR];
-    auto fetch_meta = [&](int s) {
-        const int2* range = a.range + (int64_t)s * R;
-        const int32_t* mult2 = s + 1 < a.n_steps ? a.mult + (int64_t)(s + 1) * R : nullptr;
-        const int2* entries = a.entries + (int64_t)s * 3 * a.L;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            rg[j] = en0[j] = int2{0, 0};
-            mu[j] = 0;
-            if (have[j] && s < a.n_steps) {
-                rg[j] = range[gid + j * gstride];
-                if (mult2) mu[j] = mult2[gid + j * gstride];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int len = rg[j].y - rg[j].x;
-            if (len > 0 && len <= BPR_HEAVY && lig < len) en0[j] = entries[rg[j].x + lig];
-        }
-    };
-    fetch_meta(0);
-    for (int s = 0; s < a.n_steps; ++s) {
-        MF_EPOCH_STAMP(0);
-        const float* pin = (s & 1) ? a.p1 : a.p0;
-        float* pout = (s & 1) ? a.p0 : a.p1;
-        sa.pin = pin;
-        sa.entries = a.entries + (int64_t)s * 3 * a.L;
-        const int64_t left = a.n_records - (int64_t)s * a.L;
-        const int64_t Bs = left < a.L ? left : a.L;
-        const int2* range = a.range + (int64_t)s * R;
-        // (rg, mu, en0 of this step were fetched before the previous step's barrier: the tables are constant)
-        // batch sums: every workgroup reduces the previous step's partial sums in the same order
-        f32x4 tot;
-        {
-            const float* part_in = s ? a.parts + (size_t)((s - 1) & 1) * gridDim.x * 4 : a.part0;
-            const int n_in = s ? (int)gridDim.x : a.n_part0;
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            for (int i = threadIdx.x; i < n_in; i += BPR_THREADS) {
-                const f32x4 x = mf_ld_coh(part_in + (size_t)i * 4);
-                t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off);
-                t.z += __shfl_xor(t.z, off); t.w += __shfl_xor(t.w, off);
-            }
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = t;
-            __syncthreads();
-            const f32x4 t0 = red4[0], t1 = red4[1], t2 = red4[2], t3 = red4[3];
-            tot.x = (t0.x + t1.x) + (t2.x + t3.x);
-            tot.y = (t0.y + t1.y) + (t2.y + t3.y);
-            tot.z = (t0.z + t1.z) + (t2.z + t3.z);
-            tot.w = (t0.w + t1.w) + (t2.w + t3.w);
-        }
-        MF_EPOCH_STAMP(1);
-        BwdCoef k;
-        k.invB = 1.0f / (float)Bs;
-        {
-            const float nu_ = sqrtf(tot.x), np_ = sqrtf(tot.y), nn = sqrtf(tot.z);
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                a.losses[2 * s + 1] = a.reg * (nu_ * k.invB + np_ * k.invB + nn * k.invB);
-                if (s) a.losses[2 * (s - 1)] = tot.w * (1.0f / (float)a.L);    // (only the last batch can be short)
-            }
-            k.cu = nu_ > 0.f ? a.reg * k.invB / nu_ : 0.f;
-            k.cp = np_ > 0.f ? a.reg * k.invB / np_ : 0.f;
-            k.cn = nn > 0.f ? a.reg * k.invB / nn : 0.f;
-        }
-        float bc2_sqrt = 0.f, nss = 0.f;
-        if constexpr (OPT == 0) {
-            bc2_sqrt = a.scalars[2 * s];
-            nss = a.scalars[2 * s + 1];
-        }
-        f32x4 grad[NR];
-        float sl = 0.f;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            grad[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int len = rg[j].y - rg[j].x;
-            if (len > 0 && len <= BPR_HEAVY) {
-                float loss = 0.f;
-                mf_row_entries<G, true>(sa, k, gid + j * gstride < a.U, rg[j].x, rg[j].y, on, lig, p[j], grad[j], loss, &en0[j]);
-                if (lig == 0) sl += loss;
-            }
-        }
-        MF_EPOCH_STAMP(2);
-        // heavy rows of this workgroup, in (lane group, slot) order: all lane groups split the row's entries
-        __syncthreads();
-        if (lig == 0) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) hflag[gg * NR + j] = (rg[j].y - rg[j].x) > BPR_HEAVY ? 1 : 0;
-        }
-        __syncthreads();
-        for (int t = 0; t < NGB * NR; ++t) {
-            if (!hflag[t]) continue;                              // the same for the whole workgroup
-            const int og = t / NR, oj = t % NR;
-            const int64_t row = (int64_t)og * gridDim.x + blockIdx.x + oj * gstride;
-            const int2 hr = range[row];
-            int chunk = (hr.y - hr.x + NGB - 1) / NGB;
-            chunk = (chunk + 3) & ~3;
-            const int e0 = hr.x + gg * chunk;
-            const int e1 = e0 + chunk < hr.y ? e0 + chunk : hr.y;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, own = acc;
-            if (on) own = mf_ld_coh(pin + row * a.d + lig * 4);
-            float loss = 0.f;
-            if (e0 < hr.y) mf_row_entries<G, true>(sa, k, row < a.U, e0, e1, on, lig, own, acc, loss);
-            if (lig == 0) sl += loss;
-#pragma unroll
-            for (int off = G; off < 64; off <<= 1) {
-                acc.x += __shfl_down(acc.x, off);
-                acc.y += __shfl_down(acc.y, off);
-                acc.z += __shfl_down(acc.z, off);
-                acc.w += __shfl_down(acc.w, off);
-            }
-            __syncthreads();
-            if ((threadIdx.x & 63) < G) wsum[threadIdx.x >> 6][lig] = acc;
-            __syncthreads();
-            if (gg == og) {
-                const f32x4 t0 = wsum[0][lig], t1 = wsum[1][lig], t2 = wsum[2][lig], t3 = wsum[3][lig];
-                f32x4 r;
-                r.x = (t0.x + t1.x) + (t2.x + t3.x);
-                r.y = (t0.y + t1.y) + (t2.y + t3.y);
-                r.z = (t0.z + t1.z) + (t2.z + t3.z);
-                r.w = (t0.w + t1.w) + (t2.w + t3.w);
-#pragma unroll
-                for (int j = 0; j < NR; ++j)
-                    if (j == oj) grad[j] = r;
-            }
-        }
-        MF_EPOCH_STAMP(3);
-        // optimiser in registers; the new row goes to the other buffer for the next step's gathers
-        float su = 0.f, sp = 0.f, sn = 0.f;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            if (!have[j]) continue;
-            const int64_t row = gid + j * gstride;
-            if (on) {
-                if constexpr (OPT == 0) adam_elem4(p[j], m[j], v[j], grad[j], a.k, bc2_sqrt, nss);
-                else sgd_elem4(p[j], grad[j], a.neg_lr);
-                mf_st_coh(pout + row * a.d + lig * 4, p[j]);
-            }
-            if (mu[j] == 0) continue;                             // uniform over the lane group
-            const float nsq = group_sum<G>(on ? dot4(p[j], p[j]) : 0.f);
-            if (lig == 0) {
-                if (row < a.U) {
-                    su += (float)mu[j] * nsq;
-                } else {
-                    sp += (float)(mu[j] & 0xffff) * nsq;
-                    sn += (float)(mu[j] >> 16) * nsq;
-                }
-            }
-        }
-        {   // the four block sums in one pass (component-wise the arithmetic of block_sum)
-            f32x4 t = {su, sp, sn, sl};
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off);
-                t.z += __shfl_xor(t.z, off); t.w += __shfl_xor(t.w, off);
-            }
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = t;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const f32x4 t0 = red4[0], t1 = red4[1], t2 = red4[2], t3 = red4[3];
-                f32x4 r;
-                r.x = (t0.x + t1.x) + (t2.x + t3.x);
-                r.y = (t0.y + t1.y) + (t2.y + t3.y);
-                r.z = (t0.z + t1.z) + (t2.z + t3.z);
-                r.w = (t0.w + t1.w) + (t2.w + t3.w);
-                mf_st_coh(a.parts + ((size_t)(s & 1) * gridDim.x + blockIdx.x) * 4, r);
-            }
-        }
-        // the next step's metadata: in flight while the workgroups meet
-        fetch_meta(s + 1);
-        MF_EPOCH_STAMP(4);
-        mf_grid_barrier(a.sync, (unsigned)(s + 1));
-        MF_EPOCH_STAMP(5);
-    }
-    // optimiser state back to memory; the table ends in p0 whatever the parity of the epoch
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        if (!have[j] || !on) continue;
-        const int64_t o = (gid + j * gstride) * a.d + lig * 4;
-        if (a.n_steps & 1) *reinterpret_cast<f32x4*>(a.p0 + o) = p[j];
-        if constexpr (OPT == 0) {
-            *reinterpret_cast<f32x4*>(a.m + o) = m[j];
-            *reinterpret_cast<f32x4*>(a.v + o) = v[j];
-        }
-    }
-    if (blockIdx.x == 0 && a.n_steps > 0) {                        // bpr loss of the last step
-        const float* part_in = a.parts + (size_t)((a.n_steps - 1) & 1) * gridDim.x * 4;
-        float t = 0.f;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += BPR_THREADS) {
-            const f32x4 x = mf_ld_coh(part_in + (size_t)i * 4);
-            t += x.w;
-        }
-        t = block_sum(t, red);
-        const int64_t left = a.n_records - (int64_t)(a.n_steps - 1) * a.L;
-        if (threadIdx.x == 0) a.losses[2 * (a.n_steps - 1)] = t * (1.0f / (float)(left < a.L ? left : a.L));
-    }
-    if (threadIdx.x == 0) {
-        const unsigned gone = __hip_atomic_fetch_add(&a.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (gone == gridDim.x - 1) {                              // the last workgroup out leaves the counters at zero
-            __hip_atomic_store(&a.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int x = 0; x < 8; ++x) {
-                __hip_atomic_store(&a.sync[64 * (x + 1)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.sync[1024 + 64 * x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
 
 // Flatten the plans of an epoch for mf_step_kernel (grid.y = batch): per table row its entry range and its
 // multiplicities, per entry the two other rows of the triple.  range / mult must be zero on entry.
@@ -2268,16 +1862,6 @@ extern "C" void crh_adam_step_scalars_host(double lr, double beta1, double beta2
 
 
 // ---------------------------------------------------------------- MF step in one launch (see mf_step_kernel)
-// workgroups of crh_bpr_grad_rows_f32 for a batch of `batch` triples = entries (of 4 floats) of its part_out: the batch
-// touches at most 3 * batch rows (MF_ROWS per lane group), plus the heavy-row workgroups
-extern "C" int crh_bpr_grad_parts(int64_t batch, int d) {
-    if (batch <= 0 || d < 4 || d > 256 || d % 4) return 0;
-    const int64_t per_block = (BPR_THREADS / pick_group(d)) * MF_ROWS;
-    int64_t light = (3 * batch + per_block - 1) / per_block;
-    if (light > MF_MAX_LIGHT) light = MF_MAX_LIGHT;
-    return (int)light + MF_HEAVY_BLOCKS;
-}
-
 extern "C" int crh_mf_step_parts(int64_t n_rows, int d) {
     if (n_rows <= 0 || d < 4 || d > 256 || d % 4) return 0;
     // MF_ROWS table rows per lane group (the second through the grid-stride loop): all blocks of a MovieLens-sized
@@ -2334,10 +1918,9 @@ int mf_step_run(const char* who, int opt, const float* table_in, float* table_ou
                 int64_t item_rows, int d, int64_t batch, float reg, const int32_t* plan, const int32_t* range,
                 const int32_t* entries, const int32_t* mult_next, const float* part_in, int n_parts_in, float* part_out,
                 float* loss_prev_out, int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
-                const float* step_scalars, double lr, void* stream, const float* part_in2 = nullptr, int n_parts_in2 = 0) {
+                const float* step_scalars, double lr, void* stream) {
     CRH_CHECK_ARG(table_in && table_out && table_in != table_out, "%s: NULL / aliased tables", who);
     CRH_CHECK_ARG(opt != 0 || (m && v && step_scalars), "%s: NULL optimiser state / step scalars", who);
-    CRH_CHECK_ARG(n_parts_in2 == 0 || part_in2, "%s: NULL second partial-sum source", who);
     CRH_CHECK_ARG(user_rows > 0 && item_rows > 0 && batch > 0, "%s: empty table or batch", who);
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "%s: d=%d must be a multiple of 4, at most 256", who, d);
     CRH_CHECK_ARG(plan && range && entries, "%s: NULL plan / step tables", who);
@@ -2354,22 +1937,19 @@ int mf_step_run(const char* who, int opt, const float* table_in, float* table_ou
     a.entries = reinterpret_cast<const int2*>(entries);
     a.mult2 = mult_next;
     a.part_in = part_in; a.n_in = n_parts_in; a.part_out = part_out;
-    a.part_in2 = part_in2; a.n_in2 = n_parts_in2;
     a.loss_prev = loss_prev_out; a.inv_b_prev = loss_prev_out ? 1.0f / (float)batch_prev : 0.f;
     a.loss_now = loss_out;
     a.k = AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
     a.step_scalars = step_scalars;
     a.neg_lr = (float)(-lr);
-    const int parts = opt == 3 ? crh_bpr_grad_parts(batch, d) : crh_mf_step_parts(user_rows + item_rows, d);
+    const int parts = crh_mf_step_parts(user_rows + item_rows, d);
     a.light_blocks = parts - MF_HEAVY_BLOCKS;
     static const int ablate = CRH_PROFILE_ENV("CRH_MF_ABLATE");
     a.ablate = ablate;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dispatch_group(pick_group(d), [&](auto gc) -> int {
         constexpr int GG = decltype(gc)::value;
-        if (opt == 3) hipLaunchKernelGGL((mf_step_kernel<GG, 3>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
-        else if (opt == 2) hipLaunchKernelGGL((mf_step_kernel<GG, 2>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
-        else if (opt == 1) hipLaunchKernelGGL((mf_step_kernel<GG, 1>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
+        if (opt == 1) hipLaunchKernelGGL((mf_step_kernel<GG, 1>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         else hipLaunchKernelGGL((mf_step_kernel<GG, 0>), dim3((unsigned)parts), dim3(BPR_THREADS), 0, st, a);
         CRH_HIP(hipGetLastError());
         return CRH_OK;
@@ -2398,116 +1978,6 @@ extern "C" int crh_mf_step_sgd_f32(const float* table_in, float* table_out, int6
     return mf_step_run("crh_mf_step_sgd_f32", 1, table_in, table_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
                        plan, range, entries, mult_next, part_in, n_parts_in, part_out, loss_prev_out, batch_prev, loss_out,
                        0.9, 0.999, 1e-8, nullptr, lr, stream);
-}
-
-// The gradient half of that step alone (LightGCN, model/LightGCN.py:23-26: the tables are the PROPAGATED embeddings, the
-// optimiser acts on the raw ones after the backward propagation): d(bpr_loss + l2_reg_loss)/d(table) row by row into
-// `grad_out` -- rows the batch does not touch are left as they are (keep them zero) -- with the score differences
-// recomputed from the gathered rows, so no forward pass over the batch exists any more: the three batch norms arrive as
-// partial sums from the launch that produced the table (crh_spmm_csr_norms_f32: norm_part / n_norm_parts), the previous
-// batch's loss sum from the previous call of this function (loss_part_prev / n_loss_parts_prev, or NULL / 0);
-// part_out[crh_bpr_grad_parts(batch, d)][4] receives this batch's loss sum in component 3.  Work items are the rows the
-// batch touches (from the plan), heavy rows by a workgroup each.
-extern "C" int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows, int64_t item_rows, int d,
-                                     int64_t batch, float reg, const int32_t* plan, const int32_t* range,
-                                     const int32_t* entries, const float* norm_part, int n_norm_parts,
-                                     const float* loss_part_prev, int n_loss_parts_prev, float* part_out,
-                                     float* loss_prev_out, int64_t batch_prev, float* loss_out, void* stream) {
-    return mf_step_run("crh_bpr_grad_rows_f32", 3, table, grad_out, nullptr, nullptr, user_rows, item_rows, d, batch, reg,
-                       plan, range, entries, nullptr, norm_part, n_norm_parts, part_out, loss_prev_out, batch_prev, loss_out,
-                       0.9, 0.999, 1e-8, nullptr, 0.0, stream, loss_part_prev, n_loss_parts_prev);
-}
-
-// ---- the epoch in one launch (mf_epoch_kernel)
-namespace {
-constexpr int MF_EPOCH_ROWS = 2;        // table rows a lane group keeps in registers
-
-// workgroups of mf_epoch_kernel that can be resident at once on the current device (0: unknown / error)
-template <int G, int OPT>
-int mf_epoch_capacity() {
-    static int cap = -1;
-    if (cap < 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_epoch_kernel<G, OPT, MF_EPOCH_ROWS>, BPR_THREADS, 0) !=
-                hipSuccess) {
-            (void)hipGetLastError();
-            return 0;
-        }
-        cap = per_cu * cus;
-    }
-    return cap;
-}
-
-int mf_epoch_grid(int64_t n_rows, int d) {
-    const int64_t per_block = (BPR_THREADS / pick_group(d)) * MF_EPOCH_ROWS;
-    return (int)((n_rows + per_block - 1) / per_block);
-}
-}  // namespace
-
-// Workgroups (= [4]-float partial sums per parity) of crh_mf_epoch_f32 for a table of n_rows x d, or 0 when the epoch
-// cannot run as one launch: every workgroup has to be resident at the same time (they meet at a barrier after each
-// step), which bounds the table at (resident workgroups) x (lane groups per workgroup) x 2 rows -- 12 288 rows of
-// d = 128 on an MI355X.  optimizer: 0 = Adam, 1 = SGD.
-extern "C" int crh_mf_epoch_blocks(int64_t n_rows, int d, int optimizer) {
-    if (n_rows <= 0 || d < 4 || d > 256 || d % 4 || n_rows > ((int64_t)1 << 30)) return 0;
-    const int grid = mf_epoch_grid(n_rows, d);
-    const int cap = dispatch_group(pick_group(d), [&](auto gc) -> int {
-        constexpr int GG = decltype(gc)::value;
-        return optimizer ? mf_epoch_capacity<GG, 1>() : mf_epoch_capacity<GG, 0>();
-    });
-    return grid <= cap ? grid : 0;
-}
-
-// One EPOCH of BPR-MF optimiser steps in one launch: the steps crh_mf_step_f32 / crh_mf_step_sgd_f32 would run one
-// by one over the same step tables (crh_mf_step_tables: range [n_steps][rows], entries [n_steps][3 batch], mult
-// [n_steps][rows]), with every row's p, m, v held in registers from the first step to the last.  table0 holds the
-// parameters and receives the result; table1 is scratch of the same size (the steps alternate between the two).
-// part0 / n_part0: crh_bpr_fwd_f32's partial sums over batch 0.  parts: 2 x crh_mf_epoch_blocks x 4 floats of scratch.
-// losses: [n_steps][2] (bpr, l2) of every step.  step_scalars: [n_steps][2] Adam factors (crh_adam_step_scalars), NULL
-// for SGD.  sync: 2048 zero-initialised uint32 owned by the caller for as long as it launches epochs; sync[2] != 0 after
-// a launch means a barrier timed out (not every workgroup was resident) and the results are invalid.
-extern "C" int crh_mf_epoch_f32(float* table0, float* table1, float* m, float* v, int64_t user_rows, int64_t item_rows,
-                                int d, int64_t batch, int64_t n_records, float reg, const int32_t* range,
-                                const int32_t* entries, const int32_t* mult, const float* part0, int n_part0, float* parts,
-                                float* losses, double beta1, double beta2, double eps, const float* step_scalars,
-                                int optimizer, double lr, uint32_t* sync, void* stream) {
-    CRH_CHECK_ARG(table0 && table1 && table0 != table1, "crh_mf_epoch_f32: NULL / aliased tables");
-    CRH_CHECK_ARG(optimizer == 0 || optimizer == 1, "crh_mf_epoch_f32: optimizer=%d (0 Adam, 1 SGD)", optimizer);
-    CRH_CHECK_ARG(optimizer != 0 || (m && v && step_scalars), "crh_mf_epoch_f32: NULL optimiser state / step scalars");
-    CRH_CHECK_ARG(user_rows > 0 && item_rows > 0 && batch > 0 && n_records > 0, "crh_mf_epoch_f32: empty table or epoch");
-    CRH_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "crh_mf_epoch_f32: d=%d must be a multiple of 4, at most 256", d);
-    CRH_CHECK_ARG(range && entries && mult && part0 && n_part0 > 0 && parts && losses && sync,
-                  "crh_mf_epoch_f32: NULL step tables / partial sums / losses / sync words");
-    CRH_CHECK_ARG((((uintptr_t)table0 | (uintptr_t)table1 | (uintptr_t)m | (uintptr_t)v | (uintptr_t)part0 | (uintptr_t)parts) & 15) == 0,
-                  "crh_mf_epoch_f32: tables and partial sums must be 16-byte aligned");
-    const int64_t n_steps = (n_records + batch - 1) / batch;
-    CRH_CHECK_ARG(n_steps <= (1 << 20), "crh_mf_epoch_f32: %lld steps in one launch", (long long)n_steps);
-    const int grid = crh_mf_epoch_blocks(user_rows + item_rows, d, optimizer);
-    CRH_CHECK_ARG(grid > 0, "crh_mf_epoch_f32: a table of %lld rows x %d does not fit one resident grid (crh_mf_epoch_blocks = 0): "
-                  "run the steps one by one (crh_mf_step_f32)", (long long)(user_rows + item_rows), d);
-    MfEpochArgs a;
-    a.p0 = table0; a.p1 = table1; a.m = m; a.v = v;
-    a.U = user_rows; a.I = item_rows; a.d = d;
-    a.L = batch; a.n_records = n_records; a.n_steps = (int)n_steps;
-    a.reg = reg;
-    a.range = reinterpret_cast<const int2*>(range);
-    a.entries = reinterpret_cast<const int2*>(entries);
-    a.mult = mult;
-    a.part0 = part0; a.n_part0 = n_part0;
-    a.parts = parts; a.losses = losses; a.scalars = step_scalars;
-    a.k = AdamK{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
-    a.neg_lr = (float)(-lr);
-    a.sync = sync;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return dispatch_group(pick_group(d), [&](auto gc) -> int {
-        constexpr int GG = decltype(gc)::value;
-        if (optimizer) hipLaunchKernelGGL((mf_epoch_kernel<GG, 1, MF_EPOCH_ROWS>), dim3((unsigned)grid), dim3(BPR_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((mf_epoch_kernel<GG, 0, MF_EPOCH_ROWS>), dim3((unsigned)grid), dim3(BPR_THREADS), 0, st, a);
-        CRH_HIP(hipGetLastError());
-        return CRH_OK;
-    });
 }
 
 // bpr loss of the LAST step of an epoch from its partial sums.

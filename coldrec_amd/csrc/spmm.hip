@@ -53,16 +53,6 @@ struct SpmmArgs {
     int zero_acc_in;        // clear acc_in's row once it has been consumed (ready for the next step's scatter)
     int sgd;                // optimiser epilogue is plain SGD: p <- fma(neg_step_size, g, p), no m / v
     int use_slab;           // light rows from the schedule's record stream (sched.slab, laid out for this launch's G)
-    // optional (crh_spmm_csr_norms_f32): the squared Frobenius norms of the NEXT BPR batch's gathered blocks, summed from the
-    // rows this launch writes to acc_out -- mult[row] = how often the batch gathers the row (user rows: count; item rows:
-    // positives | negatives << 16); every workgroup leaves {sum u^2, sum p^2, sum n^2, 0} in norm_part[blockIdx.x]
-    const int32_t* mult;
-    float* norm_part;
-    int64_t user_rows;
-};
-
-struct NormAcc {
-    float su, sp, sn;
 };
 
 __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
@@ -76,16 +66,13 @@ __device__ __forceinline__ void fma4(f32x4& acc, float v, const f32x4& x) {
 // beside them: the row's acc_in and, with the optimiser in the epilogue, its p / m / v.
 struct RowPre {
     f32x4 z, p, m, v;
-    int mu;
 };
 
 __device__ __forceinline__ RowPre row_prefetch(const SpmmArgs& a, int64_t o, bool live, int64_t row) {
     RowPre r;
     r.z = r.p = r.m = r.v = f32x4{0.f, 0.f, 0.f, 0.f};
-    r.mu = 0;
     if (!live) return r;
     if ((a.acc_out || a.adam_p) && a.acc_in) r.z = *reinterpret_cast<const f32x4*>(a.acc_in + o);
-    if (a.mult) r.mu = a.mult[row];
     if (a.adam_p) {
         r.p = *reinterpret_cast<const f32x4*>(a.adam_p + o);
         if (!a.sgd) {
@@ -96,7 +83,7 @@ __device__ __forceinline__ RowPre row_prefetch(const SpmmArgs& a, int64_t o, boo
     return r;
 }
 
-__device__ __forceinline__ void store_row_pre(const SpmmArgs& a, int64_t o, const f32x4& acc, RowPre q, int64_t row, NormAcc& na) {
+__device__ __forceinline__ void store_row_pre(const SpmmArgs& a, int64_t o, const f32x4& acc, RowPre q, int64_t row) {
     if (a.Y) *reinterpret_cast<f32x4*>(a.Y + o) = acc;
     if (a.acc_out || a.adam_p) {
         f32x4 r;
@@ -105,18 +92,6 @@ __device__ __forceinline__ void store_row_pre(const SpmmArgs& a, int64_t o, cons
         r.z = (q.z.z * a.s_in + acc.z) * a.s_out;
         r.w = (q.z.w * a.s_in + acc.w) * a.s_out;
         if (a.acc_out) *reinterpret_cast<f32x4*>(a.acc_out + o) = r;
-        if (a.mult) {        // per LANE (no cross-lane step here: only the lanes of the row's columns get this far)
-            const int mu = q.mu;
-            if (mu) {
-                const float nsq = ((r.x * r.x + r.y * r.y) + r.z * r.z) + r.w * r.w;
-                if (row < a.user_rows) {
-                    na.su += (float)mu * nsq;
-                } else {
-                    na.sp += (float)(mu & 0xffff) * nsq;
-                    na.sn += (float)(mu >> 16) * nsq;
-                }
-            }
-        }
         if (a.adam_p && a.sgd) {
             sgd_elem4(q.p, r, a.neg_step_size);
             *reinterpret_cast<f32x4*>(a.adam_p + o) = q.p;
@@ -132,8 +107,8 @@ __device__ __forceinline__ void store_row_pre(const SpmmArgs& a, int64_t o, cons
     }
 }
 
-__device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc, int64_t row, NormAcc& na) {
-    store_row_pre(a, o, acc, row_prefetch(a, o, true, row), row, na);
+__device__ __forceinline__ void store_row(const SpmmArgs& a, int64_t o, const f32x4& acc, int64_t row) {
+    store_row_pre(a, o, acc, row_prefetch(a, o, true, row), row);
 }
 
 // Accumulate edges [e0, e1) of one row into acc for this lane's 16-B column slice, in edge order.
@@ -257,7 +232,7 @@ __device__ __forceinline__ void slab_unit(const SpmmArgs& a, const uint2& u, int
 }
 
 template <int G>
-__device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c, bool on, int lig, NormAcc& na) {
+__device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c, bool on, int lig) {
     const crh_spmm_sched& sc = a.sched;
     const uint2* stream = reinterpret_cast<const uint2*>(sc.slab);
     const int64_t w = jl * (256 / G) + threadIdx.x / G;
@@ -302,7 +277,7 @@ __device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c,
             cur = nxt;
         }
     }
-    if (un > 0 && on) store_row_pre(a, o, acc, pre, row, na);
+    if (un > 0 && on) store_row_pre(a, o, acc, pre, row);
 }
 
 // One heavy row (more than the schedule's segment length of edges) by a whole workgroup: its 256 / GG lane groups of GG
@@ -311,7 +286,7 @@ __device__ __forceinline__ void slab_light(const SpmmArgs& a, int64_t jl, int c,
 // (One WAVE per heavy row of up to 256 / 512 / 1024 edges instead, four rows per block, measured no gain: LightGCN step
 // 158.7 -> 159.4 / 161.8 / 165.7 us.)
 template <int GG>
-__device__ __forceinline__ void heavy_row(const SpmmArgs& a, int64_t row, int c0, int c_end, f32x4 (*wsum)[64], NormAcc& na) {
+__device__ __forceinline__ void heavy_row(const SpmmArgs& a, int64_t row, int c0, int c_end, f32x4 (*wsum)[64]) {
     constexpr int NGB = 256 / GG;
     const int lig = threadIdx.x % GG, gg = threadIdx.x / GG;
     const int c = c0 + lig;
@@ -345,7 +320,7 @@ __device__ __forceinline__ void heavy_row(const SpmmArgs& a, int64_t row, int c0
         r.y = (t0.y + t1.y) + (t2.y + t3.y);
         r.z = (t0.z + t1.z) + (t2.z + t3.z);
         r.w = (t0.w + t1.w) + (t2.w + t3.w);
-        store_row(a, row * a.d + (int64_t)c * 4, r, row, na);
+        store_row(a, row * a.d + (int64_t)c * 4, r, row);
     }
 }
 
@@ -361,7 +336,7 @@ __device__ __forceinline__ void heavy_row(const SpmmArgs& a, int64_t row, int c0
 // Light path: work item = one row (no schedule) or one single-segment row; a lane group of G lanes owns the
 // row's 16*G-byte column slice and finishes it (bit-identical to the oracle's edge-order chain).
 template <int G>
-__device__ __forceinline__ void spmm_body(const SpmmArgs& a, NormAcc& na) {
+__device__ __forceinline__ void spmm_body(const SpmmArgs& a) {
     const int lig = threadIdx.x % G;
     const int xcd = blockIdx.x & 7;
     const int slice = xcd % a.cs;
@@ -375,7 +350,7 @@ __device__ __forceinline__ void spmm_body(const SpmmArgs& a, NormAcc& na) {
         if (jl >= a.light_blocks || (CRH_ABLATE(a.skip) & 2)) return;
         if constexpr (G == 8) {       // (wider lane groups: 16 - 32 gathers of a unit in flight cost the kernel its occupancy)
             if (a.use_slab) {
-                slab_light<G>(a, jl, c, on, lig, na);
+                slab_light<G>(a, jl, c, on, lig);
                 return;
             }
         }
@@ -401,7 +376,7 @@ __device__ __forceinline__ void spmm_body(const SpmmArgs& a, NormAcc& na) {
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             row_edges<G>(a, e0, e1, c, on, lig, acc);
-            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc, row, na);
+            if (on) store_row(a, row * a.d + (int64_t)c * 4, acc, row);
         }
         return;
     }
@@ -411,39 +386,14 @@ __device__ __forceinline__ void spmm_body(const SpmmArgs& a, NormAcc& na) {
     const int cut = a.sched.multi_count ? a.sched.multi_count[j] : 1;
     const int n_sub = cut & 255, sub = cut >> 8;
     const int c_end = (a.d >> 2) < (slice + 1) * G ? (a.d >> 2) : (slice + 1) * G;
-    if (G >= 4 && n_sub == 4) heavy_row<(G >= 4 ? G / 4 : 1)>(a, row, slice * G + sub * (G / 4), c_end, wsum, na);
-    else if (G >= 2 && n_sub == 2) heavy_row<(G >= 2 ? G / 2 : 1)>(a, row, slice * G + sub * (G / 2), c_end, wsum, na);
-    else if (sub == 0) heavy_row<G>(a, row, slice * G, c_end, wsum, na);   // (a cut wider than the lane group: one workgroup does the slice)
+    if (G >= 4 && n_sub == 4) heavy_row<(G >= 4 ? G / 4 : 1)>(a, row, slice * G + sub * (G / 4), c_end, wsum);
+    else if (G >= 2 && n_sub == 2) heavy_row<(G >= 2 ? G / 2 : 1)>(a, row, slice * G + sub * (G / 2), c_end, wsum);
+    else if (sub == 0) heavy_row<G>(a, row, slice * G, c_end, wsum);   // (a cut wider than the lane group: one workgroup does the slice)
 }
 
 template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
-    NormAcc na = {0.f, 0.f, 0.f};
-    spmm_body<G>(a, na);
-    if (a.mult) {
-        // every workgroup -- surplus ones included -- leaves its three sums: wave butterflies, then the four waves in a
-        // fixed order (deterministic; the consumer re-reduces norm_part[0 .. gridDim.x) in a fixed order too)
-        __shared__ float nred[4][3];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            na.su += __shfl_xor(na.su, off);
-            na.sp += __shfl_xor(na.sp, off);
-            na.sn += __shfl_xor(na.sn, off);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            nred[threadIdx.x >> 6][0] = na.su;
-            nred[threadIdx.x >> 6][1] = na.sp;
-            nred[threadIdx.x >> 6][2] = na.sn;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float* o = a.norm_part + (size_t)blockIdx.x * 4;
-            o[0] = (nred[0][0] + nred[1][0]) + (nred[2][0] + nred[3][0]);
-            o[1] = (nred[0][1] + nred[1][1]) + (nred[2][1] + nred[3][1]);
-            o[2] = (nred[0][2] + nred[1][2]) + (nred[2][2] + nred[3][2]);
-            o[3] = 0.f;
-        }
-    }
+    spmm_body<G>(a);
 }
 
 // Grid of a launch (sets use_slab / light_blocks in `a`; a.cs and a.sched must be final).
@@ -513,8 +463,7 @@ void spmm_shape(int64_t n_rows, int d, int64_t nnz, int* cs_out, int* g_out) {
 int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* x,
              int d, float* y, float* acc_in, float s_in, float* acc_out, float s_out, const crh_spmm_sched* sched,
              float* adam_p, float* adam_m, float* adam_v, AdamK k, float bc2_sqrt, float nss, const float* step_scalars,
-             int zero_acc_in, void* stream, int sgd = 0, const int32_t* mult = nullptr, int64_t user_rows = 0,
-             float* norm_part = nullptr) {
+             int zero_acc_in, void* stream, int sgd = 0) {
     CRH_CHECK_ARG(rowptr && x && n_rows > 0, "%s: NULL pointer / empty matrix", who);
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "%s: d=%d must be a positive multiple of 4", who, d);
     CRH_CHECK_ARG(y || acc_out || adam_p, "%s: nothing to write (y and acc_out both NULL)", who);
@@ -529,6 +478,9 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
     if (sched && sched->n_seg > 0) {
         CRH_CHECK_ARG(sched->seg_row && sched->seg_ptr && sched->seg_slot, "%s: incomplete schedule", who);
         CRH_CHECK_ARG(sched->n_multi == 0 || sched->multi_row, "%s: incomplete schedule (heavy rows)", who);
+        CRH_CHECK_ARG(sched->version == CRH_SPMM_SCHED_VERSION,
+                      "%s: crh_spmm_sched.version = %d, this library reads layout %d (multi_count = n_sub | sub << 8)", who,
+                      (int)sched->version, CRH_SPMM_SCHED_VERSION);
         a.sched = *sched;
         static const int use_desc = getenv("CRH_SPMM_DESC") ? atoi(getenv("CRH_SPMM_DESC")) : 1;
         if (!use_desc) a.sched.seg_desc = nullptr;
@@ -538,9 +490,6 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
         a.sched.seg_desc = nullptr;
         a.sched.slab = nullptr;
     }
-    a.mult = mult;
-    a.user_rows = user_rows;
-    a.norm_part = norm_part;
     int cs, G;
     spmm_shape(n_rows, d, sched && sched->n_seg > 0 ? sched->nnz : -1, &cs, &G);
     const int nvec = d / 4;
@@ -575,33 +524,6 @@ extern "C" int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const
     (void)workspace_bytes;
     return spmm_run("crh_spmm_csr_f32", rowptr, col, val, n_rows, x, d, y, const_cast<float*>(acc_in), s_in, acc_out,
                     s_out, sched, nullptr, nullptr, nullptr, AdamK{}, 0.f, 0.f, nullptr, 0, stream);
-}
-
-// crh_spmm_csr_f32 that also leaves the squared Frobenius norms of the next BPR batch's gathered blocks (see SpmmArgs::mult):
-// the LAST forward SpMM of a LightGCN step writes the propagated table to acc_out row by row, so |OUT[users]|^2,
-// |OUT[pos]|^2, |OUT[neg]|^2 are sums of mult-weighted row norms -- no separate forward pass over the batch.
-extern "C" int crh_spmm_csr_norms_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
-                                      const float* x, int d, float* y, const float* acc_in, float s_in, float* acc_out,
-                                      float s_out, const crh_spmm_sched* sched, const int32_t* mult, int64_t user_rows,
-                                      float* norm_part, void* stream) {
-    CRH_CHECK_ARG(mult && norm_part && acc_out, "crh_spmm_csr_norms_f32: NULL mult / norm_part / acc_out");
-    CRH_CHECK_ARG(user_rows >= 0 && user_rows <= n_rows, "crh_spmm_csr_norms_f32: user_rows outside 0..n_rows");
-    return spmm_run("crh_spmm_csr_norms_f32", rowptr, col, val, n_rows, x, d, y, const_cast<float*>(acc_in), s_in, acc_out,
-                    s_out, sched, nullptr, nullptr, nullptr, AdamK{}, 0.f, 0.f, nullptr, 0, stream, 0, mult, user_rows,
-                    norm_part);
-}
-
-// workgroups of a launch over this matrix = entries (of 4 floats) crh_spmm_csr_norms_f32 writes to norm_part
-extern "C" int64_t crh_spmm_norm_parts(int64_t n_rows, int d, const crh_spmm_sched* sched) {
-    if (n_rows <= 0 || d < 4 || d % 4) return 0;
-    SpmmArgs a{};
-    a.n_rows = n_rows;
-    a.d = d;
-    if (sched && sched->n_seg > 0) a.sched = *sched;
-    int cs, G;
-    spmm_shape(n_rows, d, sched && sched->n_seg > 0 ? sched->nnz : -1, &cs, &G);
-    a.cs = G * cs != d / 4 ? 1 : cs;
-    return spmm_grid(a, G);
 }
 
 // The last SpMM of LightGCN's backward pass with the optimiser fused into its epilogue (model/LightGCN.py:26-28):

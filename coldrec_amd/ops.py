@@ -370,54 +370,6 @@ def mf_step(table_in, table_out, m, v, user_rows: int, batch: int, reg: float, p
     _lib.check(rc, "crh_mf_step_f32")
 
 
-def bpr_grad_parts(batch: int, d: int) -> int:
-    return int(_lib.lib().crh_bpr_grad_parts(int(batch), int(d)))
-
-
-def bpr_grad_rows(table, grad_out, user_rows: int, batch: int, reg: float, plan, rng, entries, norm_part,
-                  n_norm_parts: int, loss_part_prev, n_loss_parts_prev: int, part_out, loss_prev, batch_prev: int,
-                  loss_out) -> None:
-    """d(bpr_loss + l2_reg_loss)/d(table) of one batch, row by row into ``grad_out`` (touched rows only), score differences
-    recomputed, batch norms from the partial sums of the launch that produced ``table`` (crh_bpr_grad_rows_f32)."""
-    _need_cuda(table, grad_out, plan, rng, entries, norm_part, part_out)
-    R, d = table.shape
-    assert table.dtype == torch.float32 and table.is_contiguous() and grad_out.shape == table.shape and grad_out.is_contiguous()
-    assert rng.shape == (R, 2) and rng.dtype == torch.int32 and entries.dtype == torch.int32
-    _lib.check(_lib.lib().crh_bpr_grad_rows_f32(
-        _lib.ptr(table), _lib.ptr(grad_out), int(user_rows), R - int(user_rows), d, int(batch), float(reg), _lib.ptr(plan),
-        _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(norm_part), int(n_norm_parts), _lib.ptr(loss_part_prev),
-        int(n_loss_parts_prev), _lib.ptr(part_out), _lib.ptr(loss_prev), int(batch_prev), _lib.ptr(loss_out),
-        _lib.current_stream()), "crh_bpr_grad_rows_f32")
-
-
-def mf_epoch_blocks(n_rows: int, d: int, sgd: bool = False) -> int:
-    """Workgroups of the one-launch epoch for a table of ``n_rows`` x ``d`` (0: the table does not fit one resident grid)."""
-    return int(_lib.lib().crh_mf_epoch_blocks(int(n_rows), int(d), 1 if sgd else 0))
-
-
-def mf_epoch(table0, table1, m, v, user_rows: int, batch: int, n_records: int, reg: float, rng, entries, mult, part0,
-             n_part0: int, parts, losses, step_scalars, sync, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-             sgd_lr: Optional[float] = None) -> None:
-    """All optimiser steps of one epoch of model/MF.py:17-27 in ONE launch (crh_mf_epoch_f32, include/coldrec_hip.h):
-    p, m, v of every row stay in registers between the steps.  ``rng`` / ``entries`` / ``mult``: mf_step_tables' outputs."""
-    _need_cuda(table0, table1, m, v, rng, entries, mult, part0, parts, losses, step_scalars, sync)
-    R, d = table0.shape
-    n_steps = -(-int(n_records) // int(batch))
-    for t in (table0, table1) + (() if sgd_lr is not None else (m, v)):
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (R, d)
-    for t in (rng, entries, mult):
-        assert t.dtype == torch.int32 and t.is_contiguous()
-    assert rng.shape == (n_steps, R, 2) and mult.shape == (n_steps, R) and entries.shape == (n_steps, 3 * int(batch), 2)
-    assert losses.shape == (n_steps, 2) and losses.is_contiguous() and losses.dtype == torch.float32
-    assert sgd_lr is not None or (step_scalars.shape == (n_steps, 2) and step_scalars.is_contiguous())
-    assert sync.dtype == torch.int32 and sync.numel() >= 2048 and parts.numel() >= 8 * mf_epoch_blocks(R, d, sgd_lr is not None)
-    _lib.check(_lib.lib().crh_mf_epoch_f32(
-        _lib.ptr(table0), _lib.ptr(table1), _lib.ptr(m), _lib.ptr(v), int(user_rows), R - int(user_rows), d, int(batch),
-        int(n_records), float(reg), _lib.ptr(rng), _lib.ptr(entries), _lib.ptr(mult), _lib.ptr(part0), int(n_part0),
-        _lib.ptr(parts), _lib.ptr(losses), beta1, beta2, eps, _lib.ptr(step_scalars), 1 if sgd_lr is not None else 0,
-        float(sgd_lr or 0.0), _lib.ptr(sync), _lib.current_stream()), "crh_mf_epoch_f32")
-
-
 def mf_step_finish(part_in, n_parts_in: int, batch: int, loss_out) -> None:
     _need_cuda(part_in, loss_out)
     _lib.check(_lib.lib().crh_mf_step_finish(_lib.ptr(part_in), int(n_parts_in), int(batch), _lib.ptr(loss_out),
@@ -487,7 +439,7 @@ def spmm_csr_sgd(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: float
     assert p.dtype == torch.float32 and p.is_contiguous() and p.shape == (n_rows, d)
     rc = _lib.lib().crh_spmm_csr_sgd_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                          _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                         ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None, _lib.ptr(p), float(lr),
+                                         ctypes.byref(sched.for_launch(n_rows, d, col, val)) if sched is not None else None, _lib.ptr(p), float(lr),
                                          int(bool(zero_acc_in)), _lib.current_stream())
     _lib.check(rc, "crh_spmm_csr_sgd_f32")
 
@@ -528,7 +480,7 @@ def spmm_csr_adam(rowptr, col, val, x, acc_in, s_in: float, acc_out, s_out: floa
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n_rows, d)
     rc = _lib.lib().crh_spmm_csr_adam_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                           _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                          ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None, _lib.ptr(p),
+                                          ctypes.byref(sched.for_launch(n_rows, d, col, val)) if sched is not None else None, _lib.ptr(p),
                                           _lib.ptr(m), _lib.ptr(v), float(lr), float(betas[0]), float(betas[1]),
                                           float(eps), int(step), _lib.ptr(step_scalars), int(bool(zero_acc_in)),
                                           _lib.current_stream())
@@ -552,6 +504,7 @@ class SpmmSchedule:
         rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
         rp = rp.astype(np.int64)
         self._rp, self._col, self._val, self._device, self._slabs = rp, col, val, device, {}
+        self._bound, self._sums = {}, None
         deg = np.diff(rp)
         if seg is None:
             # heavy threshold: crh_spmm_segment_edges() (64) for sparse graphs; for dense ones (MovieLens shape: mean
@@ -578,6 +531,7 @@ class SpmmSchedule:
         multi_row = np.repeat(hrows, n_sub).astype(np.int32)
         sub = (np.arange(len(multi_row)) - np.repeat(np.cumsum(n_sub) - n_sub, n_sub)).astype(np.int64)
         multi_count = (np.repeat(n_sub, n_sub) | (sub << 8)).astype(np.int32)
+        assert np.isin(multi_count & 0xff, (1, 2, 4)).all() and ((multi_count >> 8) < (multi_count & 0xff)).all()
         multi_first = np.zeros(len(multi_row) + 1, np.int64)          # not read any more (kept for the ABI struct)
         # one 16-byte descriptor per work item: {row, first edge, edges, slot}
         desc = None
@@ -593,6 +547,7 @@ class SpmmSchedule:
                                 _lib.ptr(self.t[4]) if len(multi_row) else None,
                                 _lib.ptr(self.t[5]) if len(multi_row) else None, len(multi_row),
                                 int(multi_first[-1]), int(rp[-1]), _lib.ptr(self.desc))
+        self.c.version = _lib.SPMM_SCHED_VERSION
         self.n_partial = int(multi_first[-1])
         self.n_seg = len(seg_row)
         self._ws = {}
@@ -629,14 +584,45 @@ class SpmmSchedule:
         return (torch.from_numpy(stream.view(np.int32)).to(self._device), first, units[first] if len(first) else first,
                 start[first] if len(first) else first)
 
-    def for_launch(self, n_rows: int, d: int):
+    def _same_edges(self, col, val) -> bool:
+        """Are the launch's edge arrays the ones the record stream was built from?  The stream bakes (col, val) of the LIGHT
+        rows in while the heavy rows read the launch's arrays: a caller that hands a rescaled ``val`` (or another matrix) to
+        a reused schedule would get a mix of both.  Checked once per pair of device buffers (pointer, length,
+        version counter) by two 64-bit checksums against the arrays the schedule was given; a pair that does not match -- or
+        cannot be checked because the stream is being captured -- takes the descriptor path, which reads the launch's arrays."""
+        if col is None or val is None:
+            return True
+        key = (col.data_ptr(), val.data_ptr(), col.numel(), col._version, val._version)
+        ok = self._bound.get(key)
+        if ok is None:
+            if torch.is_tensor(self._col) and torch.is_tensor(self._val) and self._col.data_ptr() == col.data_ptr() \
+                    and self._val.data_ptr() == val.data_ptr() and self._col.numel() == col.numel():
+                ok = True
+            elif col.is_cuda and torch.cuda.is_current_stream_capturing():
+                return False                                  # not cached: an eager launch decides
+            else:
+                if self._sums is None:
+                    hc = self._col.cpu().numpy() if torch.is_tensor(self._col) else np.asarray(self._col)
+                    hv = self._val.cpu().numpy() if torch.is_tensor(self._val) else np.asarray(self._val)
+                    self._sums = (len(hc), int(hc.astype(np.int64).sum()),
+                                  int(np.ascontiguousarray(hv, np.float32).view(np.int32).astype(np.int64).sum()))
+                ok = (col.numel() == self._sums[0] and val.numel() == self._sums[0]
+                      and int(col.sum(dtype=torch.int64)) == self._sums[1]
+                      and int(val.view(torch.int32).sum(dtype=torch.int64)) == self._sums[2])
+            self._bound[key] = ok
+        return ok
+
+    def for_launch(self, n_rows: int, d: int, col=None, val=None):
         """Point the C struct at the record stream laid out for THIS launch's lane-group width (built once per width);
-        without edge arrays, or where the stream does not apply, the launch takes the descriptor path."""
+        without edge arrays, where the stream does not apply, or when the launch's (col, val) are not the arrays the stream
+        was built from (``_same_edges``), the launch takes the descriptor path.  A schedule is bound to ONE (col, val)."""
         c = self.c
         G = int(_lib.lib().crh_spmm_lane_group(int(n_rows), int(d), int(self._rp[-1]))) if self._col is not None else 0
         if G not in self._slabs:
             self._slabs[G] = self._build_slab(G) if G else None
         slab = self._slabs[G]
+        if slab is not None and not self._same_edges(col, val):
+            slab = None
         if slab is None:
             c.slab, c.slab_lanes, c.slab_buckets, c.n_slab = None, 0, 0, 0
             return c
@@ -653,26 +639,6 @@ class SpmmSchedule:
         return None
 
 
-def spmm_norm_parts(n_rows: int, d: int, sched: Optional[SpmmSchedule]) -> int:
-    """Workgroups of an SpMM launch over this matrix = 4-float entries ``spmm_csr(..., norms=...)`` writes."""
-    return int(_lib.lib().crh_spmm_norm_parts(int(n_rows), int(d),
-                                               ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None))
-
-
-def spmm_csr_norms(rowptr, col, val, x, y, acc_in, s_in: float, acc_out, s_out: float, sched, mult, user_rows: int,
-                   norm_part) -> None:
-    """spmm_csr that also leaves the next BPR batch's squared block norms as per-workgroup partial sums
-    (crh_spmm_csr_norms_f32): ``mult`` (rows,) int32 multiplicities of the batch, ``norm_part`` (spmm_norm_parts, 4) fp32."""
-    _need_cuda(rowptr, col, val, x, y, acc_in, acc_out, mult, norm_part)
-    n_rows, d = rowptr.shape[0] - 1, x.shape[1]
-    assert mult.dtype == torch.int32 and mult.shape == (n_rows,) and mult.is_contiguous()
-    assert norm_part.dtype == torch.float32 and norm_part.numel() >= 4 * spmm_norm_parts(n_rows, d, sched)
-    _lib.check(_lib.lib().crh_spmm_csr_norms_f32(
-        _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d, _lib.ptr(y), _lib.ptr(acc_in), float(s_in),
-        _lib.ptr(acc_out), float(s_out), ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None,
-        _lib.ptr(mult), int(user_rows), _lib.ptr(norm_part), _lib.current_stream()), "crh_spmm_csr_norms_f32")
-
-
 def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_out=None, s_out: float = 1.0,
              sched: Optional[SpmmSchedule] = None):
     """P = A @ x; y = P; acc_out = (acc_in*s_in + P)*s_out  (model/LightGCN.py:88-93, fused layer sum)."""
@@ -683,7 +649,7 @@ def spmm_csr(rowptr, col, val, x, y=None, acc_in=None, s_in: float = 1.0, acc_ou
     ws = sched.workspace(d, x.device) if sched is not None else None
     rc = _lib.lib().crh_spmm_csr_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), n_rows, _lib.ptr(x), d,
                                      _lib.ptr(y), _lib.ptr(acc_in), float(s_in), _lib.ptr(acc_out), float(s_out),
-                                     ctypes.byref(sched.for_launch(n_rows, d)) if sched is not None else None,
+                                     ctypes.byref(sched.for_launch(n_rows, d, col, val)) if sched is not None else None,
                                      _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0,
                                      _lib.current_stream())
     _lib.check(rc, "crh_spmm_csr_f32")

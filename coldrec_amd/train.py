@@ -221,41 +221,18 @@ class MFEngine(_TableState):
         self._parts = [torch.zeros(self._nparts * 4, dtype=torch.float32, device=self.device) for _ in range(2)]
         self._fws, self._fws_cap = None, 0
         self._fsums = torch.zeros(4, dtype=torch.float32, device=self.device)
-        # the whole epoch as ONE launch (crh_mf_epoch_f32: p, m, v stay in registers between the steps, a grid barrier
-        # instead of a kernel boundary) when every workgroup of the table fits on the chip at once.  Built, tested,
-        # OFF by default (CRH_MF_EPOCH=1 switches it on): 19.2 us per step against 18.0 for one launch per step at the
-        # MovieLens shape -- the median workgroup reaches the barrier after 9.9 us, the one that owns the batch's hottest
-        # items after 15.7 (profiles/r03_mf_epoch.log)
-        self._eblocks = 0
-        if os.environ.get("CRH_MF_EPOCH", "0") == "1" and hasattr(ops, "mf_epoch"):
-            self._eblocks = ops.mf_epoch_blocks(self.E.shape[0], self.d, self._sgd_lr is not None)
-        if self._eblocks:
-            self._eparts = torch.zeros(2 * self._eblocks * 4, dtype=torch.float32, device=self.device)
-            self._esync = torch.zeros(2048, dtype=torch.int32, device=self.device)
-            self._echecked = False
 
     def fused_epoch(self, u, i, j, steps, plans, tables, losses, scalars) -> None:
-        """All optimiser steps of one epoch (``steps`` = [(lo, hi)] into the triple arrays), one launch each -- or one
-        launch for all of them (``_eblocks``); the Frobenius norms of the first batch come from a forward pass, those of
-        batch s+1 from step s."""
+        """All optimiser steps of one epoch (``steps`` = [(lo, hi)] into the triple arrays), one launch each; the Frobenius
+        norms of the first batch come from a forward pass, those of batch s+1 from step s.  (The epoch as ONE persistent
+        launch with a grid barrier between the steps was built and measured in round 3 -- 19.2 us per step against 18.0 --
+        and removed in round 4: profiles/r03_mf_epoch.log)"""
         U, (lo, hi) = self.user_num, steps[0]
         if self._fws is None or self._fws_cap < hi - lo:
             self._fws_cap = hi - lo
             self._fws = ops.bpr_workspace(self._fws_cap, self.device)
         ops.bpr_fwd(self.E[:U], self.E[U:], self.E[U:], u[lo:hi], i[lo:hi], j[lo:hi], self._fsums, self._fws)
         part_in, n_in = self._fws.view(torch.float32), ops.bpr_fwd_parts(hi - lo, self.d)
-        if self._eblocks:
-            rng, mult, ent = tables
-            ops.mf_epoch(self.E, self.E2, self.M, self.V, U, ent.shape[1] // 3, steps[-1][1], self.reg, rng, ent, mult,
-                         part_in, n_in, self._eparts, losses, scalars, self._esync, sgd_lr=self._sgd_lr)
-            self.loss.copy_(losses[len(steps) - 1])
-            self.step_count += len(steps)
-            if not self._echecked and not torch.cuda.is_current_stream_capturing():
-                self._echecked = True                 # once, on the eager first epoch: did every barrier complete?
-                if int(self._esync[2].item()) != 0:
-                    raise RuntimeError("crh_mf_epoch_f32: a grid barrier timed out (not every workgroup was resident); "
-                                       "set CRH_MF_EPOCH=0 to run the steps one by one")
-            return
         src, dst, prev = self.E, self.E2, 0
         rng, mult, ent = tables
         for s, (lo, hi) in enumerate(steps):
@@ -462,9 +439,7 @@ class LGCNEngine(_TableState):
             self.rs_own[:own].copy_(Eo)
         self.dp.all_gather_rows(self.rs_E, self.rs_own)      # every rank sees the updated table (rows >= N stay zero)
 
-    def _propagate(self, out: torch.Tensor, mult: Optional[torch.Tensor] = None) -> None:
-        """``mult``: the next batch's row multiplicities -> the last layer's launch also leaves the batch's squared block
-        norms in ``self._norm_part`` (crh_spmm_csr_norms_f32; the fused step has no forward pass over the batch)."""
+    def _propagate(self, out: torch.Tensor) -> None:
         if getattr(self, "rs", None) is not None:
             self._propagate_sharded()
             if out is not self.OUT:
@@ -475,53 +450,9 @@ class LGCNEngine(_TableState):
         for k in range(self.L):
             last = k == self.L - 1
             y = None if last else self.X[k & 1]
-            if last and mult is not None:
-                self.k.spmm_csr_norms(self.rowptr, self.col, self.val, x, y, self.E if k == 0 else out, 1.0, out, c, self.sched,
-                                      mult, self.user_num, self._norm_part)
-            else:
-                self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
-                                acc_out=out, s_out=c if last else 1.0, sched=self.sched)
+            self.k.spmm_csr(self.rowptr, self.col, self.val, x, y=y, acc_in=self.E if k == 0 else out, s_in=1.0,
+                            acc_out=out, s_out=c if last else 1.0, sched=self.sched)
             x = y
-
-    # ---------------------------------------------------------------- step without a forward pass over the batch
-    fused = False
-    FUSED_MAX_MAP_BYTES = 1 << 29
-
-    def can_fuse(self, n_batches: int, batch_size: int) -> bool:
-        return (hasattr(self.k, 'bpr_grad_rows') and self.dp is None and getattr(self, "rs", None) is None and self.fuse_adam
-                and self.d <= 256 and self.E.is_cuda and batch_size <= 8192 and 1 <= n_batches <= 65535
-                and n_batches * self.E.shape[0] * 12 <= self.FUSED_MAX_MAP_BYTES)
-
-    def enable_fused_step(self) -> None:
-        """model/LightGCN.py:23-28 in 2L + 1 launches: the last forward SpMM also sums the batch's block norms (row
-        multiplicities x row norms of the table it writes), the row-gradient kernel recomputes the score differences from
-        the rows it gathers (crh_bpr_grad_rows_f32), so ``bpr_fwd`` is gone; the bpr loss of step s is published by step
-        s + 1 (the last one by crh_mf_step_finish), as in the one-launch BPR-MF step.  Driven by ``fused_epoch``."""
-        assert self.can_fuse(1, 1)
-        self.fused = True
-        N, d = self.E.shape
-        self._n_norm = ops.spmm_norm_parts(N, d, self.sched)
-        self._norm_part = torch.zeros(self._n_norm * 4, dtype=torch.float32, device=self.device)
-        self._loss_parts = None          # two buffers of crh_bpr_grad_parts(batch, d) x 4 floats, sized by the first epoch
-
-    def fused_epoch(self, u, i, j, steps, plans, tables, losses, scalars) -> None:
-        rng, mult, ent = tables
-        gparts = [ops.bpr_grad_parts(hi - lo, self.d) for lo, hi in steps]
-        if self._loss_parts is None or self._loss_parts[0].numel() < 4 * max(gparts):
-            assert not torch.cuda.is_current_stream_capturing(), "size the loss partials before capturing the epoch"
-            self._loss_parts = [torch.zeros(4 * max(gparts), dtype=torch.float32, device=self.device) for _ in range(2)]
-        prev_parts, prev, n_prev = None, 0, 0
-        for s, (lo, hi) in enumerate(steps):
-            self._propagate(self.OUT, mult=mult[s])
-            if not self._dout_clean:
-                self.dOUT.zero_()
-            part_out = self._loss_parts[s & 1]
-            ops.bpr_grad_rows(self.OUT, self.dOUT, self.user_num, hi - lo, self.reg, plans[s], rng[s], ent[s], self._norm_part,
-                              self._n_norm, prev_parts, n_prev, part_out, losses[s - 1] if s else None, prev, losses[s])
-            self._backward(scalars[s])
-            prev_parts, prev, n_prev = part_out, hi - lo, gparts[s]
-        ops.mf_step_finish(prev_parts, n_prev, prev, losses[len(steps) - 1])
-        self.loss.copy_(losses[len(steps) - 1])
 
     def forward(self):
         self._propagate(self.OUT)
@@ -607,13 +538,12 @@ class EpochRunner:
         # BPR-MF with cache-resident tables: the whole step is one launch (CRH_MF_FUSED=0 keeps the three-kernel step)
         self.tables = None
         if fused is None:
-            # BPR-MF: the one-launch step is the default.  LightGCN: the step without a forward pass over the batch is built
-            # and tested but OFF by default -- recomputing a score difference costs two cross-lane dot products per entry on the
-            # row's dependent chain, more than the forward kernel it removes: 133.6 - 135.0 us per step against 128.3 - 128.6
-            # on the same box (CiteULike shape; profiles/r03_lgcn_fold.log).  CRH_LGCN_FUSED_LOSS=1 switches it on.
-            fused = (os.environ.get("CRH_MF_FUSED", "1") != "0") if isinstance(engine, MFEngine) else \
-                (os.environ.get("CRH_LGCN_FUSED_LOSS", "0") == "1")
-        if fused and isinstance(engine, (MFEngine, LGCNEngine)) and engine.can_fuse(len(self.steps), self.B):
+            # BPR-MF: the one-launch step is the default (CRH_MF_FUSED=0 keeps the three-kernel step).  LightGCN keeps its
+            # forward pass over the batch: the step without one (block norms from the last forward SpMM's epilogue, score
+            # differences recomputed by the row-gradient kernel) was built and measured in round 3 -- 133.6 - 135.0 us per
+            # step against 128.3 - 128.6 -- and removed in round 4 (profiles/r03_lgcn_fold.log)
+            fused = os.environ.get("CRH_MF_FUSED", "1") != "0"
+        if fused and isinstance(engine, MFEngine) and engine.can_fuse(len(self.steps), self.B):
             engine.enable_fused_step()
 
     def _all_steps(self):

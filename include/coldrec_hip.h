@@ -282,7 +282,13 @@ typedef struct {
     int32_t slab_first[CRH_SPMM_SLAB_BUCKETS];
     int32_t slab_units[CRH_SPMM_SLAB_BUCKETS];
     int64_t slab_base[CRH_SPMM_SLAB_BUCKETS];
+    /* layout version of THIS struct, CRH_SPMM_SCHED_VERSION: the meaning of multi_count changed in round 3 (segments per
+     * heavy row -> n_sub | sub << 8 per heavy workgroup) and the struct grew; a schedule built for another layout is
+     * refused (CRH_ERR_ARG) instead of being decoded as something else.  multi_count entries must have n_sub in {1, 2, 4}
+     * and sub < n_sub (checked by the builder, coldrec_amd/ops.py SpmmSchedule). */
+    int32_t version;
 } crh_spmm_sched;
+#define CRH_SPMM_SCHED_VERSION 4
 int crh_spmm_segment_edges(void);
 /* lanes per lane group (16 bytes of a row each) the SpMM launches use for an n_rows x d operand and nnz stored edges under
  * a schedule: d / 4 / (column slices), a power of two -- what a caller needs to lay out crh_spmm_sched::slab */
@@ -292,19 +298,6 @@ int crh_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val
                      const float* x, int d, float* y, const float* acc_in, float s_in,
                      float* acc_out, float s_out, const crh_spmm_sched* sched, void* workspace,
                      size_t workspace_bytes, void* stream);
-
-/*
- * crh_spmm_csr_f32 that also leaves the squared Frobenius norms l2_reg_loss needs for the NEXT BPR batch (util/utils.py:44-48
- * on the gathers of model/LightGCN.py:23-24), summed from the rows this launch writes to acc_out: mult[row] = how often the
- * batch gathers the row (user rows, i.e. row < user_rows: the count; item rows: positives | negatives << 16 -- the `mult`
- * table of crh_mf_step_tables).  Every workgroup writes {sum |u|^2, sum |p|^2, sum |n|^2, 0} to norm_part[4 * workgroup];
- * crh_spmm_norm_parts gives the number of workgroups.  Deterministic (fixed reduction orders).
- */
-int crh_spmm_csr_norms_f32(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
-                           const float* x, int d, float* y, const float* acc_in, float s_in, float* acc_out,
-                           float s_out, const crh_spmm_sched* sched, const int32_t* mult, int64_t user_rows,
-                           float* norm_part, void* stream);
-int64_t crh_spmm_norm_parts(int64_t n_rows, int d, const crh_spmm_sched* sched);
 
 /*
  * The last SpMM of LightGCN's backward pass with torch.optim.Adam fused into its epilogue (model/LightGCN.py:26-28):
@@ -353,44 +346,7 @@ int crh_mf_step_f32(const float* table_in, float* table_out, float* m, float* v,
                     const float* part_in, int n_parts_in, float* part_out, float* loss_prev_out,
                     int64_t batch_prev, float* loss_out, double beta1, double beta2, double eps,
                     const float* step_scalars, void* stream);
-/*
- * The gradient half of the one-launch step alone (LightGCN, model/LightGCN.py:23-26): d(bpr_loss + l2_reg_loss)/d(table)
- * row by row into grad_out (rows the batch does not touch are not written: keep them zero), score differences recomputed
- * from the gathered rows -- no forward pass over the batch.  The batch norms arrive as partial sums from the launch that
- * produced `table` (crh_spmm_csr_norms_f32), the previous batch's loss sum from the previous call (or NULL / 0);
- * part_out[crh_bpr_grad_parts(batch, d)][4] receives this batch's loss sum (component 3); loss_out[1] = l2 now,
- * loss_prev_out[0] = the previous batch's bpr loss; the last batch's by crh_mf_step_finish(part_out, ...).
- */
-int crh_bpr_grad_parts(int64_t batch, int d);
-int crh_bpr_grad_rows_f32(const float* table, float* grad_out, int64_t user_rows, int64_t item_rows, int d,
-                          int64_t batch, float reg, const int32_t* plan, const int32_t* range,
-                          const int32_t* entries, const float* norm_part, int n_norm_parts,
-                          const float* loss_part_prev, int n_loss_parts_prev, float* part_out,
-                          float* loss_prev_out, int64_t batch_prev, float* loss_out, void* stream);
 int crh_mf_step_finish(const float* part_in, int n_parts_in, int64_t batch, float* loss_out, void* stream);
-/*
- * One EPOCH of BPR-MF optimiser steps in ONE launch (the loop of model/MF.py:17-27 over next_batch_pairwise, util/utils.py
- * :99-127): the steps crh_mf_step_f32 (optimizer 0, torch.optim.Adam) / crh_mf_step_sgd_f32 (optimizer 1, plain SGD)
- * would run one by one over the same crh_mf_step_tables outputs, with every row's p, m, v held in registers from the first
- * step to the last and a grid-wide barrier instead of a kernel boundary between steps.
- *   crh_mf_epoch_blocks(rows, d, optimizer): workgroups of the launch = [4]-float partial sums per parity, or 0 when the
- *             table is too large for every workgroup to be resident at once (they meet at the barrier): use the per-step
- *             entry points then
- *   table0    (user_rows + item_rows, d): parameters in, parameters out; table1: scratch of the same size
- *   range / entries / mult: crh_mf_step_tables' outputs for the epoch, n_steps = ceil(n_records / batch)
- *   part0     crh_bpr_fwd_f32's partial sums over batch 0 (n_part0 = crh_bpr_fwd_parts(batch 0, d))
- *   parts     2 x crh_mf_epoch_blocks x 4 floats of scratch;  losses [n_steps][2] = (bpr, l2) of every step
- *   step_scalars [n_steps][2] (crh_adam_step_scalars; NULL for SGD), lr: SGD only
- *   sync      2048 zero-initialised uint32 kept by the caller between launches; sync[2] != 0 afterwards = a barrier timed out
- *             (some workgroup was not resident), the launch ran out without hanging and its results are invalid
- */
-int crh_mf_epoch_blocks(int64_t n_rows, int d, int optimizer);
-int crh_mf_epoch_f32(float* table0, float* table1, float* m, float* v, int64_t user_rows, int64_t item_rows, int d,
-                     int64_t batch, int64_t n_records, float reg, const int32_t* range, const int32_t* entries,
-                     const int32_t* mult, const float* part0, int n_part0, float* parts, float* losses, double beta1,
-                     double beta2, double eps, const float* step_scalars, int optimizer, double lr, uint32_t* sync,
-                     void* stream);
-
 /*
  * north_star's "BPR loss + SGD update": torch.optim.SGD(lr) defaults (no momentum, no weight decay) in place of
  * torch.optim.Adam.  The reference itself trains with Adam (model/MF.py:14, model/LightGCN.py:16), so

@@ -177,10 +177,6 @@ def case_fused(rng):
         j = np.where(j == i, (j + 1) % n_i, j).astype(np.int32)
         epochs.append((u, i, j))
     res = []
-    # half of the cases run the epoch as ONE launch (crh_mf_epoch_f32; the product default is one launch per step)
-    os.environ["CRH_MF_EPOCH"] = "1" if rng.random() < 0.5 else "0"
-    if "epoch_launch" in FORCE:
-        os.environ["CRH_MF_EPOCH"] = str(int(FORCE["epoch_launch"]))
     for fused in (True, True, False):
         eng = MFEngine(U0, V0, 1e-2, 1e-3, DEV)
         runner = EpochRunner(eng, n_rec, B, fused=fused)
@@ -235,6 +231,7 @@ def case_fused(rng):
             noisy = np.zeros((n_u + n_i, d), bool)
             cond = np.full((n_u + n_i, d), np.inf)        # smallest |g| / (eps32 * A) an element saw in any step
             tainted = np.zeros((n_u + n_i, d), bool)      # noisy elements + same-column elements downstream of them
+            cnt_frac = np.zeros(n_u + n_i)                # largest share of a batch's triples that touch the row
             for (eu, ei, ej) in epochs:
                 for lo in range(0, n_rec, B):
                     sl = slice(lo, min(lo + B, n_rec))
@@ -252,6 +249,8 @@ def case_fused(rng):
                     np.logical_or.at(tainted, pu, t_p | t_n)
                     np.logical_or.at(tainted, pp, t_u)
                     np.logical_or.at(tainted, pn, t_u)
+                    nb_ = sl.stop - sl.start
+                    cnt_frac = np.maximum(cnt_frac, np.bincount(np.concatenate([pu, pp, pn]), minlength=n_u + n_i) / nb_)
                     noisy |= (A > 0) & (np.abs(g) <= 4.0 * d * eps32 * A)
                     tainted |= noisy
                     with np.errstate(divide="ignore", invalid="ignore"):
@@ -273,7 +272,12 @@ def case_fused(rng):
                 # m is linear in the gradients: an ABSOLUTE bound for each form on its own (a convex combination of the
                 # steps' gradients, each good to ~d * eps32 * A) -- the one-launch step gets no credit for the
                 # three-kernel step being worse
+                # ... for elements whose inputs were the same in both runs.  Once a noise-floor element of some row has moved
+                # differently (by up to lr per step, see E below), the same column of every row that shares a triple with it
+                # sees a different gradient, |dg| <= sum_b |g_b| |dp| <= (entries of the row / B) * 2 lr steps (|g_b| < 1 / B),
+                # and m is a convex combination of those (round 4, seed 52 forced class: 12 downstream elements 1.4e-7 apart)
                 tol = 8.0 * d * eps32 * a_max + 1e-12
+                tol = np.where(tainted, tol + cnt_frac[:, None] * 2.0 * 1e-2 * n_steps, tol)
                 if (np.abs(a - ref) <= tol).all() and (np.abs(b - ref) <= tol).all():
                     continue
             elif not (bad & ~tainted).any() and np.abs(a - b)[tainted & ~noisy].max(initial=0.0) <= 0.02 * 1e-2 * n_steps:
@@ -283,7 +287,7 @@ def case_fused(rng):
                 # (seed 52 of round 3: ONE noise-floor element of a hot item's row -- 950 of 1 000 positives on 3 items --
                 # and column 99 of 13 users who rated that item, 1e-5 apart; per-step launch and three-kernel step)
                 continue
-            fail("fused tables", table=name, epoch_launch=os.environ["CRH_MF_EPOCH"], d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
+            fail("fused tables", table=name, d=d, B=B, n_rec=n_rec, n_u=n_u, n_i=n_i, hot=hot_frac, epochs=len(epochs),
                  err=float(np.abs(a - b).max()), scale=float(np.abs(b).max()), nbad=int(bad.sum()))
 
 
@@ -292,7 +296,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", default="", help="run only this kind of case (bpr / spmm / adam / fused)")
-    ap.add_argument("--force", default="", help="JSON: pin the shape of the fused case (d, n_u, n_i, B, n_rec, hot, epochs, epoch_launch)")
+    ap.add_argument("--force", default="", help="JSON: pin the shape of the fused case (d, n_u, n_i, B, n_rec, hot, epochs)")
     ap.add_argument("--stats", action="store_true",
                     help="fused cases: also replay every case in fp64 and report the error distributions of the one-launch "
                          "step and of the three-kernel step against it (is one of them systematically noisier?)")
