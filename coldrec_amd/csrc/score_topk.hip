@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 constexpr int WG_RING = 3;   // item-tile slots in LDS
 
 template <typename T, int D, int UW, int NW, int TT>
-__global__ __launch_bounds__(64 * NW, UW >= 4 ? 1 : 8 / NW) void score_topk_wg_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArgs a) {
     // TT = item tiles per ring slot and barrier ("step").  The cost of a step that is not MFMA (barrier skew, ring
     // commit, the drain of the matrix pipe before the threshold test) is the same for every width, so narrow rows
     // take two tiles per step: d=128 fp16 43 % -> see DESIGN section 5.
@@ -1115,12 +1115,14 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     // 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
     const size_t ring_b = (size_t)WG_RING * wg_tiles_per_step(d * esz) * (d * esz / 32) * 1024;
     const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
-    // CRH_SCORE_WG=5 (experiment, fp16 d=256): 128 users per wave, FOUR waves per workgroup, one wave per SIMD -- one LDS
-    // read of an A fragment feeds four MFMAs instead of two (bare loop: 0.60 -> 0.627 of the nominal peak)
-    const bool uw4 = wg_mode == 5 && esz == 2 && d == 256 && ring_b + 4 * wave_lds_bytes<128>(k) <= 160 * 1024;
-    const int wg_waves = uw4 ? 4 : ((wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4);
-    const int wg_upw = uw4 ? 128 : 64;
-    const int wg_slots = (wg_waves == 8 || uw4) ? 256 : 512;          // workgroups resident per round
+    // (Round 4 measured a 128-users-per-wave / one-wave-per-SIMD instantiation of this kernel -- <_Float16, 256, UW = 4, NW = 4>,
+    // 256 VGPRs + 193 AGPRs, one LDS read of an A fragment per four MFMAs: +1.4 % over the shipped form on the same box, and
+    // 0.70x with a second accumulator set that lets the threshold test ride in the next tile's MFMA shadow (B fragments 256 +
+    // accumulators 128 registers: the allocator spills inside the MFMA stream, also with the slow path as a real call):
+    // profiles/r04_f16_variant_ab_*.log, DESIGN.md 4.1.  Not shipped.)
+    const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
+    const int wg_upw = 64;
+    const int wg_slots = wg_waves == 8 ? 256 : 512;                   // workgroups resident per round
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
     // fp32: the lockstep of 8 waves makes every slow-path event a stall of the whole CU, so the workgroup kernel only
     // pays on long streams (>= 2 M items: 0.852 vs 0.845 of peak at 2 M, 0.912 vs 0.891 at 10 M; at 262 144 items the
@@ -1128,7 +1130,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     // at 0.33 against 0.60 per wave)
     const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
     const bool fp32_wg_ok = n_items >= 2000000 && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
-    const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || uw4 || 2 * wg4_lds <= 160 * 1024) &&
+    const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
                         (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
     const int upw = use_wg ? wg_upw : users_per_wave(esz, d);
     ScoreArgs a;
@@ -1273,8 +1275,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
         switch (d) {
             case 64: rc = wg_waves == 4 ? launch_score_wg<_Float16, 64, 2, 4>(a, st) : launch_score_wg<_Float16, 64, 2, 8>(a, st); break;
             case 128: rc = wg_waves == 4 ? launch_score_wg<_Float16, 128, 2, 4>(a, st) : launch_score_wg<_Float16, 128, 2, 8>(a, st); break;
-            default: rc = uw4 ? launch_score_wg<_Float16, 256, 4, 4>(a, st)
-                            : wg_waves == 4 ? launch_score_wg<_Float16, 256, 2, 4>(a, st) : launch_score_wg<_Float16, 256, 2, 8>(a, st); break;
+            default: rc = wg_waves == 4 ? launch_score_wg<_Float16, 256, 2, 4>(a, st) : launch_score_wg<_Float16, 256, 2, 8>(a, st); break;
         }
     } else {
         rc = launch_score_per_wave(esz, d, occ, a, st);
