@@ -39,6 +39,17 @@ def _db_stats(stats_dir, tag):
             w.writerows(rows[:25])
 
 
+def _long_cluster(v):
+    """One kernel instantiation launched on very different amounts of work (bench.py's fp16 leg: the 50 M-item launches and
+    the 6.25 M-item shard launches have the same name and grid): a mean over all of them describes neither.  Keep the
+    launches within 2x of the largest value (the long launches, which the roofline lines refer to); return (kept, dropped)."""
+    if len(v) < 2 or min(v) <= 0 or max(v) <= 2.0 * min(v):
+        return v, 0
+    top = max(v)
+    kept = [x for x in v if x >= top / 2.0]
+    return kept, len(v) - len(kept)
+
+
 def _db_pmc(d, out):
     import sqlite3
     for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
@@ -62,9 +73,12 @@ def _db_pmc(d, out):
         for name, cs in agg.items():
             o = out.setdefault(name, {})
             for cname, v in list(cs.items()) + list(meta.get(name, {}).items()):
+                v, dropped = _long_cluster(v) if (not cname.startswith("_") or cname == "_duration_ns") else (v, 0)
                 o[cname] = sum(v) / len(v)
                 if not cname.startswith("_"):
                     o[cname + "_launches"] = len(v)
+                    if dropped:
+                        o[cname + "_other_launches"] = dropped
 
 
 def main():
