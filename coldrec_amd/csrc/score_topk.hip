@@ -60,7 +60,7 @@ struct ScoreArgs {
     int64_t n_ugroups;
     float* out_score;   // [n_splits][n_users][k]
     int32_t* out_idx;
-    int ablate;         // measurement only (CRH_SCORE_ABLATE): 1 = skip the selection epilogue
+    int ablate;         // measurement only (CRH_SCORE_ABLATE): 1 = skip the selection epilogue, 4 = skip the workgroup barriers
     unsigned long long* wave_clock;   // measurement only (CRH_SCORE_TIMING): [wave][2] start/end wall clock
     unsigned* xcd_sync;     // [8 XCD][1 + n_windows] zeroed counters, or NULL: keeps the waves of an XCD within
     int sync_window;        // two windows of `sync_window` tiles of each other (see xcd_window_sync)
@@ -662,6 +662,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
     };
     auto lds_barrier = [&]() {   // LDS traffic of this wave done, then meet; global prefetches keep flying
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt/expcnt untouched
+        if (CRH_ABLATE(a.ablate) & 4) return;   // measurement only (profile build): what the workgroup barriers cost; results invalid
         __builtin_amdgcn_s_barrier();
     };
     // A fragments come from LDS in groups of GR chunks, one group ahead of the MFMAs that consume them
