@@ -293,3 +293,64 @@ def test_builder_truth_csr_equals_the_dict_walk(name):
     fake = types.SimpleNamespace(item_keys=np.array([9, 7, 1], np.int64))
     u, rp, it = type(d)._pairs_truth_csr(fake, p)
     assert u == [5, 3, 4] and rp.tolist() == [0, 2, 4, 5] and it.tolist() == [0, 1, 0, 2, 0]
+
+
+def test_membership_routes_equal_the_host_hit_matrix():
+    """BaseColdStartTrainer._membership (the test of every prediction against its user's ground truth that the trainers run on
+    the device) -- both routes: the dense truth table of small catalogues and the sorted (row, item) keys with one binary
+    search per prediction that S-EVAL-sized evaluations take (in blocks of 2^18 users) -- against evaluator.hit_matrix, on CPU
+    tensors (the routes are plain torch ops): padding ids, ids beyond the catalogue, empty truths, duplicate predictions."""
+    from coldrec_amd.model.BaseRecommender import BaseColdStartTrainer
+    from coldrec_amd.util.evaluator import hit_matrix, ranking_metrics, truth_dense
+    rng = np.random.default_rng(8)
+    n_users, n_items, k = 700, 5000, 20
+    lens = rng.integers(0, 9, n_users)
+    gt_rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gt_items = np.concatenate([rng.choice(n_items, n, replace=False) for n in lens]).astype(np.int64)
+    pred = rng.integers(0, n_items, (n_users, k)).astype(np.int32)
+    rows = np.repeat(np.arange(n_users), lens)
+    take = rng.random(len(rows)) < 0.4                       # plant real hits
+    pred[rows[take], rng.integers(0, k, int(take.sum()))] = gt_items[take]
+    pred[5, :3] = np.iinfo(np.int32).max                      # padding of a short list
+    pred[6, 0] = pred[6, 1]                                   # the same item twice
+    want = hit_matrix(gt_rowptr, gt_items, np.where(pred == np.iinfo(np.int32).max, -1, pred).astype(np.int64))
+
+    class T(BaseColdStartTrainer):
+        def train(self): ...
+        def predict(self, u): ...
+        def batch_predict(self, users): ...
+        def save(self): ...
+
+    tr = object.__new__(T)
+    tr.data = types.SimpleNamespace(item=range(n_items))
+    tr.max_N = k
+    i = torch.from_numpy(pred)
+    base = {"users": list(range(n_users)), "gt_rowptr": gt_rowptr, "gt_items": gt_items}
+    dense = tr._membership(dict(base, gt_dense=truth_dense(gt_rowptr, gt_items, n_items)), i)
+    keys = tr._membership(dict(base, gt_dense=None), i)
+    assert np.array_equal(dense, want) and np.array_equal(keys, want)
+    assert ranking_metrics(gt_rowptr, gt_items, None, [10, 20], hit=keys) == \
+        ranking_metrics(gt_rowptr, gt_items, np.where(pred == np.iinfo(np.int32).max, -1, pred).astype(np.int64), [10, 20])
+    # an empty ground truth: no keys at all
+    empty = tr._membership({"users": [0, 1], "gt_rowptr": np.zeros(3, np.int64), "gt_items": np.zeros(0, np.int64),
+                            "gt_dense": None}, i[:2])
+    assert not empty.any()
+
+
+def test_bench_helpers_legs_summary_and_profile_clusters():
+    """bench.legs_summary (the compact last key of the line) and tools/prof_summary._long_cluster (one kernel name launched
+    on very different sizes: the long launches are what the roofline lines refer to)."""
+    import importlib.util
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_a.json")))
+    summ = bench.legs_summary({k: v for k, v in rec.items() if k != "legs_summary"})
+    assert summ == rec["legs_summary"]
+    assert summ["headline"] == [round(rec["ms_per_step"], 3), round(rec["roofline"]["frac"], 4)]
+    assert summ["eval_f16.shard_8gpu"][1] == round(rec["eval_f16"]["shard_8gpu"]["frac_of_fp16_mfma_peak"], 4)
+    spec = importlib.util.spec_from_file_location("prof_summary", os.path.join(ROOT, "tools", "prof_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    assert ps._long_cluster([10.0, 11.0, 9.5]) == ([10.0, 11.0, 9.5], 0)
+    assert ps._long_cluster([100.0, 98.0, 12.0, 12.5, 13.0]) == ([100.0, 98.0], 3)
+    assert ps._long_cluster([0.0, 5.0]) == ([0.0, 5.0], 0)
