@@ -251,6 +251,37 @@ def test_stock_style_plugin_odd_width_stays_on_the_hip_path(monkeypatch):
         assert rel <= 1e-5                                 # north_star: embedding norms to 1e-5
 
 
+def test_blocked_evaluation_equals_one_call():
+    """S-EVAL-sized evaluations go through the fused kernel in blocks of EVAL_USER_BLOCK users (131 072 by default: a scale no
+    test reaches); with the block lowered to 97 and to 1 user the same trainer must return the same scores, ids and metrics
+    as the single call -- rated CSR sliced per block, results written into their rows of the output."""
+    from coldrec_amd.model.BaseRecommender import BaseColdStartTrainer
+    g = load_golden("g6_eval_item_cont.npz")
+    _, data = builder()
+
+    class Fused(BaseColdStartTrainer):
+        fused_eval = True
+
+        def train(self): ...
+        def predict(self, u): ...
+        def save(self): ...
+        def batch_predict(self, users): ...
+
+    tr = Fused(_cfg(data, emb_size=16, bs=100))
+    tr.user_emb, tr.item_emb = torch.from_numpy(g["U"]).to(DEV), torch.from_numpy(g["V"]).to(DEV)
+    for t in ("all", "warm", "cold"):
+        ds = tr._sets("test", t)
+        _, s0, i0 = tr._topk_arrays(ds, t)
+        m0 = tr._metrics(ds, t, [10, 20])
+        for blk in (97, 1):
+            tr.EVAL_USER_BLOCK = blk
+            _, s1, i1 = tr._topk_arrays(ds, t)
+            assert np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)), (t, blk)
+            assert tr._metrics(ds, t, [10, 20]) == m0
+        del tr.EVAL_USER_BLOCK                      # back to the class default
+        assert np.array_equal(i0, g[f"{t}_idx"])    # ... and all of it == the reference's lists (rank margin verified)
+
+
 def test_dense_batch_predict_path_equals_fused_path():
     from coldrec_amd.model.BaseRecommender import BaseColdStartTrainer
     g = load_golden("g6_eval_item_cont.npz")
