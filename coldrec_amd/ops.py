@@ -286,23 +286,30 @@ def build_plans(user_idx, pos_idx, neg_idx, batch_size: int) -> np.ndarray:
     return out
 
 
+def plan_shape(n_records: int, batch_size: int):
+    """(n_batches, ints per plan) of ``build_plans_device``'s result."""
+    return (n_records + batch_size - 1) // batch_size, int(_lib.lib().crh_bpr_plan_ints(int(batch_size)))
+
+
 def build_plans_device(user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
-                       batch_size: int, lds_max_batch: int = 8192) -> torch.Tensor:
+                       batch_size: int, lds_max_batch: int = 8192, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Plans of every batch of an epoch, (n_batches, stride) int32 on the GPU: one launch of crh_bpr_plan_build (LDS
     sort per batch) for batch_size <= 8192, crh_bpr_plan_build_large (several workgroups per batch) above that.
-    ``lds_max_batch`` below 8192 sends smaller batches through the large builder too (tests)."""
+    ``lds_max_batch`` below 8192 sends smaller batches through the large builder too (tests); ``out``: build in place."""
     _need_cuda(user_idx, pos_idx, neg_idx)
     L = _lib.lib()
     n_rec = user_idx.numel()
     nb = (n_rec + batch_size - 1) // batch_size
     stride = int(L.crh_bpr_plan_ints(batch_size))
     u, p, n = (x.to(torch.int32).contiguous() for x in (user_idx, pos_idx, neg_idx))
+    if out is not None:
+        assert out.shape == (nb, stride) and out.dtype == torch.int32 and out.is_contiguous()
     if batch_size <= min(8192, lds_max_batch):
-        plans = torch.empty((nb, stride), dtype=torch.int32, device=user_idx.device)
+        plans = out if out is not None else torch.empty((nb, stride), dtype=torch.int32, device=user_idx.device)
         _lib.check(L.crh_bpr_plan_build(_lib.ptr(u), _lib.ptr(p), _lib.ptr(n), n_rec, int(batch_size),
                                         _lib.ptr(plans), _lib.current_stream()), "crh_bpr_plan_build")
         return plans
-    plans = torch.empty((nb, stride), dtype=torch.int32, device=user_idx.device)
+    plans = out if out is not None else torch.empty((nb, stride), dtype=torch.int32, device=user_idx.device)
     group = max(1, min(nb, (256 << 20) // (48 * int(batch_size) + 4096)))     # batches per call: workspace <= ~256 MB
     for b0 in range(0, nb, group):
         b1 = min(nb, b0 + group)
