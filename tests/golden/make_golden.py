@@ -563,6 +563,8 @@ def g12_real_size(which):
     """the reference's OWN training loops at the BASELINE config sizes, whole epochs.
       mf    model/MF.py:12-46        on the MovieLens-shaped split (6 040 x 3 706, ~6.4e5 triples), d=128, B=4096
       lgcn  model/LightGCN.py:14-47  on the CiteULike-shaped split (5 551 x 16 980, ~1.3e5 triples), L=3, d=128, B=4096
+      mf64run  BASELINE configs[0] (BPR-MF, cold_object=item, d=64) through ``run()`` (model/BaseRecommender.py:353-370): the
+            same recording + the final test metrics of the all / cold / warm settings at MovieLens size
     ``trainer.train()`` itself runs (2 epochs: the product's first epoch is eager, its second is captured into a hipGraph and
     replayed -- both are pinned), observed from outside: util.utils.bpr_loss / l2_reg_loss as the trainer's module sees them
     are wrapped to record every batch's two loss terms, next_batch_pairwise to checksum the triples, and a global optimizer
@@ -575,10 +577,12 @@ def g12_real_size(which):
     import importlib
     import io
     import time
-    shape, cls_name, layers, seed = {"mf": ("movielens", "MF", 0, 1), "lgcn": ("citeulike", "LightGCN", 3, 2)}[which]
+    shape, cls_name, layers, seed = {"mf": ("movielens", "MF", 0, 1), "lgcn": ("citeulike", "LightGCN", 3, 2),
+                                     "mf64run": ("movielens", "MF", 0, 1)}[which]
     split = make_dataset(shape, "item", seed=seed, with_content=False)
     data = ref_builder(split)
-    d, B, epochs = 128, 4096, 2
+    d, B, epochs = (64 if which == "mf64run" else 128), 4096, 2
+    whole_run = which == "mf64run"          # BASELINE configs[0]: BPR-MF, cold_object=item, d=64 through run(): + the three tests
     cfg = ref_config(data, dataset=shape, model=cls_name, layers=layers or 2, emb_size=d, epochs=epochs, bs=B)
     set_seed(2024, False)
     mod = importlib.import_module("model." + cls_name)
@@ -626,7 +630,10 @@ def g12_real_size(which):
     t0 = time.time()
     try:
         with contextlib.redirect_stdout(buf):
-            trainer.train()
+            if whole_run:
+                trainer.run()           # model/BaseRecommender.py:353-370: train() + full_evaluation of all / cold / warm
+            else:
+                trainer.train()
     finally:
         handle.remove()
         mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise = real_bpr, real_l2, real_next
@@ -649,6 +656,10 @@ def g12_real_size(which):
         best_epoch=trainer.bestPerformance[0], best_metrics=json.dumps(trainer.bestPerformance[1]),
         valid_lines=json.dumps([ln for ln in log if "Valid" in ln or "valid" in ln or "NDCG" in ln][:40]),
         reference_seconds=secs, torch_version=torch.__version__)
+    if whole_run:
+        res.update(test_overall=np.array(trainer.overall_test_results, np.float64),
+                   test_cold=np.array(trainer.cold_test_results, np.float64),
+                   test_warm=np.array(trainer.warm_test_results, np.float64), epochs_ran=trainer.epochs_ran)
     if layers:
         res.update(final_out_U=fin_U[rows_u], final_out_V=fin_V[rows_v],
                    final_out_norm=np.array([np.linalg.norm(fin_U.astype(np.float64)), np.linalg.norm(fin_V.astype(np.float64))]))
@@ -659,7 +670,7 @@ def g12_real_size(which):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g12":         # round 4: real-size whole-epoch fixtures (minutes of CPU)
-        for which in (sys.argv[2:] or ["mf", "lgcn"]):
+        for which in (sys.argv[2:] or ["mf", "lgcn", "mf64run"]):
             g12_real_size(which)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":         # add the round-3 fixtures without redoing G1-G10
@@ -698,6 +709,7 @@ def main():
     g11_lgcn_e2e(split_i)
     g12_real_size("mf")
     g12_real_size("lgcn")
+    g12_real_size("mf64run")
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

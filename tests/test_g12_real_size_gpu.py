@@ -51,7 +51,7 @@ def crc_fold(crc, bu, bi, bj):
     return c ^ (crc * 31 & 0xFFFFFFFF)
 
 
-def _run_trainer(g, model, monkeypatch, env=None):
+def _run_trainer(g, model, monkeypatch, env=None, whole_run=False):
     """The product's trainer.train() on the fixture's split; every epoch's per-step [bpr, l2] losses, the tables' norms and
     the sampled rows at the end of each epoch, and the triples' checksum are collected by a recording EpochRunner."""
     import coldrec_amd.model.MF as mf_mod
@@ -85,7 +85,10 @@ def _run_trainer(g, model, monkeypatch, env=None):
     import zlib
     assert zlib.crc32(tr.model.item0.numpy().tobytes(), 0) == int(g["V0_crc"]) and \
         zlib.crc32(tr.model.user0.numpy().tobytes(), 0) == int(g["U0_crc"]), "initial xavier tables differ from the reference's"
-    tr.train()
+    if whole_run:
+        tr.run()                          # train() + the three test settings (model/BaseRecommender.py:353-370)
+    else:
+        tr.train()
     return tr, rec
 
 
@@ -179,3 +182,21 @@ def test_g12_norms_every_ten_steps_eager(which):
                     (which, step, nu, nv, want[step])
     assert crc == int(g["triples_crc"]) and step == len(g["bpr"])
     print("g12 %s eager: %d norm check points, worst relative error %.2e" % (which, len(want), worst))
+
+
+def test_g12_config1_mf_d64_run_end_to_end(monkeypatch):
+    """BASELINE configs[0] at its own size: BPR-MF, cold_object=item, d=64 on the MovieLens-shaped split through ``run()`` --
+    the reference's own MF.run() (2 epochs) is in g12_mf64run_real_size.npz: every batch's losses, table norms, sampled rows,
+    validation bookkeeping, AND the final test metrics of the all / cold / warm settings (6 040 / 2 700-odd users ranked
+    against 3 706 items with the rated lists and the cold / warm candidate masks at real size)."""
+    g = load_golden("g12_mf64run_real_size.npz")
+    tr, rec = _run_trainer(g, "MF", monkeypatch, whole_run=True)
+    _check_against_reference(g, tr, rec, "g12 config 1 (mf d=64, run())")
+    assert tr.epochs_ran == int(g["epochs_ran"])
+    for name, got in (("test_overall", tr.overall_test_results), ("test_cold", tr.cold_test_results),
+                      ("test_warm", tr.warm_test_results)):
+        # metrics are functions of the top-20 lists (5 decimals); near-ties between MKL's summation order on the reference's
+        # tables and the canonical chain on ours can move single list entries: a few 1e-5 units, never the 1e-3 a defect shows
+        np.testing.assert_allclose(np.array(got), g[name], atol=2e-4, rtol=0, err_msg=name)
+    print("g12 config 1: test metrics", np.abs(np.array(tr.overall_test_results) - g["test_overall"]).max(),
+          np.abs(np.array(tr.cold_test_results) - g["test_cold"]).max(), np.abs(np.array(tr.warm_test_results) - g["test_warm"]).max())
