@@ -565,6 +565,7 @@ def g12_real_size(which):
       lgcn  model/LightGCN.py:14-47  on the CiteULike-shaped split (5 551 x 16 980, ~1.3e5 triples), L=3, d=128, B=4096
       mf64run  BASELINE configs[0] (BPR-MF, cold_object=item, d=64) through ``run()`` (model/BaseRecommender.py:353-370): the
             same recording + the final test metrics of the all / cold / warm settings at MovieLens size
+      lgcnrun  BASELINE configs[2]'s trainer (LightGCN L=3, d=128) through ``run()`` at CiteULike size, likewise
     ``trainer.train()`` itself runs (2 epochs: the product's first epoch is eager, its second is captured into a hipGraph and
     replayed -- both are pinned), observed from outside: util.utils.bpr_loss / l2_reg_loss as the trainer's module sees them
     are wrapped to record every batch's two loss terms, next_batch_pairwise to checksum the triples, and a global optimizer
@@ -578,11 +579,11 @@ def g12_real_size(which):
     import io
     import time
     shape, cls_name, layers, seed = {"mf": ("movielens", "MF", 0, 1), "lgcn": ("citeulike", "LightGCN", 3, 2),
-                                     "mf64run": ("movielens", "MF", 0, 1)}[which]
+                                     "mf64run": ("movielens", "MF", 0, 1), "lgcnrun": ("citeulike", "LightGCN", 3, 2)}[which]
     split = make_dataset(shape, "item", seed=seed, with_content=False)
     data = ref_builder(split)
     d, B, epochs = (64 if which == "mf64run" else 128), 4096, 2
-    whole_run = which == "mf64run"          # BASELINE configs[0]: BPR-MF, cold_object=item, d=64 through run(): + the three tests
+    whole_run = which.endswith("run")       # through run(): + the three tests.  mf64run = BASELINE configs[0]: BPR-MF, cold_object=item, d=64 through run(): + the three tests
     cfg = ref_config(data, dataset=shape, model=cls_name, layers=layers or 2, emb_size=d, epochs=epochs, bs=B)
     set_seed(2024, False)
     mod = importlib.import_module("model." + cls_name)
@@ -670,7 +671,7 @@ def g12_real_size(which):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g12":         # round 4: real-size whole-epoch fixtures (minutes of CPU)
-        for which in (sys.argv[2:] or ["mf", "lgcn", "mf64run"]):
+        for which in (sys.argv[2:] or ["mf", "lgcn", "mf64run", "lgcnrun"]):
             g12_real_size(which)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g11":         # add the round-3 fixtures without redoing G1-G10
@@ -710,6 +711,7 @@ def main():
     g12_real_size("mf")
     g12_real_size("lgcn")
     g12_real_size("mf64run")
+    g12_real_size("lgcnrun")
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

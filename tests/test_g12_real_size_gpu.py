@@ -200,3 +200,19 @@ def test_g12_config1_mf_d64_run_end_to_end(monkeypatch):
         np.testing.assert_allclose(np.array(got), g[name], atol=2e-4, rtol=0, err_msg=name)
     print("g12 config 1: test metrics", np.abs(np.array(tr.overall_test_results) - g["test_overall"]).max(),
           np.abs(np.array(tr.cold_test_results) - g["test_cold"]).max(), np.abs(np.array(tr.warm_test_results) - g["test_warm"]).max())
+
+
+def test_g12_lightgcn_run_end_to_end(monkeypatch):
+    """BASELINE configs[2]'s trainer through ``run()`` at CiteULike size (L=3, d=128, 2 epochs): the reference's own
+    LightGCN.run() -- losses, norms, the best-epoch SNAPSHOT (save() copies forward()'s tensors, model/LightGCN.py:49-51) and
+    the final all / cold / warm test metrics over 16 980 items."""
+    g = load_golden("g12_lgcnrun_real_size.npz")
+    tr, rec = _run_trainer(g, "LightGCN", monkeypatch, whole_run=True)
+    _check_against_reference(g, tr, rec, "g12 lightgcn run()")
+    assert tr.epochs_ran == int(g["epochs_ran"])
+    worst = 0.0
+    for name, got in (("test_overall", tr.overall_test_results), ("test_cold", tr.cold_test_results),
+                      ("test_warm", tr.warm_test_results)):
+        np.testing.assert_allclose(np.array(got), g[name], atol=2e-4, rtol=0, err_msg=name)
+        worst = max(worst, float(np.abs(np.array(got) - g[name]).max()))
+    print("g12 lightgcn run(): test metrics worst |ours - reference| %.1e" % worst)
