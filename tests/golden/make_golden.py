@@ -27,6 +27,8 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g12_*_real_size.npz  model/MF.py:12-46 / model/LightGCN.py:14-47  trainer.train() at the BASELINE config sizes
                    (MovieLens shape d=128 B=4096; CiteULike shape L=3 d=128), 2 whole epochs each: every batch's loss terms,
                    table norms every 10 steps, sampled rows per epoch, the per-epoch validation metrics
+  g13_eval_100k.npz  model/BaseRecommender.py:109-188  _evaluate for 512 users x 100 000 items, d=128, all / warm / cold:
+                   the reference's top-20 ids and scores (tables and split regenerated from seeds on the other side)
   g8_lists.npz / g9_lists.npz  model/BaseRecommender.py:153-188  the final top-20 lists of the g8 / g9 runs (re-run,
                    tables asserted equal to the stored ones) with the eval inputs needed to re-derive rank margins
 """
@@ -669,7 +671,54 @@ def g12_real_size(which):
           % (which, len(rec["bpr"]), secs, rec["bpr"][-1], rec["l2"][-1], trainer.bestPerformance))
 
 
+def g13_pairs(n_user=512, n_item=100_000, extra=60_000, seed=13):
+    """Interactions for G13 (shared with tests/test_g13_eval_gpu.py, which imports this function's twin): every item occurs at
+    least once (an item without a record has no name in the reference's id tables), users uniform."""
+    rng = np.random.default_rng(seed)
+    u = np.concatenate([rng.integers(0, n_user, n_item), rng.integers(0, n_user, extra)])
+    i = np.concatenate([np.arange(n_item), rng.integers(0, n_item, extra)])
+    key = np.unique(u.astype(np.int64) * n_item + i)
+    return np.stack([key // n_item, key % n_item], axis=1)
+
+
+def g13_eval_100k():
+    """model/BaseRecommender.py:109-188 at a catalogue that is not toy-sized: the reference's ``_evaluate`` (torch.matmul on the
+    host -> per-user rated masks -> candidate mask -> torch.topk) for 512 users x 100 000 items, d = 128, the three test
+    settings of a cold_object=item split.  Only the OUTPUT travels (ids + scores, 250 KB): tables, split and masks are
+    regenerated on the other side from the same seeds (numpy PCG64 / the product's split_cold, both deterministic)."""
+    from coldrec_amd.data.synth import split_cold
+    import time
+    t0 = time.time()
+    split = split_cold(g13_pairs(), "item", seed=54)
+    data = ref_builder(split)
+    d = 128
+    cfg = ref_config(data, dataset="g13", emb_size=d, bs=256)
+    trainer = MF(cfg)
+    rng = np.random.default_rng(1313)
+    a_u, a_i = np.sqrt(6.0 / (data.user_num + d)), np.sqrt(6.0 / (data.item_num + d))
+    U = ((rng.random((data.user_num, d)) * 2 - 1) * a_u * 8).astype(np.float32)      # xavier-shaped, scaled so that scores are O(0.1)
+    V = ((rng.random((data.item_num, d)) * 2 - 1) * a_i * 8).astype(np.float32)
+    trainer.user_emb, trainer.item_emb = torch.from_numpy(U), torch.from_numpy(V)
+    res = dict(n_user=data.user_num, n_item=data.item_num, d=d, table_seed=1313, split_seed=54, pairs_seed=13,
+               U_crc=_crc(U), V_crc=_crc(V), user_keys_crc=_crc(np.array([data.id2user[k] for k in range(len(data.user))], np.int64)),
+               item_keys_crc=_crc(np.array([data.id2item[k] for k in range(len(data.item))], np.int64)))
+    for t in ("all", "warm", "cold"):
+        test_set = {"all": data.overall_test_set, "warm": data.warm_test_set, "cold": data.cold_test_set}[t]
+        rec = trainer.test(t)
+        users = list(test_set.keys())
+        res[t + "_users_int"] = np.array([data.user[u] for u in users], np.int32)
+        res[t + "_idx"] = np.array([[data.item[it] for it, _ in rec[u]] for u in users], np.int32)
+        res[t + "_score"] = np.array([[sc for _, sc in rec[u]] for u in users], np.float32)
+    np.savez_compressed(out("g13_eval_100k.npz"), **res)
+    print("g13: %d users x %d items, settings all/warm/cold = %d/%d/%d users, %.1f s" % (
+        data.user_num, data.item_num, len(res["all_users_int"]), len(res["warm_users_int"]), len(res["cold_users_int"]),
+        time.time() - t0))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":
+        g13_eval_100k()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g12":         # round 4: real-size whole-epoch fixtures (minutes of CPU)
         for which in (sys.argv[2:] or ["mf", "lgcn", "mf64run", "lgcnrun"]):
             g12_real_size(which)
@@ -712,6 +761,7 @@ def main():
     g12_real_size("lgcn")
     g12_real_size("mf64run")
     g12_real_size("lgcnrun")
+    g13_eval_100k()
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 
