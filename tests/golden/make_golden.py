@@ -27,6 +27,8 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g12_*_real_size.npz  model/MF.py:12-46 / model/LightGCN.py:14-47  trainer.train() at the BASELINE config sizes
                    (MovieLens shape d=128 B=4096; CiteULike shape L=3 d=128), 2 whole epochs each: every batch's loss terms,
                    table norms every 10 steps, sampled rows per epoch, the per-epoch validation metrics
+  g14_graph_real_size.npz  util/databuilder.py:220-254  checksums of the reference's normalised adjacency + id tables at the
+                   MovieLens / CiteULike shapes
   g13_eval_100k.npz  model/BaseRecommender.py:109-188  _evaluate for 512 users x 100 000 items, d=128, all / warm / cold:
                    the reference's top-20 ids and scores (tables and split regenerated from seeds on the other side)
   g8_lists.npz / g9_lists.npz  model/BaseRecommender.py:153-188  the final top-20 lists of the g8 / g9 runs (re-run,
@@ -715,7 +717,29 @@ def g13_eval_100k():
         time.time() - t0))
 
 
+def g14_graph_real_size():
+    """util/databuilder.py:220-254,953-962 at the BASELINE dataset shapes: checksums of the reference's normalised bipartite
+    adjacency (CSR arrays, fp32 values) and of its id tables for the MovieLens- and CiteULike-shaped splits -- the product's
+    builder must reproduce them bit for bit (G4 does this on the toy split)."""
+    res = {}
+    for shape, seed in (("movielens", 1), ("citeulike", 2)):
+        split = make_dataset(shape, "item", seed=seed, with_content=False)
+        data = ref_builder(split)
+        adj = data.norm_adj.tocsr()
+        adj.sort_indices()
+        res.update({shape + "_n": adj.shape[0], shape + "_nnz": adj.nnz, shape + "_indptr_crc": _crc(adj.indptr.astype(np.int64)),
+                    shape + "_indices_crc": _crc(adj.indices.astype(np.int64)), shape + "_data_crc": _crc(adj.data.astype(np.float32)),
+                    shape + "_user_keys_crc": _crc(np.array([data.id2user[k] for k in range(len(data.user))], np.int64)),
+                    shape + "_item_keys_crc": _crc(np.array([data.id2item[k] for k in range(len(data.item))], np.int64)),
+                    shape + "_n_train": len(data.training_data), shape + "_data_seed": seed})
+    np.savez_compressed(out("g14_graph_real_size.npz"), **res)
+    print("g14:", {k: int(v) for k, v in res.items() if k.endswith("_nnz") or k.endswith("_n")})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14_graph_real_size()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g13":
         g13_eval_100k()
         return
@@ -762,6 +786,7 @@ def main():
     g12_real_size("mf64run")
     g12_real_size("lgcnrun")
     g13_eval_100k()
+    g14_graph_real_size()
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

@@ -354,3 +354,26 @@ def test_bench_helpers_legs_summary_and_profile_clusters():
     assert ps._long_cluster([10.0, 11.0, 9.5]) == ([10.0, 11.0, 9.5], 0)
     assert ps._long_cluster([100.0, 98.0, 12.0, 12.5, 13.0]) == ([100.0, 98.0], 3)
     assert ps._long_cluster([0.0, 5.0]) == ([0.0, 5.0], 0)
+
+
+@pytest.mark.parametrize("shape", ["movielens", "citeulike"])
+def test_g14_builder_and_adjacency_bitwise_at_real_size(shape):
+    """G14: at the BASELINE dataset shapes the product's builder assigns the reference's internal ids and its normalised
+    bipartite adjacency (D^-1/2 A D^-1/2, fp32, CSR; util/databuilder.py:220-254) equals the reference's bit for bit --
+    checksums of the reference's arrays, taken by tests/golden/make_golden.py g14."""
+    import zlib
+    from coldrec_amd.data.synth import make_dataset
+    g = load_golden("g14_graph_real_size.npz")
+    split = make_dataset(shape, "item", seed=int(g[shape + "_data_seed"]), with_content=False)
+    info = split.info
+    d = ColdStartDataBuilder(split.warm_train, split.warm_val, split.cold_val, split.overall_val, split.warm_test,
+                             split.cold_test, split.overall_test, info["user_num"], info["item_num"], info["warm_user"],
+                             info["warm_item"], info["cold_user"], info["cold_item"], None, None)
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes(), 0)
+    assert crc(np.asarray(d.user_keys, np.int64)) == int(g[shape + "_user_keys_crc"])
+    assert crc(np.asarray(d.item_keys, np.int64)) == int(g[shape + "_item_keys_crc"])
+    rowptr, col, val = d.norm_adj_csr()
+    assert len(rowptr) - 1 == int(g[shape + "_n"]) and len(col) == int(g[shape + "_nnz"])
+    assert crc(np.asarray(rowptr, np.int64)) == int(g[shape + "_indptr_crc"])
+    assert crc(np.asarray(col, np.int64)) == int(g[shape + "_indices_crc"])
+    assert crc(np.asarray(val, np.float32)) == int(g[shape + "_data_crc"])
