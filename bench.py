@@ -1106,6 +1106,7 @@ def main():
         # (no torch.cuda call has run in this process), and the launcher is a CHILD process whose output and exit code
         # are relayed -- a process that has initialised the GPU must never be replaced by another program.
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    t_main = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1283,6 +1284,7 @@ def main():
                       % (done, nu, args.cpu_budget_s, V_cpu.shape[0], torch.__version__, os.cpu_count(), secs)}
     del U_cpu, V_cpu
     legs = [] if args.legs == "none" else [x.strip() for x in args.legs.split(",") if x.strip()]
+    wall = {"headline_incl_setup_checks_cpu_baseline": round(time.perf_counter() - t_main, 1)}   # where the run's minutes go
     if world > 1 and not args.no_train and args.dtype == "f32":
         # Secondary leg.  The headline line must survive it: an exception is caught below, and if a rank gets stuck
         # in a collective (the others would wait for ever) a watchdog on every rank prints what it has (rank 0) and
@@ -1326,8 +1328,10 @@ def main():
                              ("eval_e2e", lambda: eval_e2e_leg(dev)),
                              ("torch_rocm", lambda: torch_rocm_leg(dev))):
             if leg_name in legs:
+                t_leg = time.perf_counter()
                 result.update(fn())
                 torch.cuda.empty_cache()
+                wall[leg_name] = round(time.perf_counter() - t_leg, 1)
     shard_leg = result.get("eval_midsize", {}).get("%dx%d" % (Bu, I // 8)) if rank == 0 and world == 1 else None
     if shard_leg:
         # what the 8-GPU run is expected to give -- every rank ranks the same user block against its
@@ -1341,6 +1345,8 @@ def main():
                     "number exists, the driver's SCALE run is the only one" % (
                         I // 8, I, shard_leg["frac_of_fp32_mfma_peak"], result["roofline"]["frac"])}
     if rank == 0:
+        wall["total"] = round(time.perf_counter() - t_main, 1)
+        result["wall_s"] = wall
         result["legs_summary"] = legs_summary(result)          # LAST key: survives a truncated tail of the line
         print(json.dumps(result), flush=True)
     if world > 1:
