@@ -27,6 +27,7 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
   g12_*_real_size.npz  model/MF.py:12-46 / model/LightGCN.py:14-47  trainer.train() at the BASELINE config sizes
                    (MovieLens shape d=128 B=4096; CiteULike shape L=3 d=128), 2 whole epochs each: every batch's loss terms,
                    table norms every 10 steps, sampled rows per epoch, the per-epoch validation metrics
+  g15_dropoutnet_real_size.npz  model/DropoutNet.py:13-236 through run() on the CiteULike-shaped split with content, d=128
   g14_graph_real_size.npz  util/databuilder.py:220-254  checksums of the reference's normalised adjacency + id tables at the
                    MovieLens / CiteULike shapes
   g13_eval_100k.npz  model/BaseRecommender.py:109-188  _evaluate for 512 users x 100 000 items, d=128, all / warm / cold:
@@ -736,7 +737,77 @@ def g14_graph_real_size():
     print("g14:", {k: int(v) for k, v in res.items() if k.endswith("_nnz") or k.endswith("_n")})
 
 
+def g15_backbone(user_num, item_num, d=128):
+    """Stand-in backbone tables for G15 (what ./emb/*_MF_*_emb.pt would hold), drawn from a fixed stream so that neither the
+    fixture nor the test has to store 11 MB of them (tests/test_e2e_gpu.py holds this function's twin)."""
+    rng = np.random.default_rng(15)
+    return (rng.standard_normal((user_num, d), dtype=np.float32) * np.float32(0.1),
+            rng.standard_normal((item_num, d), dtype=np.float32) * np.float32(0.1))
+
+
+def g15_dropoutnet_real_size():
+    """SURVEY.md 8(f)3 at a real dataset shape: the reference's DropoutNet (model/DropoutNet.py:13-236) through ``run()`` on
+    the CiteULike-shaped cold-item split WITH its 300-wide item content, d=128, batches of 1024, two epochs -- EVERY batch's
+    loss (torch.nn.functional.mse_loss wrapped), the generated tables' norms + 256 sampled rows of each, and the test metrics of
+    the three settings."""
+    import contextlib
+    import io
+    import tempfile
+    import time
+    from model.DropoutNet import DropoutNet  # noqa: E402  (reference)
+    split = make_dataset("citeulike", "item", seed=2, with_content=True)
+    data = ref_builder(split)
+    U, V = g15_backbone(data.user_num, data.item_num)
+    cwd = os.getcwd()
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "emb"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(U)), os.path.join(tmp, "emb", "citeulike_cold_item_MF_user_emb.pt"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(V)), os.path.join(tmp, "emb", "citeulike_cold_item_MF_item_emb.pt"))
+        os.chdir(tmp)
+        try:
+            cfg = ref_config(data, dataset="citeulike", model="DropoutNet", emb_size=128, epochs=2, bs=1024, n_dropout=0.5,
+                             dropoutnet_hidden1=200, dropoutnet_hidden2=100)
+            set_seed(2024, False)
+            trainer = DropoutNet(cfg)
+            buf = io.StringIO()
+            every = []                       # every batch's loss: torch.nn.MSELoss.forward goes through F.mse_loss
+            real_mse = torch.nn.functional.mse_loss
+
+            def mse_spy(*a, **kw):
+                r = real_mse(*a, **kw)
+                every.append(float(r.item()))
+                return r
+
+            torch.nn.functional.mse_loss = mse_spy
+            with contextlib.redirect_stdout(buf):
+                trainer.run()
+        finally:
+            torch.nn.functional.mse_loss = real_mse
+            os.chdir(cwd)
+    secs = time.time() - t0
+    loss_lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("training:")]
+    gu, gv = trainer.user_emb.detach().numpy(), trainer.item_emb.detach().numpy()
+    rows_u = np.sort(np.random.default_rng(12).choice(gu.shape[0], 256, replace=False))
+    rows_v = np.sort(np.random.default_rng(13).choice(gv.shape[0], 256, replace=False))
+    np.savez_compressed(
+        out("g15_dropoutnet_real_size.npz"), data_seed=2, d=128, batch_size=1024, epochs=2, every_loss=np.array(every, np.float64), backbone_crc=_crc(U, V),
+        user_num=data.user_num, item_num=data.item_num, n_train=len(data.training_data),
+        losses=np.array([float(l.split("batch_loss:")[1]) for l in loss_lines], np.float64), loss_lines=json.dumps(loss_lines),
+        epochs_ran=trainer.epochs_ran, best_epoch=trainer.bestPerformance[0], best_metrics=json.dumps(trainer.bestPerformance[1]),
+        test_overall=np.array(trainer.overall_test_results, np.float64), test_cold=np.array(trainer.cold_test_results, np.float64),
+        test_warm=np.array(trainer.warm_test_results, np.float64),
+        norm=np.array([np.linalg.norm(gu.astype(np.float64)), np.linalg.norm(gv.astype(np.float64))]),
+        rows_u=rows_u, rows_v=rows_v, gen_U=gu[rows_u], gen_V=gv[rows_v], scale=np.array([np.abs(gu).max(), np.abs(gv).max()]),
+        reference_seconds=secs, torch_version=torch.__version__)
+    print("g15: the reference's DropoutNet at CiteULike size in %.1f s; %d loss lines, last %s; best %s"
+          % (secs, len(loss_lines), loss_lines[-1] if loss_lines else None, trainer.bestPerformance))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g15":
+        g15_dropoutnet_real_size()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14_graph_real_size()
         return
@@ -787,6 +858,7 @@ def main():
     g12_real_size("lgcnrun")
     g13_eval_100k()
     g14_graph_real_size()
+    g15_dropoutnet_real_size()
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 
