@@ -40,3 +40,17 @@ def test_gpus_4_user_shards_self_launched_equals_gpus_1():
     one = _bench(["--gpus", "1"] + SMALL)
     four = _bench(["--gpus", "4", "--shard", "users"] + SMALL, CRH_BENCH_BACKEND="gloo")
     assert four["n_gpus"] == 4 and one["result_crc32"] == four["result_crc32"]
+
+
+def test_gpus_8_full_headline_size_self_launched_equals_gpus_1():
+    """The driver's N = 8 command shape at the FULL headline size (1 M-row user table x 10 M items, 131 072 users per step): eight
+    self-launched ranks with 1.25 M-item shards on the one GPU, one all-gather of 8 x 131 072 x 40 words, the canonical merge,
+    rank 0's oracle check against the whole table rebuilt from the shards' seeds, and the data-parallel train leg -- the last
+    step's (scores, ids) are byte for byte those of the one-rank run (tools/n8_full_size_one_gpu.sh is the same as a script)."""
+    full = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--legs", "none"]
+    one = _bench(["--gpus", "1"] + full)
+    eight = _bench(["--gpus", "8"] + full, CRH_BENCH_BACKEND="gloo")
+    assert eight["n_gpus"] == 8 and eight["config"]["items"] == 10_000_000 and eight["config"]["users_per_step"] == 131072
+    assert one["verified_users"] == 64 and eight["verified_users"] == 64
+    assert one["result_crc32"] == eight["result_crc32"]
+    assert eight["train_mf_dp"]["replicas_identical"] is True
