@@ -839,7 +839,7 @@ def train_dp_leg(dev, world, rank):
                                    % (d, B, world, (n_u + n_i) * d * 4), "parallelism": "dp%d" % world}}
 
 
-def dropoutnet_generator(dev, n_items, d, content_dim=300, chunk=1_000_000):
+def dropoutnet_generator(dev, n_items, d, content_dim=300, chunk=1_000_000, item_lo=0, block=250_000):
     """BASELINE.json configs[4], generator half (model/DropoutNet.py:126-135): every item goes through the item tower
     of DeepCF -- [warm embedding ; content] (d + content_dim) -> 200 -> 100 -> d, Linear + eval-mode BatchNorm + tanh --
     as stock PyTorch-ROCm modules (rocBLAS / hipBLASLt GEMMs), chunk by chunk, and lands as the fp16 item table the
@@ -867,6 +867,18 @@ def dropoutnet_generator(dev, n_items, d, content_dim=300, chunk=1_000_000):
     run()
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
+    # The table that is RANKED: the same tower over inputs drawn per GLOBAL block of `block` items (seed = block index), so a
+    # rank's shard [item_lo, item_lo + n_items) holds exactly the rows the one-GPU run generates there -- the lists are then
+    # independent of the number of ranks, as in the fp32 headline (untimed: the rate above is the tower's, on resident inputs)
+    with torch.no_grad():
+        for b in range(item_lo // block, (item_lo + n_items + block - 1) // block):
+            gb = torch.Generator(device=dev).manual_seed(1000 + b)
+            w_b = torch.randn((block, d), generator=gb, device=dev) * 0.1
+            c_b = torch.randn((block, content_dim), generator=gb, device=dev)
+            _, v = net.encode(users_dummy, w_b, None, c_b)
+            g_lo, g_hi = max(b * block, item_lo), min((b + 1) * block, item_lo + n_items)
+            out[g_lo - item_lo:g_hi - item_lo] = v[g_lo - b * block:g_hi - b * block].to(torch.float16)
+    torch.cuda.synchronize()
     return out, {"metric": "items generated/sec (DropoutNet item tower)", "value": n_items / sec, "unit": "items/s",
                  "seconds": sec, "tflops": flops_item * n_items / sec / 1e12,
                  "config": {"workload": "DeepCF item tower %d -> 200 -> 100 -> %d (fp32 GEMMs via PyTorch-ROCm, eval-mode "
@@ -1151,7 +1163,7 @@ def main():
     gen_leg = None
     if args.generator:           # configs[4]: the item table is GENERATED by the DropoutNet tower, then ranked in fp16
         assert args.dtype == "f16", "--generator produces the fp16 table of configs[4]: use --dtype f16"
-        V, gen_leg = dropoutnet_generator(dev, hi - lo, d)
+        V, gen_leg = dropoutnet_generator(dev, hi - lo, d, item_lo=lo)
     else:
         V = item_shard(I, d, lo, hi, dev, tdtype)
     n_blocks = args.warmup + args.steps
@@ -1258,6 +1270,13 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     want_verify = rank == 0 and not args.no_verify and args.shard == "items" and not args.generator
     U_cpu = V_cpu = None
+    want_verify = want_verify and args.dtype == "f32"          # the fp16 table is checked on the device by the eval_f16 leg
+    if (want_cpu or want_verify) and float(I) * d * 4 > 24e9:
+        # e.g. configs[4] as a command (--dtype f16 --items 50000000 --dim 256): an fp32 host copy of the whole table would be
+        # 51 GB; the CPU legs are for tables a host comfortably holds
+        result["host_legs_skipped"] = "fp32 host copy of the %d x %d table = %.0f GB: no CPU baseline / host oracle check" % (
+            I, d, float(I) * d * 4 / 1e9)
+        want_cpu = want_verify = False
     if want_cpu or want_verify:
         U_cpu = U.float().cpu().numpy()
         if world == 1:
@@ -1265,7 +1284,7 @@ def main():
         else:   # rank 0 holds one shard: rebuild the whole table chunk by chunk (same seeds as every rank used)
             V_cpu = np.concatenate([item_shard(I, d, c, min(c + CHUNK_ROWS, I), dev, tdtype).float().cpu().numpy()
                                     for c in range(0, I, CHUNK_ROWS)])
-    if want_verify and args.dtype == "f32":
+    if want_verify:
         b_last = args.warmup + args.steps - 1
         users_last, rp_last, rc_last = blocks[b_last]
         result["verified_users"] = verify_users(
