@@ -250,8 +250,14 @@ __device__ __forceinline__ float order_key_inv(unsigned k) {
     return __builtin_bit_cast(float, k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
+// Register allocation held to three waves per SIMD (167 VGPRs, no scratch): left alone the compiler takes 248 for the unrolled
+// chunk (two waves per SIMD); at four it spills.  Same-box A/B on the validation shapes, 2 / 3 / 4 waves: 0.115 / 0.109 / 0.115 ms
+// (6 040 x 3 706) and 0.402 / 0.386 / 0.403 ms (5 551 x 16 980).
+#ifndef CRH_CHUNK_OCC
+#define CRH_CHUNK_OCC 3
+#endif
 template <int NV>
-__global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __restrict__ S, int64_t n_users,
+__global__ __launch_bounds__(256, CRH_CHUNK_OCC) void mask_topk_chunk_kernel(const float* __restrict__ S, int64_t n_users,
                                                               int64_t n_items, int64_t stride,
                                                               const int64_t* __restrict__ rated_rowptr,
                                                               const int32_t* __restrict__ rated_col,
@@ -300,7 +306,10 @@ __global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __res
             if (__ballot(m > tau) == 0ull) continue;
             if (have_masks) {
                 const int64_t g0 = item_base + base;              // global id of the chunk's first item
-                for (int w = lane; w < WORDS; w += 64) {
+#pragma unroll
+                for (int j = 0; j < (WORDS + 63) / 64; ++j) {
+                    const int w = lane + 64 * j;
+                    if (w >= WORDS) break;
                     unsigned word = 0;
                     if (bitmap) {
                         const int64_t wi = (g0 >> 5) + w;
@@ -345,7 +354,10 @@ __global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __res
                 const unsigned t = cur | (1u << b);
                 if (__popcll(__ballot(mk >= t)) >= K) cur = t;
             }
-            const float tau0 = order_key_inv(cur);
+            // one threshold for both tests of a candidate, v >= tau0 (the chunk's bound) and v > tau (strict: the list's k-th
+            // score): v > tau <=> v >= the next float above tau (-FLT_MAX for tau = -inf), and both are wave-uniform.  Items past
+            // the row's end were loaded as -inf and stay below it.
+            const float thr = fmaxf(order_key_inv(cur), order_key_inv(order_key(tau) + 1u));
             // The chunk's candidates (>= tau0, and > the list's k-th score: list entries come from earlier chunks, i.e. lower
             // ids) are compacted into LDS; if they and the list fit one entry per lane, the new list is a RANK SORT of the
             // union -- every lane counts the entries that beat its own (canonical order, ids are distinct) and stores it at
@@ -357,11 +369,11 @@ __global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __res
                 for (int u = 0; u < NV; ++u) {
                     const int64_t e0 = base + u * 256 + lane * 4;
                     const float mu = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
-                    if (__ballot(mu >= tau0 && mu > tau) == 0ull) continue;
+                    if (__ballot(mu >= thr) == 0ull) continue;
                     const float vc[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const bool pr = vc[c] >= tau0 && vc[c] > tau && e0 + c < n_items;
+                        const bool pr = vc[c] >= thr;
                         const unsigned long long bal = __ballot(pr);
                         if (pr) {
                             const int pos = nc + __popcll(bal & lt);
@@ -407,13 +419,12 @@ __global__ __launch_bounds__(256) void mask_topk_chunk_kernel(const float* __res
             // (more candidates than lanes: one by one)
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                const int64_t e0 = base + u * 256 + lane * 4;
                 const float mu = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
-                if (__ballot(mu >= tau0 && mu > tau) == 0ull) continue;
+                if (__ballot(mu >= thr) == 0ull) continue;
                 const float vc[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    unsigned long long cand = __ballot(vc[c] >= tau0 && vc[c] > tau && e0 + c < n_items);
+                    unsigned long long cand = __ballot(vc[c] >= thr);
                     while (cand) {
                         const int L = __builtin_ctzll(cand);
                         cand &= cand - 1;
