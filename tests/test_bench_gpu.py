@@ -54,3 +54,15 @@ def test_gpus_8_full_headline_size_self_launched_equals_gpus_1():
     assert one["verified_users"] == 64 and eight["verified_users"] == 64
     assert one["result_crc32"] == eight["result_crc32"]
     assert eight["train_mf_dp"]["replicas_identical"] is True
+
+
+def test_config5_generator_fp16_three_uneven_shards_equal_one_rank():
+    """BASELINE configs[4]'s command shape (--dtype f16 --generator) at a small size: the DropoutNet item tower generates each
+    rank's rows of the fp16 table from inputs drawn per GLOBAL block of 250 000 items, so three ranks whose shard bounds fall
+    inside blocks (700 003 items) rank the same table as one rank: the last step's lists are equal byte for byte."""
+    small = ["--dtype", "f16", "--generator", "--dim", "64", "--items", "700003", "--users", "4096", "--users-per-step", "2048",
+             "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train", "--legs", "none"]
+    one = _bench(["--gpus", "1"] + small)
+    three = _bench(["--gpus", "3"] + small, CRH_BENCH_BACKEND="gloo")
+    assert three["n_gpus"] == 3 and three["dtype"] == "f16" and "dropoutnet_generator" in three
+    assert one["result_crc32"] == three["result_crc32"]
