@@ -152,14 +152,16 @@ def verify_users(tag, got_s, got_i, users_rows, U_cpu, V_cpu, rowptr_blk, col_bl
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def measured_traffic(kernel_prefix, grid_threads):
+def measured_traffic(kernel_prefix, grid_threads, prefer=None):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_pmc.json, written by tools/profile_round.sh + tools/prof_summary.py in separate --pmc passes;
     FETCH_SIZE x 1024 x 2 as MI355X_MICROARCH.md prescribes for 16-B/lane streams on gfx950, + WRITE_SIZE x
     1024).  Only a record of the SAME kernel instantiation and grid counts; otherwise None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    # newest record by name; among a round's passes the one taken for this leg (``prefer``) wins
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")),
+                    key=lambda x: (os.path.basename(x).split("_")[0], bool(prefer) and prefer in os.path.basename(x), os.path.basename(x))):
         try:
             rec = json.load(open(f))
         except (OSError, ValueError):
@@ -1252,7 +1254,7 @@ def main():
         groups = (Bu + 63) // 64
         tr = None
         if groups >= 2048:       # the library's choice for this shape: the workgroup-cooperative kernel
-            tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8,", float(64 * ((groups + 7) // 8) * 8))
+            tr = measured_traffic("score_topk_wg_kernel<float, 128, 2, 8,", float(64 * ((groups + 7) // 8) * 8), prefer="_eval_pmc")
         if tr:
             # the profile is of the one-GPU launch over the whole table; a rank's launch streams its shard only
             # (the traffic is 8 XCD L2s x the table streamed, so it scales with the shard)

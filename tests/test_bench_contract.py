@@ -26,7 +26,7 @@ def test_default_command_line_and_legs():
     for leg in ("eval_f16", "mask_topk", "train_xl", "train_xl_lightgcn", "train", "eval_validation", "eval_midsize", "eval_e2e",
                 "torch_rocm"):
         assert leg in src
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_a.json")))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_d.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in rec, key
@@ -54,6 +54,7 @@ def test_default_command_line_and_legs():
     assert rec["eval_f16"]["shard_8gpu"]["items"] == 6_250_000 and 6.0 < rec["eval_f16"]["predicted_scaling_8gpu"]["value"] <= 8.0
     assert list(rec)[-1] == "legs_summary" and {"headline", "eval_f16", "mask_topk", "train_lightgcn"} <= set(rec["legs_summary"])
     assert isinstance(rec["result_crc32"], int)
+    assert rec["wall_s"]["total"] < 360 and set(rec["wall_s"]) >= {"eval_f16", "train", "eval_e2e", "total"}   # "finishes within minutes"
     # the XL SpMM's traffic comes from a profile of its own instantiation
     tr = bench.measured_traffic("spmm_csr_kernel<32>", None)
     assert tr is not None and tr[1].startswith("r0") and 1.5e11 < tr[0] < 3e11
