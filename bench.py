@@ -174,6 +174,30 @@ def measured_traffic(kernel_prefix, grid_threads, prefer=None):
     return best
 
 
+def _time_steps_each(fn, n_steps, warm):
+    """Every step between its own pair of events (the host does not wait in between): (median seconds, spread dict).  For legs
+    whose whole timed region is tens of milliseconds, where one hiccup would own a block average (VERDICT.md r3 weak #1)."""
+    for s in range(warm):
+        fn(s)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+    ev[0].record()
+    for s in range(n_steps):
+        fn(warm + s)
+        ev[s + 1].record()
+    torch.cuda.synchronize()
+    ms = np.array([ev[s].elapsed_time(ev[s + 1]) for s in range(n_steps)])
+    med = float(np.median(ms))
+    return med * 1e-3, {"median": med, "min": float(ms.min()), "max": float(ms.max()), "mean": float(ms.mean()),
+                        "stalled_step_seen": bool(ms.max() > 2 * med), "how": "each of %d steps timed event to event" % n_steps}
+
+
+def _median_ms(fn, reps, warm=2):
+    """median milliseconds of ``reps`` calls, each between its own pair of events (+ min / max): the short secondary legs"""
+    sec, sp = _time_steps_each(lambda s: fn(), reps, warm)
+    return sp["median"], sp
+
+
 def _time_steps(fn, n_steps, warm):
     for s in range(warm):
         fn(s)
@@ -202,16 +226,11 @@ def validation_eval_leg(dev):
         rp, rc = ops.rated_csr(rated, dev)
         bm = ops.make_bitmap(n_items, np.where(rng.random(n_items) < 0.2)[0], dev)
         ms = {}
-        for tag, ns in (("library", 0), ("fused_selection", 1)):
-            for _ in range(2):
-                ops.score_topk(U, None, V, 20, rp, rc, bm, n_splits=ns)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                ops.score_topk(U, None, V, 20, rp, rc, bm, n_splits=ns)
-            torch.cuda.synchronize()
-            ms[tag] = (time.perf_counter() - t0) / 10 * 1e3
+        spread = {}
+        for tag, ns, reps in (("library", 0, 50), ("fused_selection", 1, 5)):
+            ms[tag], spread[tag] = _median_ms(lambda: ops.score_topk(U, None, V, 20, rp, rc, bm, n_splits=ns), reps)
         out[name] = {"users": n_users, "items": n_items, "ms": ms["library"], "items_per_s": n_users * n_items / ms["library"] * 1e3,
+                     "ms_min_max": [spread["library"]["min"], spread["library"]["max"]], "timed_calls": 50,
                      "ms_fused_selection": ms["fused_selection"]}
     return {"eval_validation": out}
 
@@ -234,14 +253,13 @@ def midsize_eval_leg(dev):
         cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
         bm = ops.make_bitmap(n_items, cold, dev)
         rp, rc = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
-        for _ in range(2):
-            res = ops.score_topk(U, None, V, 20, rp, rc, bm)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            res = ops.score_topk(U, None, V, 20, rp, rc, bm)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
+        hold = {}
+
+        def call():
+            hold["res"] = ops.score_topk(U, None, V, 20, rp, rc, bm)
+
+        ms, sp = _median_ms(call, 5 if n_users * n_items < 4e10 else 3)
+        res = hold["res"]
         pick = np.unique(np.concatenate([[0, n_users - 1], np.random.default_rng(9).integers(0, n_users, 14)])).astype(np.int64)
         sub_rp = np.concatenate([[0], np.cumsum([rowptr[u + 1] - rowptr[u] for u in pick])]).astype(np.int64)
         sub_col = np.concatenate([col[rowptr[u]:rowptr[u + 1]] for u in pick]).astype(np.int64)
@@ -625,16 +643,13 @@ def mask_topk_leg(dev, n_users=4096, n_items=1_000_000, k=20, reps=5):
     bm = ops.make_bitmap(n_items, cold, dev)
     ms = {}
     for wb in (False, True):
-        for _ in range(2):
-            out = ops.mask_topk(S, k, rp, rc, bm, write_back=wb)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            out = ops.mask_topk(S, k, rp, rc, bm, write_back=wb)
-        e1.record()
-        torch.cuda.synchronize()
-        ms[wb] = e0.elapsed_time(e1) / reps
+        hold = {}
+
+        def call():
+            hold["out"] = ops.mask_topk(S, k, rp, rc, bm, write_back=wb)
+
+        ms[wb], _ = _median_ms(call, 3 * reps)
+        out = hold["out"]
         if not wb:                                           # self-check before the block is mutated: 32 rows vs the oracle
             rows = sorted(set(int(x) for x in np.linspace(0, n_users - 1, 32)))
             for r in rows:
@@ -902,8 +917,9 @@ def train_xl(dev, steps, warm, lazy=False):
     tri = [(torch.randint(0, n_u, (B,), generator=g, device=dev, dtype=torch.int32),
             torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32),
             torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32)) for _ in range(8)]
-    sec = _time_steps(lambda s: eng.step(*tri[s % 8]), steps, warm)
+    sec, spread = _time_steps_each(lambda s: eng.step(*tri[s % 8]), steps, warm)
     out = {"metric": "BPR triples/sec (train)", "value": B / sec, "unit": "triples/s", "ms_per_step": sec * 1e3,
+           "ms_per_step_spread": spread,
            "config": {"workload": "S-TRAIN-XL: BPR-MF, 1M users x 10M items, d=128, B=65536, %s"
                                   % ("dense Adam replayed on touched rows (bit-identical)" if lazy else "dense Adam")}}
     if lazy:
@@ -1341,7 +1357,7 @@ def main():
         del V, U, engine, blocks, out
         torch.cuda.empty_cache()
         for leg_name, fn in (("eval_f16", lambda: eval_f16_leg(dev)), ("mask_topk", lambda: mask_topk_leg(dev)),
-                             ("train_xl", lambda: {"train_xl": train_xl(dev, 3, 1)}),
+                             ("train_xl", lambda: {"train_xl": train_xl(dev, 9, 2)}),
                              ("train_xl_lightgcn", lambda: {"train_xl_lightgcn": train_xl_lightgcn(dev, 2, 1)}),
                              ("train", lambda: train_legs(dev, not args.no_cpu_baseline)),
                              ("eval_validation", lambda: validation_eval_leg(dev)),
