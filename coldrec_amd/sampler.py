@@ -10,7 +10,6 @@ import ctypes
 import math
 import os
 import random
-import threading
 import time
 
 import numpy as np

@@ -14,11 +14,10 @@ cold test, overall val, overall test (util/databuilder.py:90-216).
 from __future__ import annotations
 
 from collections import defaultdict
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import scipy.sparse as sp
-import torch
 
 
 def _as_pairs(records) -> np.ndarray:

@@ -5,10 +5,8 @@ Reference: main.py:149-301 (driver, summary, result file), model/MF.py:44-46 and
 of the tables: MF stores its live ``nn.Parameter``s, LightGCN the plain tensors its ``forward()`` built), read back by
 model/DropoutNet.py:95-100 (``nn.ParameterDict`` over ``torch.load(./emb/<dataset>_cold_<object>_<backbone>_*.pt)``)."""
 import json
-import os
 import re
 
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn

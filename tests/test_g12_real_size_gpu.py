@@ -9,7 +9,6 @@ and must agree with the north_star tolerance: losses and embedding norms to 1e-5
 table's scale."""
 import argparse
 import json
-import os
 import types
 
 import numpy as np
