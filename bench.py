@@ -1125,7 +1125,7 @@ def main():
                     help="only run the S-TRAIN-XL LightGCN leg (1.1e7 nodes, ~4e8 stored edges, d=128, L=3)")
     ap.add_argument("--cpu-sample-users", type=int, default=2048,
                     help="users of the CPU baseline (blocks of 256 against the WHOLE item table, SURVEY.md 8(d))")
-    ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="the CPU baseline stops after this many seconds")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="the CPU baseline stops after this many seconds")
     ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train_xl_lightgcn,train,eval_validation,eval_midsize,eval_e2e,torch_rocm",
                     help="N=1: secondary legs carried in the same JSON line (comma separated; 'none' = headline only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the last timed step")
