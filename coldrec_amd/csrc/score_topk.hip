@@ -979,15 +979,20 @@ size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
     return (groups * 64 * row + 255) & ~(size_t)255;       // whole 64-user groups
 }
 
-// Prefix length of the seeded route (0 = not applicable): 1/16 of the catalogue, 4 096 .. 16 384 items, whole tiles.
+// Prefix length of the seeded route (0 = not applicable): 1/16 of the catalogue in 4 096 .. 16 384 items; up to 16 384 users 1/8 of it,
+// capped at 32 768 (65 536 up to 4 096 users); whole tiles.
 // After a prefix of P items a user takes ~k ln(N / P) candidates through the slow path instead of k (1 + ln(N / k)), and
 // every item-range cut shares that total instead of repeating the warm-up; the prefix itself is ranked by the dense route
 // at 8 bytes of traffic per (user, item) pair.
-int64_t seed_prefix_items(int64_t n_items) {
+// Few users make the prefix's dense block cheap, so they take a longer one (tools/seed_prefix_sweep.sh, round 4: 8 192 x 262 144
+// 0.666 -> 0.679 at 32 768 items, 4 096 x 10 M 0.815 -> 0.827 at 65 536, 16 384 x 1 M 0.787 -> 0.793 at 32 768; 65 536 x 131 072 is
+// best at its 8 192).
+int64_t seed_prefix_items(int64_t n_items, int64_t n_users) {
     if (n_items < 65536) return 0;
     const char* pe = getenv("CRH_SCORE_SEED_ITEMS");                  // tuning hook (read per call)
-    int64_t p = pe && atoll(pe) >= 1024 ? std::min<int64_t>(atoll(pe), n_items / 4) : n_items / 16;
-    if (!pe) p = std::max<int64_t>(4096, std::min<int64_t>(16384, p));
+    const bool few = n_users <= 16384;
+    int64_t p = pe && atoll(pe) >= 1024 ? std::min<int64_t>(atoll(pe), n_items / 4) : n_items / (few ? 8 : 16);
+    if (!pe) p = std::max<int64_t>(4096, std::min<int64_t>(n_users <= 4096 ? 65536 : (few ? 32768 : 16384), p));
     return p & ~(int64_t)31;
 }
 size_t seed_bytes(int64_t n_users, int k) { return (((size_t)n_users * k * 8) + 255) & ~(size_t)255; }
@@ -1032,7 +1037,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     const char* sm = getenv("CRH_SCORE_SEED");
     const int seed_mode = sm ? atoi(sm) : 1;
-    int64_t P = seed_prefix_items(n_items);
+    int64_t P = seed_prefix_items(n_items, n_users);
     if (!seed_mode || P <= 0 || n_users <= 0) return 0;
     const int upw = users_per_wave(esz, d);
     const int64_t n_ug = (n_users + upw - 1) / upw;
