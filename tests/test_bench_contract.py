@@ -26,7 +26,7 @@ def test_default_command_line_and_legs():
     for leg in ("eval_f16", "mask_topk", "train_xl", "train_xl_lightgcn", "train", "eval_validation", "eval_midsize", "eval_e2e",
                 "torch_rocm"):
         assert leg in src
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_e.json")))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_f.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in rec, key

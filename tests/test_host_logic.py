@@ -343,7 +343,7 @@ def test_bench_helpers_legs_summary_and_profile_clusters():
     import importlib.util
     sys.path.insert(0, ROOT)
     import bench
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_e.json")))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_f.json")))
     summ = bench.legs_summary({k: v for k, v in rec.items() if k != "legs_summary"})
     assert summ == rec["legs_summary"]
     assert summ["headline"] == [round(rec["ms_per_step"], 3), round(rec["roofline"]["frac"], 4)]
