@@ -661,7 +661,7 @@ def g12_real_size(which):
         end_U=np.stack(rec["end_U"]), end_V=np.stack(rec["end_V"]), end_norm=np.array(rec["end_norm"], np.float64),
         best_epoch=trainer.bestPerformance[0], best_metrics=json.dumps(trainer.bestPerformance[1]),
         valid_lines=json.dumps([ln for ln in log if "Valid" in ln or "valid" in ln or "NDCG" in ln][:40]),
-        reference_seconds=secs, torch_version=torch.__version__)
+        torch_version=torch.__version__)       # (no wall-clock field: the file regenerates byte for byte)
     if whole_run:
         res.update(test_overall=np.array(trainer.overall_test_results, np.float64),
                    test_cold=np.array(trainer.cold_test_results, np.float64),
@@ -799,7 +799,7 @@ def g15_dropoutnet_real_size():
         test_warm=np.array(trainer.warm_test_results, np.float64),
         norm=np.array([np.linalg.norm(gu.astype(np.float64)), np.linalg.norm(gv.astype(np.float64))]),
         rows_u=rows_u, rows_v=rows_v, gen_U=gu[rows_u], gen_V=gv[rows_v], scale=np.array([np.abs(gu).max(), np.abs(gv).max()]),
-        reference_seconds=secs, torch_version=torch.__version__)
+        torch_version=torch.__version__)       # (no wall-clock field: the file regenerates byte for byte)
     print("g15: the reference's DropoutNet at CiteULike size in %.1f s; %d loss lines, last %s; best %s"
           % (secs, len(loss_lines), loss_lines[-1] if loss_lines else None, trainer.bestPerformance))
 
