@@ -31,6 +31,8 @@ SIGNATURES = {
     "crh_score_topk_supports_dim": (_i32, [_i32]),
     "crh_score_topk_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "crh_score_topk_min_workspace_bytes": (_sz, [_i64, _i32]),
+    "crh_score_topk_route": (_i32, [_i32, _i64, _i64, _i32, _i32, _sz, _i32, _i32, _vp, _vp]),
+    "crh_score_topk_route_kernel": (ctypes.c_char_p, [_i32]),
     "crh_score_topk_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,
                                   _vp, _sz, _vp]),
     "crh_score_topk_f32_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp,

@@ -39,61 +39,11 @@
 #include <algorithm>
 #include <vector>
 
-#include "crh_common.h"
-#include "topk_list.h"
+#include "score_topk_common.h"
+
+using namespace crh_score;
 
 namespace {
-
-struct ScoreArgs {
-    const void* user_emb;   // fp32 or fp16 (the kernel's element type)
-    const int32_t* users;
-    int64_t n_users;
-    const void* item_emb;
-    const void* packed;    // item tiles in MFMA-fragment order (pack_items_kernel), or NULL
-    int64_t n_items;
-    const int64_t* rated_rowptr;
-    const int32_t* rated_col;
-    const uint32_t* bitmap;
-    int k;
-    int64_t item_base;
-    int n_splits;
-    int64_t n_ugroups;
-    float* out_score;   // [n_splits][n_users][k]
-    int32_t* out_idx;
-    int ablate;         // measurement only (CRH_SCORE_ABLATE): 1 = skip the selection epilogue, 4 = skip the workgroup barriers
-    unsigned long long* wave_clock;   // measurement only (CRH_SCORE_TIMING): [wave][2] start/end wall clock
-    unsigned* xcd_sync;     // [8 XCD][1 + n_windows] zeroed counters, or NULL: keeps the waves of an XCD within
-    int sync_window;        // two windows of `sync_window` tiles of each other (see xcd_window_sync)
-    int64_t sync_stride;    // counters per XCD
-    float* dense;           // small catalogues: write the score tiles here (slot-major, `dense_stride` floats per
-    int64_t dense_stride;   // user, a multiple of 32) instead of selecting; crh_mask_topk_f32 ranks the block
-    int64_t user_base;      // first table row of the block when `users` is NULL
-    // SEEDED lists (score_topk_seeded): every user's list starts as the finished top-k of an item PREFIX that was ranked
-    // beforehand ([n_users][k], canonical order, padded with (-inf, PAD)), so the thresholds are tight from the first
-    // tile and an item-range cut no longer repeats the top-k warm-up.  The seeds' ids lie below this launch's item_base.
-    const float* seed_score;
-    const int32_t* seed_idx;
-};
-
-// in : lane (i,0) holds k = 8q+0..3 of row i, lane (i,1) holds k = 8q+4..7
-// out: .x = {8q | 8q+1}, .z = {8q+2 | 8q+3}, .y = {8q+4 | 8q+5}, .w = {8q+6 | 8q+7}  (low | high half)
-// v_permlane32_swap vdst, src exchanges lanes 32-63 of vdst with lanes 0-31 of src.
-// NOTE (hipcc 7.2): keep the swap on the integer vector.  A helper taking float& x, float& y and
-// bit-casting the two scalar results separately is miscompiled (the second result is replaced
-// by the first: v_mov y, x after the swap) -- found by reading the ISA, would fail parity.
-__device__ __forceinline__ void chunk_swap(f32x4& cf) {
-    u32x4 c = __builtin_bit_cast(u32x4, cf);
-    const u32x2 r0 = __builtin_amdgcn_permlane32_swap(c.x, c.y, false, false);
-    const u32x2 r1 = __builtin_amdgcn_permlane32_swap(c.z, c.w, false, false);
-    u32x4 o;
-    o.x = r0[0];
-    o.y = r0[1];
-    o.z = r1[0];
-    o.w = r1[1];
-    cf = __builtin_bit_cast(f32x4, o);
-}
-
-__device__ __forceinline__ f32x4 load16(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // Item table -> fragment order.  Tile t = rows [32t, 32t+32) (rows past the end repeat the last row),
 // chunk q = k in [8q, 8q+8):   packed[((t*NCH + q)*64 + h*32 + i)*4 + c] = V[32t + i][8q + 2*j(c) + h],
@@ -146,232 +96,20 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const _Float16* __r
     }
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T>
-struct Elem;
-template <>
-struct Elem<float> {
-    static constexpr bool kSwap = true;      // row-major rows need the k-pair swap (chunk_swap)
-    template <int UW>
-    static __device__ __forceinline__ void mma(f32x16 (&acc)[UW], const f32x4& c, const f32x4 (&b)[UW]) {
-        // four k-pairs per 32-byte chunk, users interleaved so dependent MFMAs are one slot apart
-#pragma unroll
-        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, b[u].x, acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, b[u].z, acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, b[u].y, acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, b[u].w, acc[u], 0, 0, 0);
-    }
-};
-template <>
-struct Elem<_Float16> {
-    static constexpr bool kSwap = false;
-    template <int UW>
-    static __device__ __forceinline__ void mma(f32x16 (&acc)[UW], const f32x4& c, const f32x4 (&b)[UW]) {
-        const f16x8 ca = __builtin_bit_cast(f16x8, c);
-#pragma unroll
-        for (int u = 0; u < UW; ++u)
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, __builtin_bit_cast(f16x8, b[u]), acc[u], 0, 0, 0);
-    }
-};
-
-template <int UPW>
-struct WaveLds {
-    float* ls;       // [UPW][K]
-    int* li;         // [UPW][K]
-    int* cnt;        // [UPW]
-    int64_t* rlo;    // [UPW] bounds of each user's rated list (rated_rowptr staged once per wave)
-    int64_t* rhi;    // [UPW]
-    unsigned* rfilter;   // [UPW][8] 256-bit membership filter of the user's rated items in this split's range
-};
-
-template <int UPW>
-__host__ __device__ constexpr size_t wave_lds_bytes(int K) {
-    return (size_t)UPW * K * 8 + (size_t)UPW * 4 + (size_t)UPW * 16 + (size_t)UPW * 32;
-}
-
-template <int UPW>
-__device__ __forceinline__ void wave_lds_carve(WaveLds<UPW>& w, char* base, int K) {
-    w.ls = reinterpret_cast<float*>(base);
-    w.li = reinterpret_cast<int*>(w.ls + UPW * K);
-    w.cnt = w.li + UPW * K;
-    w.rlo = reinterpret_cast<int64_t*>(w.cnt + UPW);
-    w.rhi = w.rlo + UPW;
-    w.rfilter = reinterpret_cast<unsigned*>(w.rhi + UPW);
-}
-
-__device__ __forceinline__ unsigned rated_hash(int gi) { return ((unsigned)gi * 2654435761u) >> 24; }
-
-// Stage the list bounds of this wave's UPW slots and build their membership filters.  A slow-path candidate is tested
-// against the filter first (one LDS word): only a hit (a rated item, or a false positive: 1 - exp(-len/256)) pays the
-// memory round trip of the exact search.  The lists of consecutive slots are one contiguous run of rated_col, read
-// coalesced; ids outside [id0, id1) (other splits, other shards) are left out.
-template <int UPW>
-__device__ __forceinline__ void wave_lds_init(const WaveLds<UPW>& w, const ScoreArgs& a, int64_t slot0, int id0, int id1,
-                                              bool filter, int lane) {
-    for (int j = lane; j < UPW; j += 64) {
-        w.cnt[j] = 0;
-        const int64_t slot = slot0 + j;
-        const bool has = a.rated_rowptr && slot < a.n_users;
-        w.rlo[j] = has ? a.rated_rowptr[slot] : 0;
-        w.rhi[j] = has ? a.rated_rowptr[slot + 1] : 0;
-    }
-    if (a.seed_score) {
-        // seeded lists: copy each slot's prefix top-k into LDS; its fill = the entries before the padding
-        const int K = a.k;
-        for (int j = 0; j < UPW; ++j) {
-            const int64_t slot = slot0 + j;
-            if (slot >= a.n_users) break;                         // wave-uniform
-            int n = 0;
-            for (int e0 = 0; e0 < K; e0 += 64) {
-                const int e = e0 + lane;
-                int gi = CRH_PAD_IDX;
-                if (e < K) {
-                    gi = a.seed_idx[slot * K + e];
-                    w.ls[j * K + e] = a.seed_score[slot * K + e];
-                    w.li[j * K + e] = gi;
-                }
-                n += __popcll(__ballot(gi != CRH_PAD_IDX));
-            }
-            if (lane == 0) w.cnt[j] = n;
-        }
-    }
-    if (!filter || !a.rated_rowptr) return;
-    for (int j = lane; j < UPW * 8; j += 64) w.rfilter[j] = 0u;
-    const int64_t s1 = slot0 + UPW < a.n_users ? slot0 + UPW : a.n_users;
-    const int64_t e0 = a.rated_rowptr[slot0], e1 = a.rated_rowptr[s1];
-    int u = 0;                                   // this lane's position in the slot sequence (entries ascend)
-    for (int64_t base = e0; base < e1; base += 64) {
-        const int64_t e = base + lane;
-        if (e < e1) {
-            const int v = a.rated_col[e];
-            while (e >= w.rhi[u]) ++u;           // rhi of the last real slot is e1: terminates
-            if (v >= id0 && v < id1) {
-                const unsigned hsh = rated_hash(v);
-                atomicOr(&w.rfilter[u * 8 + (hsh >> 5)], 1u << (hsh & 31));
-            }
-        }
-    }
-}
-
-// maximum of the 16 accumulator registers as a depth-3 tree of 3-input maxima (v_max3_f32): the wave waits
-// for this chain between two tiles, and a sequential chain of 15 is ~4x longer
-__device__ __forceinline__ float max16(const f32x16& v) {
-    const float a0 = fmaxf(fmaxf(v[0], v[1]), v[2]), a1 = fmaxf(fmaxf(v[3], v[4]), v[5]);
-    const float a2 = fmaxf(fmaxf(v[6], v[7]), v[8]), a3 = fmaxf(fmaxf(v[9], v[10]), v[11]);
-    const float a4 = fmaxf(fmaxf(v[12], v[13]), v[14]);
-    const float b0 = fmaxf(fmaxf(a0, a1), a2), b1 = fmaxf(fmaxf(a3, a4), v[15]);
-    return fmaxf(b0, b1);
-}
-
-__device__ __forceinline__ float pick16(const f32x16& v, int r) {
-    const bool b0 = r & 1, b1 = r & 2, b2 = r & 4, b3 = r & 8;
-    const float p0 = b0 ? v[1] : v[0], p1 = b0 ? v[3] : v[2], p2 = b0 ? v[5] : v[4], p3 = b0 ? v[7] : v[6];
-    const float p4 = b0 ? v[9] : v[8], p5 = b0 ? v[11] : v[10], p6 = b0 ? v[13] : v[12], p7 = b0 ? v[15] : v[14];
-    const float q0 = b1 ? p1 : p0, q1 = b1 ? p3 : p2, q2 = b1 ? p5 : p4, q3 = b1 ? p7 : p6;
-    const float s0 = b2 ? q1 : q0, s1 = b2 ? q3 : q2;
-    return b3 ? s1 : s0;
-}
-
-// Slow path for one 32x32 accumulator tile (rare).  acc[r] = score of item row
-// (r&3) + 8*(r>>2) + 4*(lane>>5) for user column lane&31.
-// Cost per event is what bounds mid-size catalogues and the fp16 kernel (each event stalls the wave, in the workgroup
-// kernel the whole CU), so memory round trips are kept off it: the candidate-bitmap bits of the tile's 32 items are ONE
-// wave-uniform 64-bit window requested on entry (it lands while the candidate masks are built), bitmap-masked
-// candidates of users whose list is full are dropped before the serial part, and the rated list is only searched when
-// the user's LDS filter says the item may be in it.
-template <int UPW>
-__device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg, const WaveLds<UPW>& w,
-                                               int K, int ucol0, int64_t slot0, const ScoreArgs& a,
-                                               int64_t item0, int64_t split_end, int lane) {
-    const int64_t g0 = a.item_base + item0;          // global id of the tile's first item
-    unsigned blo = 0u, bhi = 0u;
-    if (a.bitmap) {
-        const int64_t last = (a.item_base + a.n_items - 1) >> 5;
-        const int64_t w0 = (g0 >> 5) < last ? (g0 >> 5) : last, w1 = w0 < last ? w0 + 1 : last;
-        blo = a.bitmap[w0];
-        bhi = a.bitmap[w1];
-    }
-    unsigned cm = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
-    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
-    const unsigned tb = (unsigned)(((((unsigned long long)bhi) << 32) | blo) >> (g0 & 31));
-    const unsigned x = tb >> (4 * (lane >> 5));
-    const unsigned m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
-    // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
-    if (tau_reg > CRH_NEG_INF) cm &= ~m16;
-    const unsigned bm = cm & m16;
-    unsigned long long lanes = __ballot(cm != 0u);
-    while (lanes) {
-        const int L = __builtin_ctzll(lanes);
-        lanes &= lanes - 1;
-        unsigned cmL = __builtin_amdgcn_readlane(cm, L);
-        const unsigned bmL = __builtin_amdgcn_readlane(bm, L);
-        const int jl = L & 31, hh = L >> 5;
-        const int64_t slot = slot0 + jl;
-        if (slot >= a.n_users) continue;
-        const int ul = ucol0 + jl;
-        float* lsu = w.ls + ul * K;
-        int* liu = w.li + ul * K;
-        while (cmL) {
-            const int r = __builtin_ctz(cmL);
-            cmL &= cmL - 1;
-            const int64_t il = item0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (il >= split_end) continue;   // clamped duplicate rows of the tail tile
-            // r is wave-uniform: pick the accumulator register with a select tree (static indices only),
-            // then read lane L
-            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
-            const int gi = (int)(a.item_base + il);
-            // one batch of LDS reads: fill, tail entry, filter word
-            const unsigned hsh = rated_hash(gi);
-            const int n_raw = w.cnt[ul];
-            const float ks_raw = lsu[K - 1];
-            const int ki_raw = liu[K - 1];
-            const unsigned fw_raw = a.rated_rowptr ? w.rfilter[ul * 8 + (hsh >> 5)] : 0u;
-            const int n = __builtin_amdgcn_readfirstlane(n_raw);
-            if (n >= K) {
-                const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ks_raw)));
-                const int ki = __builtin_amdgcn_readfirstlane(ki_raw);
-                if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;   // cannot enter a full list
-            }
-            bool masked = (bmL >> r) & 1u;
-            if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u))
-                masked = wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, nullptr, lane);
-            if (masked) sc = CRH_MASKED_SCORE;
-            wave_list_insert(lsu, liu, w.cnt + ul, K, sc, gi, lane);
-        }
-    }
-    const int my = ucol0 + (lane & 31);
-    // a padding column (slot past the block) never takes a candidate: +inf keeps it out of the threshold ballot
-    tau_reg = slot0 + (lane & 31) < a.n_users ? wave_list_tau(w.ls + my * K, w.cnt[my], K) : __builtin_inff();
-}
-
-// Soft lockstep of the waves of one XCD.  Every wave streams the same item tiles, but left alone the waves
-// drift apart (the older wave of a SIMD pair gets ~80 % of the matrix pipe) until their working set no
-// longer fits the XCD's 4 MiB L2: the L2 hit rate drops to ~50 % and every wave's stream goes out to the
-// fabric (5.5 TB per launch at S-EVAL against a 5 GB table; the fp16 build is bound by exactly this).
-// Protocol: a wave adds itself to done[w] when it finishes window w (= sync_window tiles) and does not start
-// window w+2 before every REGISTERED wave of its XCD finished window w.  Only resident waves register, the
-// wait is bounded, and a wave that times out stops synchronising, so this can slow a launch down but never
-// hang or change its result.  All counters of an XCD are touched by that XCD only (one L2: coherent).
-__device__ __forceinline__ bool xcd_window_sync(unsigned* cnt, int64_t win, int lane) {
-    bool ok = true;
-    if (lane == 0) {
-        if (win >= 1) __hip_atomic_fetch_add(cnt + 1 + (win - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (win >= 2) {
-            int spins = 0;
-            while (__hip_atomic_load(cnt + 1 + (win - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                   __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > 200000) { ok = false; break; }      // ~0.2 s: give up, run free
-            }
-        }
-    }
-    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+// Candidate-bitmap bits per 32-item tile of a shard (bit r of word t = bit of global item item_base + 32 t + r): what the DMA
+// kernel streams beside the item tiles (256 bytes per 64 tiles), so that its slow path finds a tile's bits in LDS instead of
+// fetching bitmap words from memory.  Items past the shard's end read as "not masked" (their candidates are dropped anyway).
+__global__ __launch_bounds__(256) void tile_bits_kernel(const uint32_t* __restrict__ bitmap, int64_t item_base, int64_t n_items,
+                                                        int64_t n_tiles, uint32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t g0 = item_base + (t << 5), last = (item_base + n_items - 1) >> 5;
+    const int64_t w0 = (g0 >> 5) < last ? (g0 >> 5) : last, w1 = w0 < last ? w0 + 1 : last;
+    const unsigned long long both = ((unsigned long long)bitmap[w1] << 32) | bitmap[w0];
+    unsigned bits = (unsigned)(both >> (g0 & 31));
+    const int64_t left = n_items - (t << 5);
+    if (left < 32) bits &= (1u << left) - 1u;
+    out[t] = bits;
 }
 
 // OCC = waves per SIMD the kernel is built for:
@@ -567,7 +305,6 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 // registers, two tiles ahead), drops it into a two-slot LDS ring, and all 8 waves read their A fragments from
 // LDS -- 8x less L2 -> CU traffic.  One s_barrier per tile (LDS only: the prefetch loads stay in flight across
 // it).  Users, thresholds, lists and the slow path are per wave exactly as above, so results are identical.
-constexpr int WG_RING = 3;   // item-tile slots in LDS
 
 template <typename T, int D, int UW, int NW, int TT>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArgs a) {
@@ -897,6 +634,7 @@ size_t lists_bytes(int64_t n_users, int k) {   // worst case: 64 splits of (scor
 }
 size_t packed_bytes(int64_t n_items, int d, int esz) { return (size_t)((n_items + 31) / 32) * 32 * (size_t)d * esz; }
 // window counters of the XCD lockstep: 8 XCDs x (1 + one per 8-tile window, the smallest window allowed)
+size_t tbits_bytes(int64_t n_items) { return (((size_t)((n_items + 31) / 32) * sizeof(uint32_t)) + 255) & ~(size_t)255; }
 size_t sync_bytes(int64_t n_items) { return ((size_t)((n_items + 255) / 256 + 2) * 8 * sizeof(unsigned) + 255) & ~(size_t)255; }
 
 int pack_items(int esz, const void* item_emb, int64_t n_items, int d, void* pk, hipStream_t st) {
@@ -1016,6 +754,104 @@ int pick_splits_seeded(int64_t n_units, int64_t n_items, double cap) {
     return best;
 }
 
+// Everything the dispatcher decides about one stage of a call BEFORE it touches the GPU -- shared with crh_score_topk_route,
+// so that a caller (bench.py's kernel labels, tests) asks the library which kernels a shape takes instead of guessing.
+struct RoutePlan {
+    bool dense;        // score block + crh_mask_topk_f32
+    bool use_wg;       // a workgroup kernel (register-staged ring, or the LDS-DMA form when use_dma)
+    bool use_dma;
+    bool can_pack;     // the workspace holds the fragment-ordered copy of the shard
+    int wg_waves_l;    // waves of the workgroup that is launched
+    int wg_slots_l;    // workgroups resident per round
+    int upw;           // users per wave
+    int occ;           // waves per SIMD of the per-wave kernel
+    size_t dense_b;    // bytes of the dense block (0: not applicable)
+    size_t tb_off;     // workspace offset of the tiles' candidate bits (DMA kernel)
+    int no_pack;
+};
+
+RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bool has_workspace, size_t workspace_bytes,
+                     bool has_bitmap, int n_splits, bool seeded) {
+    RoutePlan r;
+    // The workgroup-cooperative kernel (8 waves share the packed item tiles through LDS) once there are enough
+    // user groups to fill the CUs and the workspace holds the packed copy.  fp16: d = 64/128/256, 64 users per
+    // wave.  fp32: d = 128 (64 users per wave; +1.5 % over the per-wave kernel and 1/8 of its L2 -> CU traffic).
+    static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
+    const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;   // per call: tests force 2
+    const bool can_pack = !no_pack && has_workspace &&
+                          workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz);
+    // one 8-wave workgroup per CU when its lists fit the 160 KiB of LDS, else two 4-wave workgroups (large k);
+    // measured at k=20 (fp16): 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two 4-wave groups
+    // 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
+    const size_t ring_b = (size_t)WG_RING * wg_tiles_per_step(d * esz) * (d * esz / 32) * 1024;
+    const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
+    // (Round 4 measured a 128-users-per-wave / one-wave-per-SIMD instantiation of this kernel -- <_Float16, 256, UW = 4, NW = 4>,
+    // 256 VGPRs + 193 AGPRs, one LDS read of an A fragment per four MFMAs: +1.4 % over the shipped form on the same box, and
+    // 0.70x with a second accumulator set that lets the threshold test ride in the next tile's MFMA shadow (B fragments 256 +
+    // accumulators 128 registers: the allocator spills inside the MFMA stream, also with the slow path as a real call):
+    // profiles/r04_f16_variant_ab_*.log, DESIGN.md 4.1.  Not shipped.)
+    const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
+    const int wg_upw = 64;
+    const int wg_slots = wg_waves == 8 ? 256 : 512;                   // workgroups resident per round
+    const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
+    // fp32: the lockstep of 8 waves makes every slow-path event a stall of the whole CU, so the workgroup kernel only
+    // pays on long streams (>= 2 M items: 0.852 vs 0.845 of peak at 2 M, 0.912 vs 0.891 at 10 M; at 262 144 items the
+    // per-wave kernel is 0.705 vs 0.655) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
+    // at 0.33 against 0.60 per wave)
+    const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
+    const bool fp32_wg_ok = n_items >= 2000000 && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
+    const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
+                        (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
+    // 512-byte rows: the LDS-DMA form (four waves of 128 users, score_topk_dma_kernel).  CRH_SCORE_DMA (read per call):
+    // 0 never, 1 fp16 (default), 2 fp32 as well
+    const int dma_mode = getenv("CRH_SCORE_DMA") ? atoi(getenv("CRH_SCORE_DMA")) : 1;
+    const size_t dma_lds = score_dma_lds_bytes(d * esz, k);
+    const size_t tb_off = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);   // the tiles' candidate bits
+    const bool use_dma = use_wg && dma_mode && d * esz == 512 && dma_lds <= 160 * 1024 && (esz == 2 || dma_mode == 2) &&
+                         (!has_bitmap || workspace_bytes >= tb_off + tbits_bytes(n_items));
+    const int wg_waves_l = use_dma ? 4 : wg_waves;                    // waves of the workgroup that is launched
+    const int wg_slots_l = use_dma ? 256 : wg_slots;                  // ... and how many of them are resident per round
+    const int upw = use_dma ? 128 : (use_wg ? wg_upw : users_per_wave(esz, d));
+    // two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured at fp32
+    // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
+    static const int variant = getenv("CRH_SCORE_OCC") ? atoi(getenv("CRH_SCORE_OCC")) : 2;
+    const int occ = esz == 2 ? 2 : ((variant == 2 && d == 128) ? 2 : 1);
+    // Small catalogues (the trainers' per-epoch validation: a few thousand users x a few thousand items).  The fused
+    // selection is built for catalogues where a candidate above the running threshold is rare; here every user takes
+    // ~k (1 + ln(N/k)) candidates through the wave-serial slow path (5 - 8 ms for 5 K users x 4 K items, a single
+    // wave of 64 users being the critical path).  Instead: the same MFMA kernel writes its score tiles to a dense
+    // block (bit-identical scores) and crh_mask_topk_f32 -- one wave per user, same masks, same canonical order --
+    // ranks it; users go in chunks if the block would pass 8 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
+    static const int dense_mode = getenv("CRH_SCORE_DENSE") ? atoi(getenv("CRH_SCORE_DENSE")) : 1;
+    const size_t dense_b = dense_block_bytes(n_users, n_items);
+    r.dense = dense_mode && n_splits == 0 && !seeded && dense_b && has_workspace && workspace_bytes >= dense_b;
+    r.use_wg = use_wg;
+    r.use_dma = use_dma;
+    r.can_pack = can_pack;
+    r.wg_waves_l = wg_waves_l;
+    r.wg_slots_l = wg_slots_l;
+    r.upw = upw;
+    r.occ = occ;
+    r.dense_b = dense_b;
+    r.tb_off = tb_off;
+    r.no_pack = no_pack;
+    return r;
+}
+
+// item-range cut count of a fused stage
+int plan_splits(const RoutePlan& r, int esz, int64_t n_users, int64_t n_items, int k, int n_splits, bool seeded) {
+    const int64_t T = (n_items + 31) / 32;
+    const int64_t n_ug = (n_users + r.upw - 1) / r.upw;
+    int s = n_splits > 0 ? n_splits
+            : seeded     ? pick_splits_seeded(r.use_wg ? (n_ug + r.wg_waves_l - 1) / r.wg_waves_l : n_ug, n_items,
+                                              r.use_wg ? (double)r.wg_slots_l : 1024.0 * r.occ)
+            : r.use_wg   ? pick_splits_wg((n_ug + r.wg_waves_l - 1) / r.wg_waves_l, n_items, k, r.wg_slots_l,
+                                          esz == 2 ? 18750.0 : 5700.0)
+                         : pick_splits(n_ug, n_items, r.occ);
+    if (s > T) s = (int)T;
+    return s;
+}
+
 int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
                     int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
                     const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
@@ -1044,8 +880,12 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     const bool cuts = pick_splits(n_ug, n_items, 2) > 1;
     const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
     const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1999999);
-    if (small_cat && !getenv("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
-    if (!(cuts || small_cat || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
+    // fp16, 512-byte rows (configs[4]): at 16x the fp32 MFMA rate a slow-path event costs as much as a whole tile and, in
+    // the workgroup kernels, stalls the whole CU: 9 % of the launch at 10 M items (profiles/r05_f16_*).  A 4 096-item prefix
+    // takes k (1 + ln(P / k)) of every user's k (1 + ln(N / k)) events out of the stream: 282 -> 156 per user at 10 M items
+    const bool f16_stream = !cuts && esz == 2 && d == 256 && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
+    if ((small_cat || f16_stream) && !getenv("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
+    if (!(cuts || small_cat || f16_stream || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
     return P;
 }
 
@@ -1109,36 +949,11 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     CRH_CHECK_ARG(item_base >= 0 && item_base + n_items < (int64_t)CRH_PAD_IDX, "%s: item ids exceed int32", who);
     CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "%s: n_splits=%d outside 0..64", who, n_splits);
 
-    // The workgroup-cooperative kernel (8 waves share the packed item tiles through LDS) once there are enough
-    // user groups to fill the CUs and the workspace holds the packed copy.  fp16: d = 64/128/256, 64 users per
-    // wave.  fp32: d = 128 (64 users per wave; +1.5 % over the per-wave kernel and 1/8 of its L2 -> CU traffic).
-    static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
-    const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;   // per call: tests force 2
-    const bool can_pack = !no_pack && workspace &&
-                          workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz);
-    // one 8-wave workgroup per CU when its lists fit the 160 KiB of LDS, else two 4-wave workgroups (large k);
-    // measured at k=20 (fp16): 8 waves 50.6 % / 45.7 % of the fp16 peak at d=256 / 128, two 4-wave groups
-    // 46.5 % / 47.4 % (CRH_SCORE_WG=4 forces them)
-    const size_t ring_b = (size_t)WG_RING * wg_tiles_per_step(d * esz) * (d * esz / 32) * 1024;
-    const size_t wg4_lds = ring_b + 4 * wave_lds_bytes<64>(k), wg8_lds = ring_b + 8 * wave_lds_bytes<64>(k);
-    // (Round 4 measured a 128-users-per-wave / one-wave-per-SIMD instantiation of this kernel -- <_Float16, 256, UW = 4, NW = 4>,
-    // 256 VGPRs + 193 AGPRs, one LDS read of an A fragment per four MFMAs: +1.4 % over the shipped form on the same box, and
-    // 0.70x with a second accumulator set that lets the threshold test ride in the next tile's MFMA shadow (B fragments 256 +
-    // accumulators 128 registers: the allocator spills inside the MFMA stream, also with the slow path as a real call):
-    // profiles/r04_f16_variant_ab_*.log, DESIGN.md 4.1.  Not shipped.)
-    const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
-    const int wg_upw = 64;
-    const int wg_slots = wg_waves == 8 ? 256 : 512;                   // workgroups resident per round
-    const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
-    // fp32: the lockstep of 8 waves makes every slow-path event a stall of the whole CU, so the workgroup kernel only
-    // pays on long streams (>= 2 M items: 0.852 vs 0.845 of peak at 2 M, 0.912 vs 0.891 at 10 M; at 262 144 items the
-    // per-wave kernel is 0.705 vs 0.655) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
-    // at 0.33 against 0.60 per wave)
-    const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
-    const bool fp32_wg_ok = n_items >= 2000000 && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
-    const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
-                        (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
-    const int upw = use_wg ? wg_upw : users_per_wave(esz, d);
+    const RoutePlan rp = plan_route(esz, n_users, n_items, d, k, workspace != nullptr, workspace_bytes, cand_bitmap != nullptr,
+                                    n_splits, seed_score != nullptr);
+    const bool use_wg = rp.use_wg, use_dma = rp.use_dma, can_pack = rp.can_pack;
+    const int wg_waves_l = rp.wg_waves_l, upw = rp.upw, occ = rp.occ, no_pack = rp.no_pack;
+    const size_t tb_off = rp.tb_off, dense_b = rp.dense_b;
     ScoreArgs a;
     a.user_emb = user_emb;
     a.users = users;
@@ -1153,10 +968,6 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     a.n_ugroups = (n_users + upw - 1) / upw;
     static const int ablate = CRH_PROFILE_ENV("CRH_SCORE_ABLATE");
     a.ablate = ablate;
-    // two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured at fp32
-    // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
-    static const int variant = getenv("CRH_SCORE_OCC") ? atoi(getenv("CRH_SCORE_OCC")) : 2;
-    const int occ = esz == 2 ? 2 : ((variant == 2 && d == 128) ? 2 : 1);
     a.dense = nullptr;
     a.dense_stride = 0;
     a.user_base = 0;
@@ -1165,15 +976,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     const int64_t T = (n_items + 31) / 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-    // Small catalogues (the trainers' per-epoch validation: a few thousand users x a few thousand items).  The fused
-    // selection is built for catalogues where a candidate above the running threshold is rare; here every user takes
-    // ~k (1 + ln(N/k)) candidates through the wave-serial slow path (5 - 8 ms for 5 K users x 4 K items, a single
-    // wave of 64 users being the critical path).  Instead: the same MFMA kernel writes its score tiles to a dense
-    // block (bit-identical scores) and crh_mask_topk_f32 -- one wave per user, same masks, same canonical order --
-    // ranks it; users go in chunks if the block would pass 8 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
-    static const int dense_mode = getenv("CRH_SCORE_DENSE") ? atoi(getenv("CRH_SCORE_DENSE")) : 1;
-    const size_t dense_b = dense_block_bytes(n_users, n_items);
-    if (dense_mode && n_splits == 0 && !seed_score && dense_b && workspace && workspace_bytes >= dense_b) {
+    if (rp.dense) {   // small catalogues: score block + wave-per-user ranking (see plan_route)
         const int64_t stride = T * 32;
         const int upw_pw = users_per_wave(esz, d);
         int64_t chunk = (int64_t)(dense_b / ((size_t)stride * sizeof(float)));
@@ -1215,13 +1018,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
         return CRH_OK;
     }
 
-    a.n_splits = n_splits > 0 ? n_splits
-                 : seed_score ? pick_splits_seeded(use_wg ? (a.n_ugroups + wg_waves - 1) / wg_waves : a.n_ugroups, n_items,
-                                                   use_wg ? (double)wg_slots : 1024.0 * occ)
-                 : use_wg     ? pick_splits_wg((a.n_ugroups + wg_waves - 1) / wg_waves, n_items, k, wg_slots,
-                                               esz == 2 ? 18750.0 : 5700.0)
-                              : pick_splits(a.n_ugroups, n_items, occ);
-    if (a.n_splits > T) a.n_splits = (int)T;
+    a.n_splits = plan_splits(rp, esz, n_users, n_items, k, n_splits, seed_score != nullptr);
 
     if (a.n_splits == 1) {
         a.out_score = out_score;
@@ -1251,13 +1048,13 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     a.xcd_sync = nullptr;
     a.sync_window = sync_win;
     a.sync_stride = 0;
-    const int64_t n_wg_launch = (a.n_ugroups + wg_waves - 1) / wg_waves;
+    const int64_t n_wg_launch = (a.n_ugroups + wg_waves_l - 1) / wg_waves_l;
     // Item-range cuts under SEEDED lists take part too (per-wave kernel): every cut walks its own range, window by window
     // from its own start, and the cuts' window counts differ by at most one, so no wave ever waits for a window another
     // wave will not report; the L2 of an XCD then holds two windows of each cut instead of the cuts' drifting streams.
     const bool cuts_ok = a.n_splits == 1 || (seed_score && !use_wg && T / a.n_splits >= 4 * sync_win);
     const bool sync_pw = !use_wg && occ == 2 && a.n_ugroups * a.n_splits <= 2048 && a.n_ugroups * a.n_splits > 256;
-    const bool sync_wg = use_wg && n_wg_launch <= wg_slots && n_wg_launch > 8;   // one resident round
+    const bool sync_wg = use_wg && n_wg_launch <= rp.wg_slots_l && n_wg_launch > 8;   // one resident round
     if (sync_win > 0 && (sync_pw || sync_wg) && cuts_ok && a.packed) {
         const int64_t n_win = (T / a.n_splits + 1 + sync_win - 1) / sync_win + 1;
         const size_t need = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);
@@ -1268,6 +1065,13 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
             CRH_HIP(hipMemsetAsync(a.xcd_sync, 0, (size_t)a.sync_stride * 8 * sizeof(unsigned), st));
         }
     }
+    a.tile_bits = reinterpret_cast<const uint32_t*>(a.packed);      // readable filler when there is no candidate bitmap
+    if (use_dma && cand_bitmap) {
+        uint32_t* tb = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + tb_off);
+        hipLaunchKernelGGL(tile_bits_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, cand_bitmap, item_base, n_items, T, tb);
+        CRH_HIP(hipGetLastError());
+        a.tile_bits = tb;
+    }
     a.wave_clock = nullptr;
 #ifdef CRH_PROFILE
     static const int timing = CRH_PROFILE_ENV("CRH_SCORE_TIMING");
@@ -1275,13 +1079,15 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // profile build only
 #endif
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
-    if (esz == 4 && use_wg) {
+    if (use_dma) {
+        rc = launch_score_dma(esz, a, st);
+    } else if (esz == 4 && use_wg) {
         rc = launch_score_wg<float, 128, 2, 8>(a, st);
     } else if (use_wg) {
         switch (d) {
-            case 64: rc = wg_waves == 4 ? launch_score_wg<_Float16, 64, 2, 4>(a, st) : launch_score_wg<_Float16, 64, 2, 8>(a, st); break;
-            case 128: rc = wg_waves == 4 ? launch_score_wg<_Float16, 128, 2, 4>(a, st) : launch_score_wg<_Float16, 128, 2, 8>(a, st); break;
-            default: rc = wg_waves == 4 ? launch_score_wg<_Float16, 256, 2, 4>(a, st) : launch_score_wg<_Float16, 256, 2, 8>(a, st); break;
+            case 64: rc = wg_waves_l == 4 ? launch_score_wg<_Float16, 64, 2, 4>(a, st) : launch_score_wg<_Float16, 64, 2, 8>(a, st); break;
+            case 128: rc = wg_waves_l == 4 ? launch_score_wg<_Float16, 128, 2, 4>(a, st) : launch_score_wg<_Float16, 128, 2, 8>(a, st); break;
+            default: rc = wg_waves_l == 4 ? launch_score_wg<_Float16, 256, 2, 4>(a, st) : launch_score_wg<_Float16, 256, 2, 8>(a, st); break;
         }
     } else {
         rc = launch_score_per_wave(esz, d, occ, a, st);
@@ -1323,7 +1129,7 @@ namespace {
 // seed lists in front plus the prefix's own dense block
 size_t full_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k, int esz, bool dim_ok) {
     if (n_users <= 0 || k <= 0) return 0;
-    const size_t tail = dim_ok && n_items > 0 ? packed_bytes(n_items, d, esz) + sync_bytes(n_items) : 0;
+    const size_t tail = dim_ok && n_items > 0 ? packed_bytes(n_items, d, esz) + sync_bytes(n_items) + tbits_bytes(n_items) : 0;
     size_t need = std::max(lists_bytes(n_users, k), dense_block_bytes(n_users, n_items)) + tail;
     const int64_t P = dim_ok ? seed_route(esz, n_users, n_items, d) : 0;      // only shapes that DO seed pay for the prefix
     if (P > 0)
@@ -1344,6 +1150,46 @@ extern "C" size_t crh_score_topk_f16_workspace_bytes(int64_t n_users, int64_t n_
 extern "C" size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k) {
     if (n_users <= 0 || k <= 0) return 0;
     return lists_bytes(n_users, k);
+}
+
+// Which kernels a crh_score_topk_{f32,f16}[_ex] call of this shape takes: the dispatcher's own predicates (seed_route,
+// plan_route, plan_splits) under the same environment switches, evaluated without touching the GPU.
+extern "C" int crh_score_topk_route(int elem_bytes, int64_t n_users, int64_t n_items, int d, int k, size_t workspace_bytes,
+                                    int has_bitmap, int n_splits, int64_t* prefix_items, int* picked_splits) {
+    CRH_CHECK_ARG(elem_bytes == 4 || elem_bytes == 2, "crh_score_topk_route: elem_bytes=%d (4 = fp32 tables, 2 = fp16)", elem_bytes);
+    CRH_CHECK_ARG(n_users > 0 && n_items > 0 && k >= 1 && k <= CRH_MAX_K, "crh_score_topk_route: empty block or k outside 1..%d",
+                  CRH_MAX_K);
+    CRH_CHECK_ARG(elem_bytes == 4 ? crh_score_topk_supports_dim(d) : crh_score_topk_f16_supports_dim(d),
+                  "crh_score_topk_route: d=%d unsupported", d);
+    CRH_CHECK_ARG(n_splits >= 0 && n_splits <= 64, "crh_score_topk_route: n_splits=%d outside 0..64", n_splits);
+    const bool has_ws = workspace_bytes > 0;
+    int64_t P = n_splits == 0 && has_ws ? seed_route(elem_bytes, n_users, n_items, d) : 0;
+    size_t ws = workspace_bytes;
+    if (P > 0) {    // the seeded route needs room for the seeds in front of either stage (score_topk_any)
+        const size_t sb = seed_bytes(n_users, k);
+        const size_t stage1 = dense_block_bytes(n_users, P) + packed_bytes(P, d, elem_bytes);
+        const size_t stage2 = lists_bytes(n_users, k) + packed_bytes(n_items - P, d, elem_bytes);
+        if (workspace_bytes >= sb + std::max(stage1, stage2)) ws = workspace_bytes - sb;
+        else P = 0;
+    }
+    const int64_t n_main = n_items - P;
+    const RoutePlan r = plan_route(elem_bytes, n_users, n_main, d, k, has_ws, ws, has_bitmap != 0, n_splits, P > 0);
+    int route = r.dense ? CRH_ROUTE_DENSE : (r.use_dma ? CRH_ROUTE_FUSED_DMA : (r.use_wg ? CRH_ROUTE_FUSED_WG : CRH_ROUTE_FUSED_WAVE));
+    if (P > 0) route |= CRH_ROUTE_SEEDED;
+    if (prefix_items) *prefix_items = P;
+    if (picked_splits) *picked_splits = r.dense ? 1 : plan_splits(r, elem_bytes, n_users, n_main, k, n_splits, P > 0);
+    return route;
+}
+
+// the scoring kernel of a route as rocprofv3 prints it (prefix of the demangled name)
+extern "C" const char* crh_score_topk_route_kernel(int route) {
+    switch (route & 15) {
+        case CRH_ROUTE_DENSE: return "score_topk_kernel";          // + mask_topk_kernel over the score block
+        case CRH_ROUTE_FUSED_WAVE: return "score_topk_kernel";
+        case CRH_ROUTE_FUSED_WG: return "score_topk_wg_kernel";
+        case CRH_ROUTE_FUSED_DMA: return "score_topk_dma_kernel";
+        default: return "";
+    }
 }
 
 extern "C" int crh_score_topk_f32_ex(const float* user_emb, const int32_t* users, int64_t n_users,

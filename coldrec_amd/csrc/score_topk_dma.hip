@@ -1,0 +1,436 @@
+// LDS-DMA form of the fused scoring + top-k workgroup kernel (see the comment on the kernel).  Its own translation unit
+// because it is built with -mllvm -amdgpu-mfma-vgpr-form (Makefile): one wave per SIMD owns all 512 registers, the
+// accumulators must stay in VGPRs (the threshold test reads them) while the user fragments fill the 256 AGPRs; without
+// the flag hipcc puts a one-wave-per-SIMD kernel's accumulators into AGPRs and copies half of the user fragments around.
+#include <type_traits>
+#include <utility>
+
+#include "score_topk_common.h"
+
+namespace crh_score {
+namespace {
+
+constexpr int DMA_RING = 4;         // item-tile slots in LDS
+constexpr int DMA_NW = 4;           // waves per workgroup (one per SIMD)
+constexpr int DMA_UPW = 128;        // users per wave
+constexpr int TBITS_B = 2 * 64 * 4; // two blocks of 64 tiles' candidate bits
+
+// per-wave LDS of the DMA kernel: the lists (scores, ids, fill) and a 192-bit membership filter of each user's rated list.
+// The rated-list bounds are read from memory when a candidate's filter says "maybe rated" (rare).  k = 20: 188 bytes per user,
+// 94 KiB per workgroup beside the 64 KiB ring.
+constexpr int DMA_FW = 6;           // filter words per user
+__host__ __device__ constexpr size_t dma_wave_lds_bytes(int K) {
+    return (size_t)DMA_UPW * K * 8 + (size_t)DMA_UPW * 4 + (size_t)DMA_UPW * DMA_FW * 4;
+}
+__device__ __forceinline__ unsigned rated_hash192(int gi) { return ((((unsigned)gi * 2654435761u) >> 16) * (32u * DMA_FW)) >> 16; }
+
+// Slow path of one 32x32 accumulator tile, as tile_slow_path (score_topk_common.h) with every memory round trip of the
+// common case removed: the candidate-bitmap bits of the tile come out of LDS (tb: the tile's 32 bits, fetched by DMA with
+// the tile stream, see tile_bits_kernel), the membership filter out of LDS; only a filter hit goes to memory (list
+// bounds + search).  While one wave is in here the other three wait at the next barrier, and a memory wait in here would
+// also wait for the tile DMAs in flight.
+__device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau_reg, float* ls, int* li, int* cnt, int K,
+                                                   int ucol0, int64_t slot0, const ScoreArgs& a, int64_t item0,
+                                                   int64_t split_end, int lane, unsigned tb, const unsigned* rfilter) {
+    unsigned cm = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
+    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
+    const unsigned x = tb >> (4 * (lane >> 5));
+    const unsigned m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
+    // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
+    if (tau_reg > CRH_NEG_INF) cm &= ~m16;
+    const unsigned bm = cm & m16;
+    unsigned long long lanes = __ballot(cm != 0u);
+    while (lanes) {
+        const int L = __builtin_ctzll(lanes);
+        lanes &= lanes - 1;
+        unsigned cmL = __builtin_amdgcn_readlane(cm, L);
+        const unsigned bmL = __builtin_amdgcn_readlane(bm, L);
+        const int jl = L & 31, hh = L >> 5;
+        const int64_t slot = slot0 + jl;
+        if (slot >= a.n_users) continue;
+        const int ul = ucol0 + jl;
+        float* lsu = ls + ul * K;
+        int* liu = li + ul * K;
+        while (cmL) {
+            const int r = __builtin_ctz(cmL);
+            cmL &= cmL - 1;
+            const int64_t il = item0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (il >= split_end) continue;   // clamped duplicate rows of the tail tile
+            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
+            const int gi = (int)(a.item_base + il);
+            // one batch of LDS reads: fill, tail entry, filter word
+            const unsigned hsh = rated_hash192(gi);
+            const int n_raw = cnt[ul];
+            const float ks_raw = lsu[K - 1];
+            const int ki_raw = liu[K - 1];
+            const unsigned fw_raw = a.rated_rowptr ? rfilter[ul * DMA_FW + (hsh >> 5)] : 0u;
+            const int n = __builtin_amdgcn_readfirstlane(n_raw);
+            if (n >= K) {
+                const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ks_raw)));
+                const int ki = __builtin_amdgcn_readfirstlane(ki_raw);
+                if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;   // cannot enter a full list
+            }
+            bool masked = (bmL >> r) & 1u;
+            if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u)) {
+                const int64_t lo = a.rated_rowptr[slot], hi = a.rated_rowptr[slot + 1];
+                masked = wave_is_masked_at(gi, lo, hi, a.rated_col, nullptr, lane);
+            }
+            if (masked) sc = CRH_MASKED_SCORE;
+            wave_list_insert(lsu, liu, cnt + ul, K, sc, gi, lane);
+        }
+    }
+    const int my = ucol0 + (lane & 31);
+    // a padding column (slot past the block) never takes a candidate: +inf keeps it out of the threshold ballot
+    tau_reg = slot0 + (lane & 31) < a.n_users ? wave_list_tau(ls + my * K, cnt[my], K) : __builtin_inff();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA form of the workgroup kernel for 512-byte rows (fp16 d=256: configs[4]; fp32 d=128: the headline).
+// What changes against score_topk_wg_kernel, and why (profiles/r04_z_f16_ceiling.json: two thirds of the matrix
+// pipe's cycles were MFMA, the rest ring commits, the per-tile barrier and the threshold test at the end of a tile):
+//   * the item stream reaches LDS by DMA (global_load_lds, 16 B per lane, 1 KiB per instruction): no staging
+//     registers, no ds_write pass; FOUR ring slots, the fill of a tile is issued two tiles before the barrier that
+//     publishes it (one tile of slack measured 7 % slower: the first workgroup of an XCD to ask for a tile waits for the
+//     fabric, and the lockstep makes everybody wait with it);
+//   * FOUR waves (one per SIMD) of 128 users each instead of eight of 64: an A fragment read from LDS feeds four
+//     MFMAs instead of two (half the LDS traffic per flop; the chip is power-limited on fp16 operands).  The B
+//     fragments of 128 users are 256 registers: they live in the ACCUMULATOR half of the unified register file
+//     (an empty asm with an "a" constraint pins them there; gfx950 MFMAs take A/B operands from AGPRs), the two
+//     accumulator SETS, the A fragments and everything else in the 256 VGPRs;
+//   * two accumulator sets: the threshold test of tile j-1 (and, rarely, its slow path) is issued between the
+//     MFMAs of tile j, so the pipe no longer drains at every tile boundary;
+//   * ONE workgroup barrier per tile, in the MIDDLE of the tile's MFMA stream: it publishes tile j+1 (every wave
+//     waited for its own DMA pieces first) and frees the slot of tile j-1 for the DMA of tile j+3.  A fragment
+//     prefetches run across the tile boundary, so no LDS latency is exposed anywhere in the steady state;
+//   * the slow path touches no memory in the common case (tile_slow_path_dma): the tiles' candidate bits ride the DMA
+//     stream (64 tiles per 256-byte piece); the rated-list bounds left the LDS and the membership filters shrank to 192
+//     bits, which makes room for the fourth ring slot at k <= 20.
+// Users, thresholds and lists are per wave exactly as in the other kernels: results are identical.
+// The loop runs n_steps + 1 bodies: body j multiplies tile j (the last one a clamped duplicate nobody selects) and
+// selects tile j - 1.
+template <typename T, int D>
+__global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
+    constexpr int NW = DMA_NW, UW = 4, UPW = DMA_UPW;
+    constexpr int ROWB = D * (int)sizeof(T);
+    constexpr int NCH = ROWB / 32;
+    constexpr int TILE_B = NCH * 1024;
+    constexpr int CPW = NCH / NW;                      // 1 KiB DMA pieces of a tile each wave issues
+    constexpr int GR = 2, NG = NCH / GR;               // A fragments are read in groups of GR chunks, one group ahead
+    constexpr int BG = NG / 2 - 1;                     // the group in front of which the ring barrier sits
+    static_assert(NCH % NW == 0 && NG % 4 == 0 && BG + 2 < NG, "row width not supported by the DMA kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int S = a.n_splits;
+    const int split = (int)(blockIdx.x % S);
+    const int64_t ug_raw = (int64_t)(blockIdx.x / S) * NW + wave;
+    const bool live = ug_raw < a.n_ugroups;            // a dead wave still fetches and synchronises
+    const int64_t ug = live ? ug_raw : a.n_ugroups - 1;
+    const int K = a.k;
+    const int i = lane & 31, h = lane >> 5;
+
+    char* ring = smem;                                  // [DMA_RING][TILE_B]
+    unsigned* tbits = reinterpret_cast<unsigned*>(smem + DMA_RING * TILE_B);   // [2][64]
+    const int64_t NT = (a.n_items + 31) >> 5;
+    const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
+    const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
+    const int64_t slot0w = ug * UPW;
+
+    // ---- this wave's lists
+    char* wl = smem + DMA_RING * TILE_B + TBITS_B + (size_t)wave * dma_wave_lds_bytes(K);
+    float* ls = reinterpret_cast<float*>(wl);           // [UPW][K]
+    int* li = reinterpret_cast<int*>(ls + UPW * K);      // [UPW][K]
+    int* cnt = li + UPW * K;                            // [UPW]
+    for (int j = lane; j < UPW; j += 64) cnt[j] = 0;
+    if (a.seed_score) {
+        // seeded lists: copy each slot's prefix top-k into LDS; its fill = the entries before the padding
+        for (int j = 0; j < UPW; ++j) {
+            const int64_t slot = slot0w + j;
+            if (slot >= a.n_users) break;                         // wave-uniform
+            int n = 0;
+            for (int e0 = 0; e0 < K; e0 += 64) {
+                const int e = e0 + lane;
+                int gi = CRH_PAD_IDX;
+                if (e < K) {
+                    gi = a.seed_idx[slot * K + e];
+                    ls[j * K + e] = a.seed_score[slot * K + e];
+                    li[j * K + e] = gi;
+                }
+                n += __popcll(__ballot(gi != CRH_PAD_IDX));
+            }
+            if (lane == 0) cnt[j] = n;
+        }
+    }
+    // ---- membership filters of the rated lists (192 bits per user, ids of this split's range only)
+    unsigned* rfilter = reinterpret_cast<unsigned*>(cnt + UPW);      // [UPW][DMA_FW]
+    for (int j = lane; j < UPW * DMA_FW; j += 64) rfilter[j] = 0u;
+    if (live && a.rated_rowptr) {
+        const int id0 = (int)(a.item_base + (t0 << 5)), id1 = (int)(a.item_base + split_end);
+        const int64_t s1 = slot0w + UPW < a.n_users ? slot0w + UPW : a.n_users;
+        const int64_t e0 = a.rated_rowptr[slot0w], e1 = a.rated_rowptr[s1];
+        int64_t nxt = a.rated_rowptr[slot0w + 1];   // end of the list of this lane's current user
+        int u = 0;
+        for (int64_t base = e0; base < e1; base += 64) {
+            const int64_t e = base + lane;
+            if (e < e1) {
+                const int v = a.rated_col[e];
+                while (e >= nxt) { ++u; nxt = a.rated_rowptr[slot0w + u + 1]; }      // entries ascend: terminates at e1
+                if (v >= id0 && v < id1) {
+                    const unsigned hsh = rated_hash192(v);
+                    atomicOr(&rfilter[u * DMA_FW + (hsh >> 5)], 1u << (hsh & 31));
+                }
+            }
+        }
+    }
+
+    f32x4 b[NCH][UW];
+    float tau[UW];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+        int64_t slot = slot0w + 32 * u + i;
+        tau[u] = slot < a.n_users ? CRH_NEG_INF : __builtin_inff();      // padding columns never take a candidate
+        if (a.seed_score && slot < a.n_users) tau[u] = wave_list_tau(ls + (32 * u + i) * K, cnt[32 * u + i], K);
+        if (slot >= a.n_users) slot = a.n_users - 1;
+        const int64_t row = a.users ? (int64_t)a.users[slot] : a.user_base + slot;
+        const char* up = reinterpret_cast<const char*>(a.user_emb) + row * ROWB + 16 * h;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            b[q][u] = load16(up + 32 * q);
+            if constexpr (Elem<T>::kSwap) chunk_swap(b[q][u]);
+        }
+    }
+    // the user fragments live in AGPRs from here on (and have landed: nothing of theirs is left on the VM counter)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+        for (int u = 0; u < UW; ++u) asm volatile("" : "+a"(b[q][u]));
+#endif
+
+    const char* packed = reinterpret_cast<const char*>(a.packed);
+    const int64_t n_steps = t1 - t0;
+    // this wave's pieces of step j -> ring slot.  Steps past the split (the extra body, the prefetch distance) read clamped
+    // tiles: valid addresses, data nobody selects.
+    // One global pointer per lane and ONE LDS base per slot serve the wave's CPW pieces: the instruction's immediate offset
+    // moves both addresses (LDS address = M0 + offset + 16 * lane).
+    const char* my_pieces = packed + (wave * CPW) * 1024 + lane * 16;
+    const int n_tiles32 = (int)NT;                     // item ids are int32, so tiles fit easily
+    auto dma_tile = [&](int64_t j, int slot) __attribute__((always_inline)) {
+        int t = (int)t0 + (int)j;
+        t = t < n_tiles32 ? t : n_tiles32 - 1;
+        if (CRH_ABLATE(a.ablate) & 2) t = 0;   // measurement only: every fetch hits the same (cached) tile
+        const char* g = my_pieces + (int64_t)t * TILE_B;
+        char* l = ring + slot * TILE_B + (wave * CPW) * 1024;
+#define CRH_DMA_PIECE(CQ)                                                                                              \
+    if constexpr (CQ < CPW)                                                                                            \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,                             \
+                                         (__attribute__((address_space(3))) void*)l, 16, (CQ) * 1024, 0)
+        CRH_DMA_PIECE(0); CRH_DMA_PIECE(1); CRH_DMA_PIECE(2); CRH_DMA_PIECE(3);
+#undef CRH_DMA_PIECE
+        static_assert(CPW <= 4, "pieces beyond the immediate offset range");
+    };
+    // candidate bits of the 64 tiles of block blk (tile >> 6) -> tbits[blk & 1].  Issued by EVERY wave with EVERY tile (a
+    // 256-byte piece; the waves write identical bytes): no branch inside the MFMA stream, one more DMA on everybody's counter
+    auto dma_tbits = [&](int64_t blk) __attribute__((always_inline)) {
+        int t = ((int)blk << 6) + lane;
+        t = t < n_tiles32 ? t : n_tiles32 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.tile_bits + (unsigned)t),
+                                         (__attribute__((address_space(3))) void*)(tbits + (blk & 1) * 64), 4, 0, 0);
+    };
+    const bool has_bits = a.bitmap != nullptr;          // without a candidate bitmap tile_bits points at readable filler
+    auto dma_wait_all = [&]() __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    };
+    auto dma_wait_but_newest_tile = [&]() __attribute__((always_inline)) {   // everything but the CPW + 1 pieces issued last
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CPW + 1) : "memory");
+#endif
+    };
+
+    f32x16 acc[2][UW];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int u = 0; u < UW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][u][r] = 0.0f;
+    // A fragments: LDS -> registers by inline asm with COUNTED waits.  Left to hipcc the loop gets "s_waitcnt lgkmcnt(0)" right
+    // behind the reads of the NEXT group (seen in the ISA: every second group stalls for a full LDS round trip).  The asm reads
+    // are invisible to the compiler's counter bookkeeping; lds_wait names the registers it guards, so no MFMA that consumes
+    // them can be scheduled above it (cdna_hip_programming.md 5.7: form (ii)).  LDS operations complete in order, so
+    // lgkmcnt(2 GR) = "everything but the 2 GR reads issued last has landed" also covers any list access of the slow path.
+    f32x4 c[4][GR];
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + lane * 16;
+    auto lds_group = [&](f32x4(&dst)[GR], uint32_t addr, auto Gc) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(addr), "i"((decltype(Gc)::value * GR + 0) * 1024));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(addr), "i"((decltype(Gc)::value * GR + 1) * 1024));
+#endif
+    };
+    auto lds_wait = [&](f32x4(&x)[GR], auto Nc) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "i"(decltype(Nc)::value));
+#endif
+    };
+    static_assert(GR == 2, "lds_group / lds_wait are written for two chunks per group");
+
+    // body j: MFMAs of tile j (ring slot s_cur) into accumulator set P, threshold test of tile j-1 out of set 1-P;
+    // s_nxt = slot of tile j+1, s_fill = slot tile j-1 left = slot of tile j+3
+    auto body = [&](auto Pc, int64_t j, int s_cur, int s_nxt, int s_fill) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value, Q = 1 - P;
+        const uint32_t src = ring_lds + s_cur * TILE_B, srcn = ring_lds + s_nxt * TILE_B;
+        float m[UW];
+        // one group of GR chunks; g is a compile-time constant (every register array below is indexed statically)
+        auto group = [&](auto Gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gc)::value;
+            // fragments of the group after next (two groups = 16 MFMAs of slack for the LDS round trip); the last two groups
+            // of a tile read the first two of tile j+1, visible since this body's barrier
+            if constexpr (g + 2 < NG) lds_group(c[(g + 2) & 3], src, std::integral_constant<int, g + 2>{});
+            else lds_group(c[(g + 2) & 3], srcn, std::integral_constant<int, g + 2 - NG>{});
+            if constexpr (g == BG) {
+                dma_wait_but_newest_tile();             // my pieces of tile j+1 (issued two tiles ago) have landed
+                if (!(CRH_ABLATE(a.ablate) & 4)) __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait(c[g & 3], std::integral_constant<int, 2 * GR>{});   // this group's fragments (read two groups ago) are in
+            // tile j+3 into the slot tile j-1 left (every wave is past it); the scheduler places the DMA instructions
+            // BETWEEN this group's MFMAs (they follow the wait in program order).  With it the candidate bits of the block
+            // of 64 tiles that holds tile j + 32: the current block again (same bytes) in its first half, the NEXT block in
+            // its second half -- into the buffer of the block before, whose last tile was selected at the head of body
+            // 64 b, before every wave's barrier of that body
+            if constexpr (g == BG) {
+                dma_tbits((t0 + j + 32) >> 6);
+                dma_tile(j + 3, s_fill);
+            }
+#pragma unroll
+            for (int jj = 0; jj < GR; ++jj) {
+                if constexpr (g == 0) {
+                    if (jj == 0) {
+#pragma unroll
+                        for (int u = 0; u < UW; ++u)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[P][u][r] = 0.0f;
+                    }
+                }
+                Elem<T>::template mma<UW>(acc[P], c[g & 3][jj], b[g * GR + jj]);
+            }
+            if constexpr (g == 1) {
+#pragma unroll
+                for (int u = 0; u < UW; ++u) m[u] = max16(acc[Q][u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g == 1) {
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < UW; ++u) hit = hit || (m[u] > tau[u]);
+                if (__ballot(hit) != 0ull && live && j > 0 && !(CRH_ABLATE(a.ablate) & 1)) {
+                    const int64_t ts = t0 + j - 1;                                      // the tile being selected
+                    const unsigned tb = has_bits ? tbits[((ts >> 6) & 1) * 64 + (ts & 63)] : 0u;
+#pragma unroll
+                    for (int u = 0; u < UW; ++u)
+                        if (__ballot(m[u] > tau[u]) != 0ull)
+                            tile_slow_path_dma(acc[Q][u], tau[u], ls, li, cnt, K, 32 * u, slot0w + 32 * u, a, ts << 5,
+                                               split_end, lane, tb, rfilter);
+                    // the list stores of the inserts are drained HERE: left pending, the compiler parks an lgkmcnt(0) at a
+                    // later point of the common path, right behind the fragment reads of the barrier group
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                }
+            }
+        };
+        [&]<int... Gs>(std::integer_sequence<int, Gs...>) __attribute__((always_inline)) {
+            (group(std::integral_constant<int, Gs>{}), ...);
+        }(std::make_integer_sequence<int, NG>{});
+    };
+
+    if (n_steps > 0) {
+        dma_tbits(t0 >> 6);
+        dma_tbits((t0 >> 6) + 1);
+        dma_tile(0, 0);
+        dma_tile(1, 1);
+        dma_tile(2, 2);
+        dma_wait_all();
+        __builtin_amdgcn_s_barrier();
+        lds_group(c[0], ring_lds, std::integral_constant<int, 0>{});
+        lds_group(c[1], ring_lds, std::integral_constant<int, 1>{});
+        int s0 = 0;
+        // XCD soft lockstep (see xcd_window_sync): wave 0 reports / waits for the workgroup, the others meet it at the
+        // tile's barrier
+        unsigned* sync_cnt = nullptr;
+        int64_t win_steps = 0, next_sync = n_steps + 4;
+        if (a.xcd_sync && wave == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
+            sync_cnt = a.xcd_sync + (int64_t)xcc * a.sync_stride;
+            if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            win_steps = a.sync_window & ~(int64_t)1;      // whole loop trips (two bodies each)
+            if (win_steps < 2) win_steps = 2;
+            next_sync = 0;
+        }
+        for (int64_t j = 0; j <= n_steps; j += 2) {
+            if (j >= next_sync && j < n_steps) {       // wave 0 only (next_sync stays beyond the range elsewhere)
+                const int64_t win = j / win_steps;
+                if (xcd_window_sync(sync_cnt, win, lane)) {
+                    next_sync += win_steps;
+                } else {                // timed out: run free, and count this workgroup into every window it will not report
+                    next_sync = n_steps + 4;
+                    const int64_t n_win = (n_steps + win_steps - 1) / win_steps;
+                    if (lane == 0)
+                        for (int64_t wdw = win; wdw < n_win; ++wdw)
+                            __hip_atomic_fetch_add(sync_cnt + 1 + wdw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const int s1 = (s0 + 1) & 3, s2 = (s0 + 2) & 3, s3 = (s0 + 3) & 3;
+            body(std::integral_constant<int, 0>{}, j, s0, s1, s3);          // tile j+3 -> slot of tile j-1 = s0 - 1 = s3
+            if (j + 1 > n_steps) break;
+            body(std::integral_constant<int, 1>{}, j + 1, s1, s2, s0);      // tile j+4 -> slot of tile j
+            s0 = s2;
+        }
+        dma_wait_all();   // the prefetches of the last bodies must not outlive the workgroup's LDS ...
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[2][0]), "+v"(c[2][1]),
+                     "+v"(c[3][0]), "+v"(c[3][1]));   // ... nor the last fragment reads their registers
+#endif
+    }
+
+    if (live) {
+        for (int j = 0; j < UPW; ++j) {
+            const int64_t slot = slot0w + j;
+            if (slot >= a.n_users) break;
+            const int n = __builtin_amdgcn_readfirstlane(cnt[j]);
+            const int64_t o = ((int64_t)split * a.n_users + slot) * K;
+            if (a.seed_score && S > 1)
+                wave_list_store_range(ls + j * K, li + j * K, n, K, a.out_score + o, a.out_idx + o, lane,
+                                      split == 0 ? INT32_MIN : (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end));
+            else
+                wave_list_store(ls + j * K, li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
+        }
+    }
+}
+
+template <typename T, int D>
+int launch_score_dma_t(const ScoreArgs& a, hipStream_t stream) {
+    const size_t lds = score_dma_lds_bytes(D * (int)sizeof(T), a.k);
+    auto kern = score_topk_dma_kernel<T, D>;
+    CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    const int64_t blocks = ((a.n_ugroups + DMA_NW - 1) / DMA_NW) * a.n_splits;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * DMA_NW), lds, stream, a);
+    CRH_HIP(hipGetLastError());
+    return CRH_OK;
+}
+
+}  // namespace
+
+size_t score_dma_lds_bytes(int row_bytes, int k) {
+    return (size_t)DMA_RING * (row_bytes / 32) * 1024 + TBITS_B + DMA_NW * dma_wave_lds_bytes(k);
+}
+
+int launch_score_dma(int esz, const ScoreArgs& a, hipStream_t stream) {
+    return esz == 4 ? launch_score_dma_t<float, 128>(a, stream) : launch_score_dma_t<_Float16, 256>(a, stream);
+}
+
+}  // namespace crh_score

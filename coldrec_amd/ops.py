@@ -122,6 +122,29 @@ def score_topk(user_emb: torch.Tensor, users: Optional[torch.Tensor], item_emb: 
     return out
 
 
+ROUTE_NAMES = {1: "dense", 2: "fused-wave", 3: "fused-wg", 4: "fused-dma"}
+
+
+def score_topk_route(n_users: int, n_items: int, d: int, k: int, half: bool = False, has_bitmap: bool = True,
+                     n_splits: int = 0, pack: bool = True) -> dict:
+    """Which kernels ``score_topk`` runs for a block of this shape: the library's own answer (crh_score_topk_route evaluates
+    the dispatcher's predicates under the current environment switches; no GPU needed), with the workspace ``score_topk``
+    would pass.  ``{"route", "seeded", "prefix_items", "n_splits", "kernel", "code"}``; ``kernel`` is the scoring kernel's
+    name as rocprofv3 prints it."""
+    import ctypes
+    L = _lib.lib()
+    d = d if d % 8 == 0 and (L.crh_score_topk_f16_supports_dim(d) if half else L.crh_score_topk_supports_dim(d)) else \
+        next(w for w in (8, 16, 32, 64, 128, 256) if w >= d and (w >= 16 or not half))
+    full = L.crh_score_topk_f16_workspace_bytes if half else L.crh_score_topk_workspace_bytes
+    ws_bytes = full(n_users, n_items, d, k) if pack else L.crh_score_topk_min_workspace_bytes(n_users, k)
+    prefix, splits = ctypes.c_int64(0), ctypes.c_int(0)
+    code = L.crh_score_topk_route(2 if half else 4, n_users, n_items, d, k, ws_bytes, 1 if has_bitmap else 0, n_splits,
+                                  ctypes.byref(prefix), ctypes.byref(splits))
+    _lib.check(code if code < 0 else 0, "crh_score_topk_route")
+    return {"route": ROUTE_NAMES[code & 15], "seeded": bool(code & 16), "prefix_items": int(prefix.value),
+            "n_splits": int(splits.value), "kernel": L.crh_score_topk_route_kernel(code).decode(), "code": int(code)}
+
+
 def mask_topk(scores: torch.Tensor, k: int, rated_rowptr=None, rated_col=None, cand_bitmap=None,
               item_base: int = 0, write_back: bool = True):
     """Masks + top-k over a dense (n_users, n_items) fp32 block (model/BaseRecommender.py:175-183)."""
@@ -511,7 +534,7 @@ class SpmmSchedule:
         rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
         rp = rp.astype(np.int64)
         self._rp, self._col, self._val, self._device, self._slabs = rp, col, val, device, {}
-        self._bound, self._sums = {}, None
+        self._bound, self._baked = {}, None
         deg = np.diff(rp)
         if seg is None:
             # heavy threshold: crh_spmm_segment_edges() (64) for sparse graphs; for dense ones (MovieLens shape: mean
@@ -578,6 +601,11 @@ class SpmmSchedule:
         n_pairs = int(start[-1]) + 2 * G                                   # tail: a one-unit record's second-unit read
         col = self._col.cpu().numpy() if torch.is_tensor(self._col) else np.asarray(self._col)
         val = self._val.cpu().numpy() if torch.is_tensor(self._val) else np.asarray(self._val)
+        # what exactly is being baked in: version counters of the source tensors and two checksums of the host copies taken
+        # NOW (a later in-place ``val.mul_(c)`` must not pass for "the same edges" because the pointer is the same)
+        self._baked = (self._col._version if torch.is_tensor(self._col) else None,
+                       self._val._version if torch.is_tensor(self._val) else None, len(col), int(col.astype(np.int64).sum()),
+                       int(np.ascontiguousarray(val, np.float32).view(np.int32).astype(np.int64).sum()))
         stream = np.zeros((n_pairs, 2), np.uint32)
         stream[start[:-1], 0] = rows.astype(np.uint32)
         stream[start[:-1], 1] = deg.astype(np.uint32)
@@ -602,20 +630,27 @@ class SpmmSchedule:
         key = (col.data_ptr(), val.data_ptr(), col.numel(), col._version, val._version)
         ok = self._bound.get(key)
         if ok is None:
-            if torch.is_tensor(self._col) and torch.is_tensor(self._val) and self._col.data_ptr() == col.data_ptr() \
-                    and self._val.data_ptr() == val.data_ptr() and self._col.numel() == col.numel():
-                ok = True
+            baked = getattr(self, "_baked", None)
+            if baked is None:
+                return False                                  # no stream was built: nothing to vouch for
+            same_tensors = torch.is_tensor(self._col) and torch.is_tensor(self._val) and self._col.data_ptr() == col.data_ptr() \
+                and self._val.data_ptr() == val.data_ptr() and self._col.numel() == col.numel()
+            if same_tensors and (col._version, val._version) == baked[:2]:
+                ok = True                                     # the very tensors the stream was baked from, untouched since
             elif col.is_cuda and torch.cuda.is_current_stream_capturing():
+                if not getattr(self, "_warned_capture", False):
+                    self._warned_capture = True
+                    import warnings
+                    warnings.warn("SpmmSchedule: an edge-array pair met inside a stream capture has not been checked against the "
+                                  "record stream; this launch (and the captured graph) takes the slower descriptor path -- bind the "
+                                  "pair once eagerly (sched.for_launch(n, d, col, val)) before capturing")
                 return False                                  # not cached: an eager launch decides
-            else:
-                if self._sums is None:
-                    hc = self._col.cpu().numpy() if torch.is_tensor(self._col) else np.asarray(self._col)
-                    hv = self._val.cpu().numpy() if torch.is_tensor(self._val) else np.asarray(self._val)
-                    self._sums = (len(hc), int(hc.astype(np.int64).sum()),
-                                  int(np.ascontiguousarray(hv, np.float32).view(np.int32).astype(np.int64).sum()))
-                ok = (col.numel() == self._sums[0] and val.numel() == self._sums[0]
-                      and int(col.sum(dtype=torch.int64)) == self._sums[1]
-                      and int(val.view(torch.int32).sum(dtype=torch.int64)) == self._sums[2])
+            else:                                             # checksums of the launch's arrays against the BAKE-TIME sums
+                ok = (col.numel() == baked[2] and val.numel() == baked[2]
+                      and int(col.sum(dtype=torch.int64)) == baked[3]
+                      and int(val.view(torch.int32).sum(dtype=torch.int64)) == baked[4])
+            if len(self._bound) >= 64:                        # fresh ``val`` tensors every step must not grow this without bound
+                self._bound.clear()
             self._bound[key] = ok
         return ok
 

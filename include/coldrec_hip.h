@@ -67,6 +67,26 @@ int crh_score_topk_supports_dim(int d);
  */
 size_t crh_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int d, int k);
 size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k);
+
+/* Which kernels a crh_score_topk_{f32,f16}[_ex] call of this shape takes, answered by the dispatcher's own code (the same
+ * predicates and environment switches, no GPU work): the library reports its route, callers do not re-derive it.
+ *   elem_bytes 4 (fp32 tables) | 2 (fp16);  workspace_bytes as it will be passed (0 = no workspace);  has_bitmap: a
+ *   candidate bitmap will be passed;  n_splits as in the _ex calls (0 = library's choice).
+ * Returns the route of the stage that walks the catalogue -- CRH_ROUTE_DENSE (score block + crh_mask_topk_f32),
+ * CRH_ROUTE_FUSED_WAVE (one wave per user group), CRH_ROUTE_FUSED_WG (8-wave workgroups, register-staged LDS ring),
+ * CRH_ROUTE_FUSED_DMA (4-wave workgroups fed by LDS-DMA) -- OR-ed with CRH_ROUTE_SEEDED when a catalogue prefix is ranked
+ * first and seeds the lists; < 0 on bad arguments.  prefix_items / picked_splits (either may be NULL) receive the prefix
+ * length (0: not seeded) and the item-range cut count of the main stage.
+ * There is no counterpart in the reference (model/BaseRecommender.py:172-183 is one matmul + topk whatever the shape). */
+#define CRH_ROUTE_DENSE 1
+#define CRH_ROUTE_FUSED_WAVE 2
+#define CRH_ROUTE_FUSED_WG 3
+#define CRH_ROUTE_FUSED_DMA 4
+#define CRH_ROUTE_SEEDED 16
+int crh_score_topk_route(int elem_bytes, int64_t n_users, int64_t n_items, int d, int k, size_t workspace_bytes,
+                         int has_bitmap, int n_splits, int64_t* prefix_items, int* picked_splits);
+/* kernel-name prefix of a route's scoring kernel as rocprofv3 prints it ("score_topk_dma_kernel", ...) */
+const char* crh_score_topk_route_kernel(int route);
 int crh_score_topk_f32(const float* user_emb, const int32_t* users, int64_t n_users,
                        const float* item_emb, int64_t n_items, int d,
                        const int64_t* rated_rowptr, const int32_t* rated_col,

@@ -32,6 +32,8 @@ Fixtures (ids refer to SURVEY.md section 8(c)):
                    MovieLens / CiteULike shapes
   g13_eval_100k.npz  model/BaseRecommender.py:109-188  _evaluate for 512 users x 100 000 items, d=128, all / warm / cold:
                    the reference's top-20 ids and scores (tables and split regenerated from seeds on the other side)
+  g16_*            cold_object=user through run() (MF toy + CiteULike shape, DropoutNet with user content) and main.py --runs 2
+  g17_ngcf.npz     model/NGCF.py:15-104  NGCF.run() on the toy split: a second consumer of the SpMM / BPR / ranking hooks
   g8_lists.npz / g9_lists.npz  model/BaseRecommender.py:153-188  the final top-20 lists of the g8 / g9 runs (re-run,
                    tables asserted equal to the stored ones) with the eval inputs needed to re-derive rank margins
 """
@@ -584,12 +586,18 @@ def g12_real_size(which):
     import io
     import time
     shape, cls_name, layers, seed = {"mf": ("movielens", "MF", 0, 1), "lgcn": ("citeulike", "LightGCN", 3, 2),
-                                     "mf64run": ("movielens", "MF", 0, 1), "lgcnrun": ("citeulike", "LightGCN", 3, 2)}[which]
-    split = make_dataset(shape, "item", seed=seed, with_content=False)
+                                     "mf64run": ("movielens", "MF", 0, 1), "lgcnrun": ("citeulike", "LightGCN", 3, 2),
+                                     # G16: cold_object=user through run() -- no candidate mask in _evaluate
+                                     # (model/BaseRecommender.py:130-143), cold USERS ranked over the whole catalogue
+                                     "mfuserrun": ("citeulike", "MF", 0, 2), "mfusertoyrun": ("toy", "MF", 0, 2),
+                                     "lgcnuserrun": ("citeulike", "LightGCN", 3, 2)}[which]
+    cold_object = "user" if "user" in which else "item"
+    split = make_dataset(shape, cold_object, seed=seed, with_content=False)
     data = ref_builder(split)
-    d, B, epochs = (64 if which == "mf64run" else 128), 4096, 2
+    d, B, epochs = (64 if which in ("mf64run", "mfusertoyrun") else 128), (512 if shape == "toy" else 4096), (3 if shape == "toy" else 2)
     whole_run = which.endswith("run")       # through run(): + the three tests.  mf64run = BASELINE configs[0]: BPR-MF, cold_object=item, d=64 through run(): + the three tests
-    cfg = ref_config(data, dataset=shape, model=cls_name, layers=layers or 2, emb_size=d, epochs=epochs, bs=B)
+    cfg = ref_config(data, dataset=shape, model=cls_name, layers=layers or 2, emb_size=d, epochs=epochs, bs=B,
+                     cold_object=cold_object)
     set_seed(2024, False)
     mod = importlib.import_module("model." + cls_name)
     trainer = getattr(mod, cls_name)(cfg)
@@ -669,7 +677,18 @@ def g12_real_size(which):
     if layers:
         res.update(final_out_U=fin_U[rows_u], final_out_V=fin_V[rows_v],
                    final_out_norm=np.array([np.linalg.norm(fin_U.astype(np.float64)), np.linalg.norm(fin_V.astype(np.float64))]))
-    np.savez_compressed(out("g12_%s_real_size.npz" % which), **res)
+    if cold_object == "user":
+        lists = _final_lists(trainer, data)
+        res.update(cold_object="user")
+        if shape == "toy":
+            res.update(lists)                       # small: the lists themselves
+        else:                                       # real size: their checksums + the first 64 users of each setting
+            for t in ("all", "cold", "warm"):
+                res.update({f"{t}_idx_crc": _crc(lists[f"{t}_idx"].astype(np.int32)), f"{t}_n_users": len(lists[f"{t}_users_int"]),
+                            f"{t}_idx_head": lists[f"{t}_idx"][:64].astype(np.int32), f"{t}_score_head": lists[f"{t}_score"][:64]})
+        np.savez_compressed(out("g16_%s.npz" % which), **res)
+    else:
+        np.savez_compressed(out("g12_%s_real_size.npz" % which), **res)
     print("g12 %s: %d steps of the reference in %.1f s; last losses bpr %.6f l2 %.3e; best %s"
           % (which, len(rec["bpr"]), secs, rec["bpr"][-1], rec["l2"][-1], trainer.bestPerformance))
 
@@ -804,7 +823,205 @@ def g15_dropoutnet_real_size():
           % (secs, len(loss_lines), loss_lines[-1] if loss_lines else None, trainer.bestPerformance))
 
 
+def g16_dropoutnet_user():
+    """the reference's DropoutNet with cold_object=user (model/DropoutNet.py:82-93,110-134: the USER tower takes
+    the content, user rows are the ones dropped out) through run() on the CiteULike-shaped user-cold split with its 300-wide
+    user content, d=128, batches of 1024, two epochs.  Recorded exactly like G15."""
+    import contextlib
+    import io
+    import tempfile
+    from model.DropoutNet import DropoutNet  # noqa: E402  (reference)
+    split = make_dataset("citeulike", "user", seed=2, with_content=True)
+    data = ref_builder(split)
+    U, V = g15_backbone(data.user_num, data.item_num)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "emb"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(U)), os.path.join(tmp, "emb", "citeulike_cold_user_MF_user_emb.pt"))
+        torch.save(torch.nn.Parameter(torch.from_numpy(V)), os.path.join(tmp, "emb", "citeulike_cold_user_MF_item_emb.pt"))
+        os.chdir(tmp)
+        try:
+            cfg = ref_config(data, dataset="citeulike", model="DropoutNet", emb_size=128, epochs=2, bs=1024, n_dropout=0.5,
+                             dropoutnet_hidden1=200, dropoutnet_hidden2=100, cold_object="user")
+            set_seed(2024, False)
+            trainer = DropoutNet(cfg)
+            buf = io.StringIO()
+            every = []
+            real_mse = torch.nn.functional.mse_loss
+
+            def mse_spy(*a, **kw):
+                r = real_mse(*a, **kw)
+                every.append(float(r.item()))
+                return r
+
+            torch.nn.functional.mse_loss = mse_spy
+            with contextlib.redirect_stdout(buf):
+                trainer.run()
+        finally:
+            torch.nn.functional.mse_loss = real_mse
+            os.chdir(cwd)
+    gu, gv = trainer.user_emb.detach().numpy(), trainer.item_emb.detach().numpy()
+    rows_u = np.sort(np.random.default_rng(12).choice(gu.shape[0], 256, replace=False))
+    rows_v = np.sort(np.random.default_rng(13).choice(gv.shape[0], 256, replace=False))
+    np.savez_compressed(
+        out("g16_dropoutnet_user.npz"), data_seed=2, d=128, batch_size=1024, epochs=2, every_loss=np.array(every, np.float64),
+        backbone_crc=_crc(U, V), user_num=data.user_num, item_num=data.item_num, n_train=len(data.training_data),
+        epochs_ran=trainer.epochs_ran, best_epoch=trainer.bestPerformance[0], best_metrics=json.dumps(trainer.bestPerformance[1]),
+        test_overall=np.array(trainer.overall_test_results, np.float64), test_cold=np.array(trainer.cold_test_results, np.float64),
+        test_warm=np.array(trainer.warm_test_results, np.float64),
+        norm=np.array([np.linalg.norm(gu.astype(np.float64)), np.linalg.norm(gv.astype(np.float64))]),
+        rows_u=rows_u, rows_v=rows_v, gen_U=gu[rows_u], gen_V=gv[rows_v], scale=np.array([np.abs(gu).max(), np.abs(gv).max()]),
+        torch_version=torch.__version__)
+    print("g16 dropoutnet user: %d batch losses, last %.6f; best %s; overall %s"
+          % (len(every), every[-1], trainer.bestPerformance, trainer.overall_test_results))
+
+
+def g16_runs2():
+    """``python main.py --runs 2`` of the reference ITSELF (main.py:149-301 executed by runpy: Config from the
+    CSV files our generator wrote, seed = round index, the data object -- and with it the cumulatively shuffled training_data --
+    shared by both rounds, mean / std aggregation, one result block).  ``model`` is the bare namespace package of this
+    script; its registry is filled with the reference's own classes (model/__init__.py would import faiss).
+    Stored: every round's test metrics, the aggregated payload, the result block without its timestamp / timing lines, and the
+    checksum of every round's FIRST batch of triples + of all its triples (model.MF.next_batch_pairwise wrapped)."""
+    import contextlib
+    import io
+    import runpy
+    import tempfile
+    import model.MF as mf_mod
+    from coldrec_amd.data.synth import write_dataset
+    sys.modules["model"].AVAILABLE_MODELS = {"MF": MF, "LightGCN": LightGCN}
+    split = make_dataset("toy", "item", seed=1)
+    rec = dict(first=[], allcrc=[], n_batches=[])
+    real_next = mf_mod.next_batch_pairwise
+
+    def next_spy(*a, **kw):
+        first = True
+        for bu, bi, bj in real_next(*a, **kw):
+            c = _crc(np.array(bu, np.int32), np.array(bi, np.int32), np.array(bj, np.int32))
+            if first and rec["_new_round"]:
+                rec["first"].append(c)
+                rec["allcrc"].append(0)
+                rec["n_batches"].append(0)
+                rec["_new_round"] = False
+            first = False
+            rec["allcrc"][-1] = c ^ (rec["allcrc"][-1] * 31 & 0xFFFFFFFF)
+            rec["n_batches"][-1] += 1
+            yield bu, bi, bj
+
+    real_run = MF.run
+
+    def run_spy(self):
+        rec["_new_round"] = True
+        return real_run(self)
+
+    cwd, argv = os.getcwd(), sys.argv
+    with tempfile.TemporaryDirectory() as tmp:
+        write_dataset(split, os.path.join(tmp, "data"), "toy")
+        os.chdir(tmp)
+        sys.argv = ["main.py", "--dataset", "toy", "--model", "MF", "--runs", "2", "--epochs", "3", "--bs", "512", "--emb_size",
+                    "64", "--use_gpu", "false", "--save_emb", "false", "--cold_object", "item", "--result_file",
+                    os.path.join(tmp, "res.txt"), "--result_overwrite"]
+        mf_mod.next_batch_pairwise, MF.run = next_spy, run_spy
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                g = runpy.run_path(os.path.join(REF, "main.py"), run_name="__main__")
+        finally:
+            mf_mod.next_batch_pairwise, MF.run = real_next, real_run
+            os.chdir(cwd)
+            sys.argv = argv
+        block = open(os.path.join(tmp, "res.txt"), encoding="utf-8").read()
+    keep = [ln for ln in block.split("--- JSON")[0].splitlines()
+            if not ln.startswith(("timestamp:", "seconds_per_completed", "result_file:"))]
+    res = g["results"]
+    per_run = np.array([[[res[s][m][i] for m in ("hit", "precision", "recall", "ndcg")] for i in range(len(g["top_Ns"]))]
+                        for s in ("all", "cold", "warm")], np.float64)           # [setting][topN][metric][run]
+    json.dump(dict(argv=["--dataset", "toy", "--model", "MF", "--runs", "2", "--epochs", "3", "--bs", "512", "--emb_size", "64",
+                         "--cold_object", "item"],
+                   per_run=per_run.tolist(), metrics=g["metrics_payload"], block_lines=keep,
+                   first_batch_crc=rec["first"], all_triples_crc=rec["allcrc"], n_batches=rec["n_batches"],
+                   console_tail=[ln for ln in buf.getvalue().splitlines() if "±" in ln or ln.startswith(("Top-", "Start round"))]),
+              open(out("g16_runs2.json"), "w"), indent=1, ensure_ascii=False)
+    print("g16 runs2: per-run NDCG@20 overall", per_run[0, -1, 3].tolist(), "first-batch crcs", rec["first"])
+
+
+def g17_ngcf(split):
+    """VERDICT r4 #4 -- SURVEY.md 8(f)4 pinned to the reference NUMERICALLY: the reference's own NGCF.run()
+    (model/NGCF.py:15-104: torch.sparse.mm over the normalised adjacency + two dense layers per hop + leaky_relu, bpr_loss +
+    l2_reg_loss, Adam over tables AND weights, stock batch_predict) on the toy split, L=2, d=64, 3 epochs of 8 batches.
+    Stored: the initial state_dict (tables from the xavier stream, the four nn.Linear from kaiming), every batch's two loss
+    terms, the propagated tables' norms after every epoch, the weights' norms at the end, best epoch + validation metrics,
+    the three test settings' metrics and 64 sampled rows of the final (best-epoch) tables."""
+    import contextlib
+    import importlib
+    import io
+    mod = importlib.import_module("model.NGCF")
+    data = ref_builder(split)
+    cfg = ref_config(data, model="NGCF", layers=2, emb_size=64, epochs=3, bs=512)
+    set_seed(2024, False)
+    trainer = mod.NGCF(cfg)
+    init = {k: v.detach().clone().numpy() for k, v in trainer.model.state_dict().items() if k != "norm_adj"}
+    rec = dict(bpr=[], l2=[], crc=0, sizes=[], epoch_norm=[])
+    real_bpr, real_l2, real_next = mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise
+    real_fast = mod.NGCF.fast_evaluation
+
+    def bpr_spy(*a):
+        r = real_bpr(*a)
+        rec["bpr"].append(float(r.item()))
+        return r
+
+    def l2_spy(*a):
+        r = real_l2(*a)
+        rec["l2"].append(float(r.item()))
+        return r
+
+    def next_spy(*a, **kw):
+        for bu, bi, bj in real_next(*a, **kw):
+            rec["crc"] = _crc(np.array(bu, np.int32), np.array(bi, np.int32), np.array(bj, np.int32)) ^ (rec["crc"] * 31 & 0xFFFFFFFF)
+            rec["sizes"].append(len(bu))
+            yield bu, bi, bj
+
+    def fast_spy(self, *a, **kw):
+        rec["epoch_norm"].append([float(torch.linalg.norm(self.user_emb.double())), float(torch.linalg.norm(self.item_emb.double()))])
+        return real_fast(self, *a, **kw)
+
+    mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise, mod.NGCF.fast_evaluation = bpr_spy, l2_spy, next_spy, fast_spy
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            trainer.run()
+    finally:
+        mod.bpr_loss, mod.l2_reg_loss, mod.next_batch_pairwise, mod.NGCF.fast_evaluation = real_bpr, real_l2, real_next, real_fast
+    fin = {k: v.detach().numpy() for k, v in trainer.model.state_dict().items() if k != "norm_adj"}
+    U, V = trainer.user_emb.detach().numpy(), trainer.item_emb.detach().numpy()
+    rows_u = np.sort(np.random.default_rng(12).choice(U.shape[0], 64, replace=False))
+    rows_v = np.sort(np.random.default_rng(13).choice(V.shape[0], 64, replace=False))
+    res = {"init__" + k: v for k, v in init.items()}
+    res.update(layers=2, d=64, batch_size=512, epochs=3, lr=cfg.args.lr, reg=cfg.args.reg, seed=2024, triples_crc=rec["crc"],
+               sizes=np.array(rec["sizes"], np.int32), bpr=np.array(rec["bpr"], np.float64), l2=np.array(rec["l2"], np.float64),
+               epoch_norm=np.array(rec["epoch_norm"], np.float64),
+               final_param_norm=np.array([np.linalg.norm(fin[k].astype(np.float64)) for k in sorted(fin)]),
+               param_names=json.dumps(sorted(fin)), best_epoch=trainer.bestPerformance[0],
+               best_metrics=json.dumps(trainer.bestPerformance[1]), epochs_ran=trainer.epochs_ran,
+               test_overall=np.array(trainer.overall_test_results, np.float64), test_cold=np.array(trainer.cold_test_results, np.float64),
+               test_warm=np.array(trainer.warm_test_results, np.float64), rows_u=rows_u, rows_v=rows_v, final_U=U[rows_u],
+               final_V=V[rows_v], final_norm=np.array([np.linalg.norm(U.astype(np.float64)), np.linalg.norm(V.astype(np.float64))]),
+               torch_version=torch.__version__)
+    np.savez_compressed(out("g17_ngcf.npz"), **res)
+    print("g17 ngcf: %d batches, last bpr %.6f l2 %.3e; best %s; overall %s" % (len(rec["bpr"]), rec["bpr"][-1], rec["l2"][-1],
+                                                                           trainer.bestPerformance, trainer.overall_test_results))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g17":
+        g17_ngcf(make_dataset("toy", "item", seed=1))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g16":
+        for which in ("mfusertoyrun", "mfuserrun"):
+            g12_real_size(which)
+        g16_dropoutnet_user()
+        g16_runs2()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g15":
         g15_dropoutnet_real_size()
         return
@@ -859,6 +1076,11 @@ def main():
     g13_eval_100k()
     g14_graph_real_size()
     g15_dropoutnet_real_size()
+    for which in ("mfusertoyrun", "mfuserrun"):
+        g12_real_size(which)
+    g16_dropoutnet_user()
+    g16_runs2()
+    g17_ngcf(split_i)
     total = sum(os.path.getsize(out(f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden vectors written, %.1f KiB" % (total / 1024))
 

@@ -64,3 +64,31 @@ def test_ops_refuse_cpu_tensors():
     from coldrec_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.score_topk(torch.zeros(4, 8), None, torch.zeros(9, 8), 2)
+
+
+def test_the_library_reports_its_route():
+    """bench.py and the profiles name the kernel the LIBRARY says a shape takes (crh_score_topk_route = the
+    dispatcher's own predicates), instead of re-deriving the dispatcher in Python.  Pinned here, on the CPU: the shapes of the
+    bench line."""
+    from coldrec_amd import ops
+    head = ops.score_topk_route(131072, 10_000_000, 128, 20)                 # the headline: 8-wave workgroups through the LDS ring
+    assert head["route"] == "fused-wg" and not head["seeded"] and head["kernel"] == "score_topk_wg_kernel" and head["n_splits"] == 1
+    shard = ops.score_topk_route(131072, 1_250_000, 128, 20)                 # one rank's shard of the 8-GPU split: below the
+    assert shard["route"] == "fused-wave" and shard["seeded"]                # 2 M-item gate -> per-wave kernel, seeded (4 096-item prefix)
+    assert shard["prefix_items"] == 4096 and shard["kernel"] == "score_topk_kernel"
+    assert shard["code"] != head["code"]
+    f16 = ops.score_topk_route(131072, 50_000_000, 256, 20, half=True)       # configs[4]: the LDS-DMA workgroup kernel
+    assert f16["route"] == "fused-dma" and f16["kernel"] == "score_topk_dma_kernel" and not f16["seeded"]
+    f16_shard = ops.score_topk_route(131072, 6_250_000, 256, 20, half=True)
+    assert f16_shard["route"] == "fused-dma"
+    assert ops.score_topk_route(131072, 50_000_000, 256, 21, half=True)["route"] == "fused-wg"   # k > 20: the lists leave no room for 4 slots
+    assert ops.score_topk_route(131072, 50_000_000, 256, 50, half=True)["route"] == "fused-wave"  # ... k = 50: nor for a workgroup's lists
+    val = ops.score_topk_route(6040, 3706, 128, 20)                          # a trainer's validation block: dense block + ranking
+    assert val["route"] == "dense" and val["n_splits"] == 1
+    mid = ops.score_topk_route(8192, 262144, 128, 20)
+    assert mid["seeded"] and mid["prefix_items"] == 32768 and mid["route"] == "fused-wave" and mid["n_splits"] > 1
+    # a caller that withholds the packed copy stays on the per-wave row-major kernel; a caller that names a split count is not seeded
+    assert ops.score_topk_route(131072, 10_000_000, 128, 20, pack=False)["route"] == "fused-wave"
+    assert not ops.score_topk_route(8192, 262144, 128, 20, n_splits=4)["seeded"]
+    L = _lib.lib()
+    assert L.crh_score_topk_route(3, 10, 10, 128, 20, 0, 0, 0, None, None) == -1 and b"elem_bytes" in L.crh_last_error()

@@ -25,7 +25,8 @@ RTOL = 1e-5                       # north_star: "within 1e-5 relative for BPR lo
 def real_size_data(g):
     from coldrec_amd.data.synth import make_dataset
     from coldrec_amd.util.databuilder import ColdStartDataBuilder
-    split = make_dataset(str(g["shape"]), "item", seed=int(g["data_seed"]), with_content=False)
+    cold_object = str(g["cold_object"]) if "cold_object" in g else "item"          # G16 fixtures are user-cold splits
+    split = make_dataset(str(g["shape"]), cold_object, seed=int(g["data_seed"]), with_content=False)
     info = split.info
     data = ColdStartDataBuilder(split.warm_train, split.warm_val, split.cold_val, split.overall_val, split.warm_test,
                                 split.cold_test, split.overall_test, info["user_num"], info["item_num"], info["warm_user"],
@@ -37,7 +38,8 @@ def real_size_data(g):
 def _cfg(data, g, **kw):
     a = dict(dataset=str(g["shape"]), model="MF", epochs=int(g["epochs"]), layers=int(g["layers"]) or 2, topN="10,20",
              bs=int(g["batch_size"]), emb_size=int(g["d"]), lr=float(g["lr"]), reg=float(g["reg"]), runs=1, seed=2024,
-             use_gpu=True, save_emb=False, gpu_id=0, cold_object="item", backbone="MF", early_stop=10, eval_every=1)
+             use_gpu=True, save_emb=False, gpu_id=0, cold_object=str(g["cold_object"]) if "cold_object" in g else "item",
+             backbone="MF", early_stop=10, eval_every=1)
     a.update(kw)
     return types.SimpleNamespace(args=argparse.Namespace(**a), data=data, device=DEV)
 

@@ -38,6 +38,48 @@ def test_matches_reference_stream_golden_g1():
     assert np.array_equal(np.random.randint(0, 1 << 30, size=4), g1["rng_tail"])
 
 
+def test_two_runs_share_the_shuffled_training_list_g16():
+    """``--runs 2`` of the reference's main.py (main.py:160-205; tests/golden/g16_runs2.json was written by main.py itself):
+    round r is seeded with r and BOTH rounds sample from the one data object, so round 2 shuffles the training list as round
+    1 left it (util/utils.py:125 shuffles in place).  One PairwiseSampler reseeded between the rounds -- what
+    coldrec_amd.main does through set_seed -- must reproduce the checksum of each round's first batch and of all its batches."""
+    import json
+    import zlib
+    from tests.conftest import GOLDEN
+    g16 = json.load(open(os.path.join(GOLDEN, "g16_runs2.json")))
+    g, ru, ri = _toy()
+    s = PairwiseSampler(ru, ri, int(g["user_num"]), len(g["item_keys"]))
+    B, epochs = 512, 3
+
+    def crc3(a, b, c):
+        x = 0
+        for arr in (a, b, c):
+            x = zlib.crc32(np.ascontiguousarray(arr, dtype=np.int32).tobytes(), x)
+        return x
+
+    first, every, counts = [], [], []
+    for rnd in range(2):
+        s.seed(rnd)
+        acc, n = 0, 0
+        for _ in range(epochs):
+            u, i, j = s.epoch(B)
+            for lo in range(0, len(u), B):
+                c = crc3(u[lo:lo + B], i[lo:lo + B], j[lo:lo + B])
+                if n == 0:
+                    first.append(c)
+                acc = c ^ (acc * 31 & 0xFFFFFFFF)
+                n += 1
+        every.append(acc)
+        counts.append(n)
+    assert counts == g16["n_batches"]
+    assert first == g16["first_batch_crc"] and every == g16["all_triples_crc"]
+    # a FRESH sampler seeded with 1 gives a different first batch: the carried-over order is what the fixture pins
+    t = PairwiseSampler(ru, ri, int(g["user_num"]), len(g["item_keys"]))
+    t.seed(1)
+    u, i, j = t.epoch(B)
+    assert crc3(u[:B], i[:B], j[:B]) != g16["first_batch_crc"][1]
+
+
 @pytest.mark.parametrize("seed,bs", [(0, 7), (2024, 4096), (123456789, 100), (4294967295, 333)])
 def test_matches_numpy_oracle_other_seeds(seed, bs):
     g, ru, ri = _toy()

@@ -396,10 +396,11 @@ def test_xcd_lockstep_launch_is_exact():
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
 
 
-@pytest.mark.parametrize("d,n_splits", [(256, 1), (128, 0), (128, 1), (128, 3), (64, 1), (64, 3)])
+@pytest.mark.parametrize("d,n_splits", [(256, 1), (256, 0), (256, 3), (128, 0), (128, 1), (128, 3), (64, 1), (64, 3)])
 def test_f16_workgroup_kernel_is_exact(d, n_splits):
-    """>= 512 groups of 64 users: fp16 launches use the workgroup-cooperative kernel (8 waves share the item tiles
-    through an LDS ring).  The helper demands bit-identity with the per-wave row-major kernel; sampled users are
+    """>= 512 groups of 64 users: fp16 launches use the workgroup-cooperative kernels (d = 256: four waves of 128 users
+    fed by LDS-DMA, score_topk_dma.hip; narrower rows: 8 waves share the item tiles through a register-staged LDS
+    ring).  The helper demands bit-identity with the per-wave row-major kernel; sampled users are
     checked against the canonical oracle on exact-arithmetic tables (odd sizes: dead waves, clamped tail tile)."""
     rng = np.random.default_rng(d)
     n_users, n_items, k = 32768 + 77, 5003, 20
@@ -415,6 +416,52 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
     sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
     ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, bm)
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype,n_items,n_splits,k", [("f16", 200_003, 1, 20), ("f16", 200_003, 0, 20), ("f16", 70_001, 2, 50),
+                                                     ("f32", 200_003, 1, 20), ("f32", 70_001, 3, 20)])
+def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits, k, monkeypatch):
+    """The LDS-DMA workgroup kernel (512-byte rows: fp16 d=256 by default, fp32 d=128 with CRH_SCORE_DMA=2) against the
+    register-staged ring kernel (CRH_SCORE_DMA=0) on thousands of tiles with continuous embeddings: every list of every
+    user bit-identical (a tile read before its DMA landed, or overwritten while a slower wave still reads it, shows up
+    here), plus sampled users against the oracle."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(n_items + n_splits)
+    n_users, d = 32768 + 77, (256 if dtype == "f16" else 128)
+    npdt = np.float16 if dtype == "f16" else np.float32
+    U = (rng.standard_normal((n_users, d)) * 0.3).astype(npdt)
+    V = (rng.standard_normal((n_items, d)) * 0.3).astype(npdt)
+    rated = [np.unique(rng.integers(0, n_items, 6)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    cold = np.where(rng.random(n_items) < 0.2)[0]
+    dev = _dev()
+    tU, tV = torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev)
+    srp, src = orc.sort_rated(rowptr, col)
+    rp, rc = torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev)
+    bm = ops.make_bitmap(n_items, cold, dev)
+    monkeypatch.setenv("CRH_SCORE_WG", "2")
+    monkeypatch.setenv("CRH_SCORE_DMA", "2")
+    s1, i1 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
+    monkeypatch.setenv("CRH_SCORE_DMA", "0")
+    s0, i0 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i0) and torch.equal(s1.view(torch.int32), s0.view(torch.int32))
+    pick = np.concatenate([rng.choice(n_users, 28, replace=False), [0, n_users - 1, 32767, 32768]])
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    if dtype == "f32":
+        ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, cold)
+        assert np.array_equal(i1.cpu().numpy()[pick], wi)
+        assert np.array_equal(s1.cpu().numpy()[pick].view(np.uint32), ws.view(np.uint32))
+    else:   # fp16 tables: fp32 accumulation order is the MFMA's own; sets equal up to near-ties, scores to 1e-3 of fp64
+        S = U[pick].astype(np.float64) @ V.astype(np.float64).T
+        got_s, got_i = s1.cpu().numpy()[pick], i1.cpu().numpy()[pick]
+        for r in range(len(pick)):
+            ok = got_i[r] != 0x7FFFFFFF
+            raw = S[r, got_i[r][ok]]
+            masked = np.isin(got_i[r][ok], cold) | np.isin(got_i[r][ok], rated[pick[r]])
+            assert np.allclose(got_s[r][ok][~masked], raw[~masked], rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("n_splits,n_items", [(1, 5003), (0, 5003), (1, 200_003)])

@@ -371,6 +371,26 @@ def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, 
     np.testing.assert_allclose(Ys.cpu().numpy()[~light], want2[~light], rtol=1e-5, atol=4e-4)
     vl.mul_(1.0)                                                        # an in-place write bumps the version: re-checked, same sums
     assert bool(slab.for_launch(n, d, cl, vl).slab) == (G == 8)
+    # the same hole with the schedule built FROM DEVICE TENSORS (LGCNEngine.from_device, xl_spmm_probe): rescaling
+    # ``val`` in place after the stream was baked keeps pointer and length, so only the version counter / the bake-time
+    # checksums can tell -- the launch must take the descriptor path and every row must follow the live values
+    cl_d, vl_d = cl.clone(), vl.clone()
+    dev_sched = ops.SpmmSchedule(rowptr, DEV, col=cl_d, val=vl_d)
+    if G == 8:
+        assert dev_sched.for_launch(n, d, cl_d, vl_d).slab                 # untouched since the bake: pointer fast path
+        vl_d.mul_(3.0)
+        assert not dev_sched.for_launch(n, d, cl_d, vl_d).slab             # same pointers, other contents
+        Yd = torch.empty_like(tX)
+        ops.spmm_csr(rp, cl_d, vl_d, tX, y=Yd, sched=dev_sched)
+        want3 = orc.spmm(rowptr, col, (val * np.float32(3.0)).astype(np.float32), X)
+        np.testing.assert_array_equal(Yd.cpu().numpy()[light], want3[light])
+        np.testing.assert_allclose(Yd.cpu().numpy()[~light], want3[~light], rtol=1e-5, atol=6e-4)
+        vl_d.mul_(1.0 / 3.0)                                               # (x 3 / 3 is not the identity in fp32 for every value:
+        same = torch.equal(vl_d, vl)                                       #  whatever it gave, the stream is used iff the bits are back)
+        assert bool(dev_sched.for_launch(n, d, cl_d, vl_d).slab) == same
+        for _ in range(200):                                               # fresh value tensors every step: the cache stays bounded
+            dev_sched.for_launch(n, d, cl_d, vl_d.clone())
+        assert len(dev_sched._bound) <= 64
     # a schedule built for another struct layout is refused by name, not decoded
     slab.c.version = 3
     with pytest.raises(RuntimeError, match="version"):
