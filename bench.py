@@ -393,7 +393,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
                         per wall second over ``e2e_epochs`` epochs (the reference's timing point, main.py:179-187,
                         without the validation pass)."""
     from coldrec_amd.data.synth import make_dataset
-    from coldrec_amd.sampler import DevicePrefetcher, DeviceSampler, EpochPrefetcher, PairwiseSampler
+    from coldrec_amd.sampler import EpochPrefetcher, PairwiseSampler
     from coldrec_amd.train import EpochRunner, LGCNEngine, MFEngine
     from coldrec_amd.ops import mf_step_parts as ops_parts
     from coldrec_amd import ops as _ops
@@ -452,8 +452,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         t_plans = time.perf_counter() - t0
         # ---- end to end: sampler + prefetch + upload + plans + steps, as model/MF.py's epoch loop runs them
         np.random.seed(2024)
-        use_dev = os.environ.get("CRH_SAMPLER_DEVICE", "0") == "1"
-        pref = DevicePrefetcher(smp, DeviceSampler(ru, ri, n_u, n_i, dev), B) if use_dev else EpochPrefetcher(smp, B, device=dev)
+        pref = EpochPrefetcher(smp, B, device=dev)
         for _ in range(3):                                            # warm: speculation running, worker core at speed
             runner.run(*pref.get())
         torch.cuda.synchronize()
@@ -481,7 +480,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
                                       "d=%d, B=%d, %s" % (2 if layers else 1, "LightGCN L=3" if layers else "BPR-MF",
                                                           shape, n_u, n_i, n, d, B,
                                                           "plain SGD (torch.optim.SGD defaults)" if optim == "sgd" else "dense Adam")},
-               "sampler": "device (csrc/sampler_dev.hip, side stream)" if use_dev else "host (csrc/sampler.hip, persistent worker thread, pinned async upload)",
+               "sampler": "host (csrc/sampler.hip, persistent worker thread, pinned async upload)",
                "host_sampler_s_per_epoch": t_sample, "device_plan_s_per_epoch": t_plans,
                "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,

@@ -104,10 +104,6 @@ SIGNATURES = {
     "crh_sampler_epoch": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "crh_sampler_epoch_async": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32]),
     "crh_sampler_epoch_wait": (_i32, [_vp]),
-    "crh_dsampler_workspace_bytes": (_sz, [_i64, _i64]),
-    "crh_dsampler_blocks_hint": (_i64, [_i64, _i32, _f64]),
-    "crh_dsampler_max_batch": (_i32, []),
-    "crh_dsampler_epoch": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
     "crh_sampler_set_catalogue": (_i32, [_vp, _i32, _vp]),
     "crh_sampler_set_py_state": (_i32, [_vp, _vp, _i32]),
     "crh_sampler_get_py_state": (_i32, [_vp, _vp, _vp]),
@@ -129,13 +125,6 @@ class SpmmSched(ctypes.Structure):
 
 
 SPMM_SCHED_VERSION = 4       # CRH_SPMM_SCHED_VERSION of include/coldrec_hip.h
-
-
-class DSamplerIO(ctypes.Structure):
-    """crh_dsampler_io of include/coldrec_hip.h."""
-    _fields_ = [("rec_user", _vp), ("rec_item", _vp), ("n_records", _i64), ("n_users", _i32), ("n_items", _i32),
-                ("rated_bits", _vp), ("bits_words_per_user", _i64), ("rated_rowptr", _vp), ("rated_col", _vp),
-                ("order", _vp), ("state", _vp), ("user_out", _vp), ("pos_out", _vp), ("neg_out", _vp)]
 
 
 def build(force: bool = False) -> str:

@@ -51,9 +51,19 @@ namespace {
 // 32x32x2 MFMAs of chunk q (k = 8q+2j in the low half-wave, 8q+2j+1 in the high one), so the scoring loop issues one fully coalesced 1 KiB load per
 // chunk and no cross-lane swaps (measured: the two v_permlane32_swap per chunk cost ~9 % of the MFMA
 // rate, the 32-B-per-row gather another ~4 %).  One workgroup per tile, staged through LDS.
+// Rows of items the candidate bitmap masks are packed as ZEROS (both pack kernels): a masked item is worth -1e9 whatever its
+// embedding says, it can only enter a list that is not full yet (threshold -inf, where every item is a candidate anyway), and
+// a full list drops it in the slow path by its bitmap bit -- but with its real embedding one masked item in five would first
+// beat the threshold and cost an event (a stall of the wave, in the workgroup kernels of the whole CU).  Score 0 never beats a
+// positive threshold.  The dense route ranks with crh_mask_topk_f32, which applies the bitmap itself.
+__device__ __forceinline__ bool pack_row_masked(const uint32_t* bitmap, int64_t gid) {
+    return bitmap != nullptr && ((bitmap[gid >> 5] >> (gid & 31)) & 1u);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void pack_items_kernel(const float* __restrict__ v, int64_t n_items,
-                                                         float* __restrict__ packed) {
+                                                         float* __restrict__ packed, const uint32_t* __restrict__ bitmap,
+                                                         int64_t item_base) {
     constexpr int NCH = D / 8;
     __shared__ float tile[32][D + 4];
     const int64_t t = blockIdx.x;
@@ -61,7 +71,8 @@ __global__ __launch_bounds__(256) void pack_items_kernel(const float* __restrict
         const int r = e / (D / 4), c = e % (D / 4);
         int64_t row = (t << 5) + r;
         if (row >= n_items) row = n_items - 1;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(v + row * D + 4 * c);
+        f32x4 x = *reinterpret_cast<const f32x4*>(v + row * D + 4 * c);
+        if (pack_row_masked(bitmap, item_base + row)) x = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         tile[r][4 * c + 0] = x.x; tile[r][4 * c + 1] = x.y; tile[r][4 * c + 2] = x.z; tile[r][4 * c + 3] = x.w;
     }
     __syncthreads();
@@ -81,7 +92,8 @@ __global__ __launch_bounds__(256) void pack_items_kernel(const float* __restrict
 // packing only makes the loads contiguous: unit (2q+h) of row i -> slot ((t*NCH+q)*64 + h*32 + i).
 template <int D>
 __global__ __launch_bounds__(256) void pack_items_f16_kernel(const _Float16* __restrict__ v, int64_t n_items,
-                                                             _Float16* __restrict__ packed) {
+                                                             _Float16* __restrict__ packed, const uint32_t* __restrict__ bitmap,
+                                                             int64_t item_base) {
     constexpr int NCH = D / 16;
     const int64_t t = blockIdx.x;
     const u32x4* src = reinterpret_cast<const u32x4*>(v);
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const _Float16* __r
         int64_t row = (t << 5) + r;
         if (row >= n_items) row = n_items - 1;
         const int q = c >> 1, h = c & 1;
-        dst[(t * NCH + q) * 64 + h * 32 + r] = src[row * (2 * NCH) + c];
+        dst[(t * NCH + q) * 64 + h * 32 + r] = pack_row_masked(bitmap, item_base + row) ? u32x4{0u, 0u, 0u, 0u} : src[row * (2 * NCH) + c];
     }
 }
 
@@ -637,13 +649,14 @@ size_t packed_bytes(int64_t n_items, int d, int esz) { return (size_t)((n_items 
 size_t tbits_bytes(int64_t n_items) { return (((size_t)((n_items + 31) / 32) * sizeof(uint32_t)) + 255) & ~(size_t)255; }
 size_t sync_bytes(int64_t n_items) { return ((size_t)((n_items + 255) / 256 + 2) * 8 * sizeof(unsigned) + 255) & ~(size_t)255; }
 
-int pack_items(int esz, const void* item_emb, int64_t n_items, int d, void* pk, hipStream_t st) {
+int pack_items(int esz, const void* item_emb, int64_t n_items, int d, void* pk, hipStream_t st, const uint32_t* bitmap,
+               int64_t item_base) {
     const unsigned tiles = (unsigned)((n_items + 31) / 32);
     const float* vf = reinterpret_cast<const float*>(item_emb);
     float* pf = reinterpret_cast<float*>(pk);
     const _Float16* vh = reinterpret_cast<const _Float16*>(item_emb);
     _Float16* ph = reinterpret_cast<_Float16*>(pk);
-#define CRH_PACK(KERN, V, P) hipLaunchKernelGGL(KERN, dim3(tiles), dim3(256), 0, st, V, n_items, P)
+#define CRH_PACK(KERN, V, P) hipLaunchKernelGGL(KERN, dim3(tiles), dim3(256), 0, st, V, n_items, P, bitmap, item_base)
     if (esz == 4) {
         switch (d) {
             case 8: CRH_PACK(pack_items_kernel<8>, vf, pf); break;
@@ -984,7 +997,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
         a.packed = nullptr;
         if (!no_pack && workspace_bytes >= dense_b + packed_bytes(n_items, d, esz)) {
             void* pk = reinterpret_cast<char*>(workspace) + dense_b;
-            const int prc = pack_items(esz, item_emb, n_items, d, pk, st);
+            const int prc = pack_items(esz, item_emb, n_items, d, pk, st, cand_bitmap, item_base);
             if (prc != CRH_OK) return prc;
             a.packed = pk;
         }
@@ -1037,7 +1050,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     a.packed = nullptr;
     if (can_pack) {
         void* pk = reinterpret_cast<char*>(workspace) + lists_bytes(n_users, k);
-        const int prc = pack_items(esz, item_emb, n_items, d, pk, st);
+        const int prc = pack_items(esz, item_emb, n_items, d, pk, st, cand_bitmap, item_base);
         if (prc != CRH_OK) return prc;
         a.packed = pk;
     }
@@ -1077,6 +1090,10 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     static const int timing = CRH_PROFILE_ENV("CRH_SCORE_TIMING");
     const int64_t n_waves = a.n_ugroups * a.n_splits;
     if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // profile build only
+    if (timing && use_dma) {   // DMA kernel: per-tile duration histograms of the first 16 workgroups' waves (64 buckets of 128 cycles)
+        CRH_HIP(hipMalloc(&a.wave_clock, (size_t)16 * 4 * 64 * 8));
+        CRH_HIP(hipMemsetAsync(a.wave_clock, 0, (size_t)16 * 4 * 64 * 8, st));
+    }
 #endif
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
     if (use_dma) {
@@ -1095,6 +1112,23 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     if (rc != CRH_OK) return rc;
     if (ev_kernel_stop) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_stop), st));
 #ifdef CRH_PROFILE
+    if (timing && use_dma) {
+        CRH_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)16 * 4 * 64);
+        CRH_HIP(hipMemcpy(h.data(), a.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));
+        CRH_HIP(hipFree(a.wave_clock));
+        for (int wv = 0; wv < 4; ++wv) {
+            unsigned long long tot = 0, wsum = 0;
+            std::vector<unsigned long long> b(64, 0);
+            for (int blk = 0; blk < 16; ++blk)
+                for (int q = 0; q < 64; ++q) b[q] += h[((size_t)blk * 4 + wv) * 64 + q];
+            for (int q = 0; q < 64; ++q) { tot += b[q]; wsum += b[q] * (unsigned long long)(q * 128 + 64); }
+            fprintf(stderr, "[crh dma timing] wave %d: %llu tiles, mean %.0f cycles; histogram (128-cycle buckets from 0):", wv, tot,
+                    tot ? (double)wsum / (double)tot : 0.0);
+            for (int q = 0; q < 64; ++q) fprintf(stderr, " %llu", b[q]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (timing && !use_wg) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
         CRH_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)n_waves * 2);

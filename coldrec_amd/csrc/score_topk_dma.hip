@@ -26,9 +26,13 @@ __device__ __forceinline__ unsigned rated_hash192(int gi) { return ((((unsigned)
 
 // Slow path of one 32x32 accumulator tile, as tile_slow_path (score_topk_common.h) with every memory round trip of the
 // common case removed: the candidate-bitmap bits of the tile come out of LDS (tb: the tile's 32 bits, fetched by DMA with
-// the tile stream, see tile_bits_kernel), the membership filter out of LDS; only a filter hit goes to memory (list
+// the tile stream, see tile_bits_kernel), the membership filter out of LDS too; only a filter hit goes to memory (list
 // bounds + search).  While one wave is in here the other three wait at the next barrier, and a memory wait in here would
 // also wait for the tile DMAs in flight.
+// The insert hands back the user's new threshold out of the registers it holds (+1.0 % against reading it back, same box).
+// (Measured and not kept, round 5: one LDS round trip per candidate -- the whole list, its fill and the filter word
+// requested together, the insert and the user's new threshold computed from those registers -- ran 2.7 % SLOWER on the
+// same box, 0.5316 vs 0.5457 of 2.5 PF: most events end at the "cannot enter" test after three scalar reads.)
 __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau_reg, float* ls, int* li, int* cnt, int K,
                                                    int ucol0, int64_t slot0, const ScoreArgs& a, int64_t item0,
                                                    int64_t split_end, int lane, unsigned tb, const unsigned* rfilter) {
@@ -78,13 +82,40 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
                 masked = wave_is_masked_at(gi, lo, hi, a.rated_col, nullptr, lane);
             }
             if (masked) sc = CRH_MASKED_SCORE;
-            wave_list_insert(lsu, liu, cnt + ul, K, sc, gi, lane);
+            // wave_list_insert (k <= 64 here) that also hands back the user's NEW threshold out of the registers it already
+            // holds -- the k-th entry after the insert is the old (k-1)-th or the candidate -- instead of reading it back
+            {
+                const int n = __builtin_amdgcn_readfirstlane(cnt[ul]);
+                float es = CRH_NEG_INF;
+                int ei = CRH_PAD_IDX;
+                if (lane < n) {
+                    es = lsu[lane];
+                    ei = liu[lane];
+                }
+                const int p = __popcll(__ballot(lane < n && crh_better(es, ei, sc, gi)));
+                if (p < K) {
+                    if (lane >= p && lane < n && lane + 1 < K) {
+                        lsu[lane + 1] = es;
+                        liu[lane + 1] = ei;
+                    }
+                    const int n2 = n < K ? n + 1 : K;
+                    if (lane == 0) {
+                        lsu[p] = sc;
+                        liu[p] = gi;
+                        cnt[ul] = n2;
+                    }
+                    if (n2 >= K) {
+                        const float prev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, es), K >= 2 ? K - 2 : 0));
+                        const float kth = (p == K - 1) ? sc : prev;
+                        if ((lane & 31) == jl) tau_reg = kth >= CRH_MASKED_SCORE ? kth : CRH_NEG_INF;
+                    }
+                }
+            }
         }
     }
-    const int my = ucol0 + (lane & 31);
-    // a padding column (slot past the block) never takes a candidate: +inf keeps it out of the threshold ballot
-    tau_reg = slot0 + (lane & 31) < a.n_users ? wave_list_tau(ls + my * K, cnt[my], K) : __builtin_inff();
+    // (no read-back of the thresholds: every insert above updated its user's lanes; padding columns keep their +inf)
 }
+
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA form of the workgroup kernel for 512-byte rows (fp16 d=256: configs[4]; fp32 d=128: the headline).
@@ -211,15 +242,15 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 #endif
 
     const char* packed = reinterpret_cast<const char*>(a.packed);
-    const int64_t n_steps = t1 - t0;
+    const int n_steps = (int)(t1 - t0);                 // tiles of this split (32-bit loop arithmetic: scalar compares, no VALU)
     // this wave's pieces of step j -> ring slot.  Steps past the split (the extra body, the prefetch distance) read clamped
     // tiles: valid addresses, data nobody selects.
     // One global pointer per lane and ONE LDS base per slot serve the wave's CPW pieces: the instruction's immediate offset
     // moves both addresses (LDS address = M0 + offset + 16 * lane).
     const char* my_pieces = packed + (wave * CPW) * 1024 + lane * 16;
     const int n_tiles32 = (int)NT;                     // item ids are int32, so tiles fit easily
-    auto dma_tile = [&](int64_t j, int slot) __attribute__((always_inline)) {
-        int t = (int)t0 + (int)j;
+    auto dma_tile = [&](int j, int slot) __attribute__((always_inline)) {
+        int t = (int)t0 + j;
         t = t < n_tiles32 ? t : n_tiles32 - 1;
         if (CRH_ABLATE(a.ablate) & 2) t = 0;   // measurement only: every fetch hits the same (cached) tile
         const char* g = my_pieces + (int64_t)t * TILE_B;
@@ -248,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     };
     auto dma_wait_but_newest_tile = [&]() __attribute__((always_inline)) {   // everything but the CPW + 1 pieces issued last
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (CRH_ABLATE(a.ablate) & 16) return;   // measurement only: what the DMA wait costs (results invalid)
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(CPW + 1) : "memory");
 #endif
     };
@@ -274,6 +306,10 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     };
     auto lds_wait = [&](f32x4(&x)[GR], auto Nc) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        if (CRH_ABLATE(a.ablate) & 8) {          // measurement only: what the fragment waits cost (results invalid)
+            asm volatile("" : "+v"(x[0]), "+v"(x[1]));
+            return;
+        }
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "i"(decltype(Nc)::value));
 #endif
     };
@@ -281,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 
     // body j: MFMAs of tile j (ring slot s_cur) into accumulator set P, threshold test of tile j-1 out of set 1-P;
     // s_nxt = slot of tile j+1, s_fill = slot tile j-1 left = slot of tile j+3
-    auto body = [&](auto Pc, int64_t j, int s_cur, int s_nxt, int s_fill) __attribute__((always_inline)) {
+    auto body = [&](auto Pc, int j, int s_cur, int s_nxt, int s_fill) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value, Q = 1 - P;
         const uint32_t src = ring_lds + s_cur * TILE_B, srcn = ring_lds + s_nxt * TILE_B;
         float m[UW];
@@ -306,6 +342,15 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
             if constexpr (g == BG) {
                 dma_tbits((t0 + j + 32) >> 6);
                 dma_tile(j + 3, s_fill);
+                // one DMA instruction and a few of its address instructions per MFMA gap instead of all of them in one gap
+                // (+0.9 % on the same box: a single wave per SIMD hides about five issue slots per MFMA, not twenty)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // SALU
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the DMA)
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < GR; ++jj) {
@@ -361,25 +406,39 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
         // XCD soft lockstep (see xcd_window_sync): wave 0 reports / waits for the workgroup, the others meet it at the
         // tile's barrier
         unsigned* sync_cnt = nullptr;
-        int64_t win_steps = 0, next_sync = n_steps + 4;
+        int win_steps = 0, next_sync = n_steps + 4;
         if (a.xcd_sync && wave == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
             sync_cnt = a.xcd_sync + (int64_t)xcc * a.sync_stride;
             if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            win_steps = a.sync_window & ~(int64_t)1;      // whole loop trips (two bodies each)
+            win_steps = a.sync_window & ~1;               // whole loop trips (two bodies each)
             if (win_steps < 2) win_steps = 2;
             next_sync = 0;
         }
-        for (int64_t j = 0; j <= n_steps; j += 2) {
+#ifdef CRH_PROFILE
+        unsigned long long t_prev = 0;                  // CRH_SCORE_TIMING: duration of every PAIR of tiles, histogrammed per wave
+#endif
+        for (int j = 0; j <= n_steps; j += 2) {
+#ifdef CRH_PROFILE
+            if (a.wave_clock != nullptr && blockIdx.x < 16) {
+                const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+                if (j >= 64 && lane == 0) {
+                    unsigned long long dt = (t_now - t_prev) >> 8;      // two tiles per trip: 256-cycle units = 128 per tile
+                    if (dt > 63) dt = 63;
+                    atomicAdd(&a.wave_clock[((size_t)blockIdx.x * 4 + wave) * 64 + dt], 1ull);
+                }
+                t_prev = t_now;
+            }
+#endif
             if (j >= next_sync && j < n_steps) {       // wave 0 only (next_sync stays beyond the range elsewhere)
-                const int64_t win = j / win_steps;
+                const int win = j / win_steps;
                 if (xcd_window_sync(sync_cnt, win, lane)) {
                     next_sync += win_steps;
                 } else {                // timed out: run free, and count this workgroup into every window it will not report
                     next_sync = n_steps + 4;
-                    const int64_t n_win = (n_steps + win_steps - 1) / win_steps;
+                    const int n_win = (n_steps + win_steps - 1) / win_steps;
                     if (lane == 0)
-                        for (int64_t wdw = win; wdw < n_win; ++wdw)
+                        for (int wdw = win; wdw < n_win; ++wdw)
                             __hip_atomic_fetch_add(sync_cnt + 1 + wdw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }

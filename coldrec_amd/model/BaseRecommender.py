@@ -19,6 +19,7 @@ import math
 import re
 import time
 from abc import ABC, abstractmethod
+from collections.abc import Mapping
 from typing import Any, Dict, List, Tuple
 
 import numpy as np
@@ -33,6 +34,61 @@ from ..util.evaluator import format_measure, ranking_metrics, truth_csr, truth_d
 def _truth_pairs(data_set: Dict) -> int:
     fast = getattr(data_set, 'n_pairs', None)         # array-backed ground truths (bench.py's S-EVAL leg) know their size
     return int(fast) if fast is not None else sum(map(len, data_set.values()))
+
+
+class RecList(Mapping):
+    """What ``_evaluate`` / ``valid`` / ``test`` return: ``{user: [(original item id, np.float32 score), ...]}`` exactly as
+    model/BaseRecommender.py:185-187 builds it -- same keys in the same order, same lists on access -- but held as the
+    ``(users, k)`` score / id arrays the ranking kernel wrote, and materialised one user at a time when somebody looks.
+    The eager dict was 2e6 Python tuples per 1e5 users (0.55 s beside 1.95 s of ranking); callers that only hand the result
+    to ``full_evaluation`` (every reference model does) never pay for it: ``full_evaluation`` takes the arrays.  A plugin
+    that edits lists assigns into it (``rec[u] = [...]``): such users are kept as plain lists and win over the arrays."""
+
+    def __init__(self, users, scores: np.ndarray, idx: np.ndarray, item_keys: np.ndarray):
+        self.users, self.scores, self.idx, self._item_keys = users, scores, idx, item_keys
+        self._row = None            # user -> row, built on first keyed access
+        self._edited: Dict[Any, list] = {}
+
+    def _rows(self):
+        if self._row is None:
+            self._row = {u: r for r, u in enumerate(self.users)}
+        return self._row
+
+    def _list(self, r: int) -> list:
+        names = self._item_keys[np.minimum(self.idx[r], len(self._item_keys) - 1)].tolist()
+        return list(zip(names, self.scores[r]))
+
+    def __getitem__(self, user):
+        if user in self._edited:
+            return self._edited[user]
+        return self._list(self._rows()[user])
+
+    def __setitem__(self, user, value):
+        if user not in self._rows():
+            raise KeyError(user)
+        self._edited[user] = value
+
+    def __iter__(self):
+        return iter(self.users)
+
+    def __len__(self):
+        return len(self.users)
+
+    def __contains__(self, user):
+        return user in self._rows()
+
+    def items(self):
+        for r, u in enumerate(self.users):
+            yield u, (self._edited[u] if u in self._edited else self._list(r))
+
+    def values(self):
+        for _, v in self.items():
+            yield v
+
+    @property
+    def untouched(self) -> bool:
+        """no list was replaced: the arrays ARE the lists"""
+        return not self._edited
 
 
 _STOCK_PREDICT = re.compile(
@@ -215,10 +271,10 @@ class BaseColdStartTrainer(ABC):
         t0 = self._tick('_before', time.perf_counter())
         c, s, i = self._topk_arrays(data_set, data_type)
         t0 = self._tick('evaluate_rank_s', t0)
-        # {user: [(original item id, np.float32 score), ...]} as model/BaseRecommender.py:185-187 builds it: the ids in bulk
-        # (one gather + one tolist), the pairing row by row
-        names = self.data.item_keys[np.minimum(i, len(self.data.item_keys) - 1)].tolist()
-        out = {u: list(zip(nr, sr)) for u, nr, sr in zip(c['users'], names, s)}
+        # {user: [(original item id, np.float32 score), ...]} as model/BaseRecommender.py:185-187 builds it, as a Mapping over
+        # the arrays that materialises a user's list on access (RecList)
+        out = RecList(c['users'], s, i, self.data.item_keys)
+        out._ranked_for = (id(data_set), data_type)
         self._tick('evaluate_dict_s', t0)
         return out
 
@@ -300,6 +356,10 @@ class BaseColdStartTrainer(ABC):
         """Metrics of a caller-supplied ``{user: [(item, score), ...]}`` (what ``test()`` returns, possibly
         post-processed by a plugin) -- the reference's ranking_evaluation(test_set, rec_list, topN) on arrays."""
         c = self._get_eval_cache(data_set, data_type)
+        if isinstance(rec_list, RecList) and rec_list.untouched and rec_list.idx.shape[0] == len(c['users']) and \
+                rec_list.idx.shape[1] >= max(topn) and list(rec_list.users) == list(c['users']):
+            # the lists are the ranking kernel's own arrays (internal ids): no Python tuple is built on the way to the metrics
+            return ranking_metrics(c['gt_rowptr'], c['gt_items'], rec_list.idx.astype(np.int64), topn, dense=c['gt_dense'])
         item_id = self.data.item
         pred = np.full((len(c['users']), max(topn)), np.iinfo(np.int32).max, np.int64)
         for r, u in enumerate(c['users']):

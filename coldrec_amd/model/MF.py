@@ -11,7 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..sampler import DevicePrefetcher, EpochPrefetcher
+from ..sampler import EpochPrefetcher
 from ..train import EpochRunner, MFEngine, dp_from_env
 from .BaseRecommender import BaseColdStartTrainer
 
@@ -66,16 +66,8 @@ class MF(BaseColdStartTrainer):
         # collectives are kept out of graph capture: the data-parallel epoch is launched eagerly
         runner = EpochRunner(eng, len(self.data.train_u), self.batch_size, use_graph=dp is None)
         # epoch e+1 is sampled (same NumPy stream) while the GPU trains and ranks epoch e: by the C++ sampler on its
-        # persistent worker thread, into pinned buffers uploaded asynchronously (EpochPrefetcher), or --
-        # CRH_SAMPLER_DEVICE=1 -- by a chain of kernels on a side stream (DevicePrefetcher: the triples never leave HBM;
-        # bit-identical, currently the slower of the two at MovieLens size: DESIGN.md 4.5)
-        dsmp = None
-        if os.environ.get('CRH_SAMPLER_DEVICE', '0') == '1':
-            dsmp = self.data.device_sampler(self.device)
-            if dsmp is not None and self.batch_size > dsmp.max_batch:
-                dsmp = None
-        triples = DevicePrefetcher(self.data.sampler, dsmp, self.batch_size) if dsmp is not None else \
-            EpochPrefetcher(self.data.sampler, self.batch_size, device=self.device)
+        # persistent worker thread, into pinned buffers uploaded asynchronously (EpochPrefetcher)
+        triples = EpochPrefetcher(self.data.sampler, self.batch_size, device=self.device)
         # the reference starts its clock once model and optimiser are on the device (model/MF.py:13-16); what it samples
         # from was built when the data was loaded (util/databuilder.py).  Same here: engine, sampler tables, staging
         # buffers and the runner's device buffers exist before the clock starts; every epoch's sampling is inside it.

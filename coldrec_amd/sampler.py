@@ -284,210 +284,3 @@ class EpochPrefetcher:
         if self._base is not None:
             self._finish()
             self._abort()
-
-
-class DeviceSampler:
-    """next_batch_pairwise on the GPU (csrc/sampler_dev.hip, crh_dsampler_epoch): the same NumPy stream, the triples
-    are written to device memory by a chain of kernels on ``stream``.  Holds the device copies of the records, of the
-    rated-item table (users x items bitmap while it fits ``bitmap_bytes``, else the sorted CSR) and of the cumulative
-    permutation; the 624-word generator state travels host <-> device as 2.5 KB copies."""
-
-    def __init__(self, rec_user, rec_item, n_users: int, n_items_seen: int, device, bitmap_bytes: int = 1 << 29):
-        import torch
-        self._torch = torch
-        ru = np.ascontiguousarray(rec_user, dtype=np.int32)
-        ri = np.ascontiguousarray(rec_item, dtype=np.int32)
-        if ru.shape != ri.shape or ru.ndim != 1 or ru.shape[0] < 1:
-            raise ValueError("rec_user / rec_item must be non-empty 1-D arrays of equal length")
-        if n_items_seen < 2:
-            raise ValueError("the device sampler needs at least two items")
-        self._L = _lib.lib()
-        self.device = torch.device(device)
-        self.n, self.n_users, self.n_items = int(ru.shape[0]), int(n_users), int(n_items_seen)
-        dev = self.device
-        self.rec_u, self.rec_i = torch.from_numpy(ru).to(dev), torch.from_numpy(ri).to(dev)
-        wpu = (self.n_items + 31) // 32
-        self.bits = self.rowptr = self.col = None
-        if wpu * 4 * self.n_users <= bitmap_bytes:
-            words = np.zeros(self.n_users * wpu + 1, np.uint32)
-            np.bitwise_or.at(words, ru.astype(np.int64) * wpu + (ri >> 5), np.uint32(1) << (ri & 31).astype(np.uint32))
-            self.bits, self.wpu = torch.from_numpy(words.view(np.int32)).to(dev), wpu
-        else:
-            key = np.unique(ru.astype(np.int64) << 32 | ri.astype(np.int64))
-            rowptr = np.zeros(self.n_users + 1, np.int64)
-            np.cumsum(np.bincount((key >> 32).astype(np.int64), minlength=self.n_users), out=rowptr[1:])
-            self.rowptr = torch.from_numpy(rowptr).to(dev)
-            self.col = torch.from_numpy((key & 0xFFFFFFFF).astype(np.int32)).to(dev)
-            self.wpu = 0
-        cnt = np.bincount(ru, minlength=self.n_users).astype(np.float64)
-        self.reject_rate = float((cnt * cnt).sum() / (self.n * float(self.n_items)))   # P(a uniform item is rated by the slot's user)
-        self.order = torch.arange(self.n, dtype=torch.int32, device=dev)
-        self.state = torch.zeros(626, dtype=torch.int32, device=dev)
-        self._snap_order, self._snap_state = torch.empty_like(self.order), torch.empty_like(self.state)
-        self._pin = torch.empty(626, dtype=torch.int32).pin_memory()
-        self.n_blocks = int(self._L.crh_dsampler_blocks_hint(self.n, self.n_items, self.reject_rate))
-        self._ws = None
-        self.max_batch = int(self._L.crh_dsampler_max_batch())
-        self.seed(5489)
-
-    # ---- generator state (np.random.get_state()[1:3])
-    def set_state(self, key, pos: int) -> None:
-        torch = self._torch
-        self._pin[:624] = torch.from_numpy(np.ascontiguousarray(key, dtype=np.uint32).view(np.int32))
-        self._pin[624], self._pin[625] = int(pos), 0
-        self.state.copy_(self._pin, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()          # the pinned buffer is reused by the next call
-
-    def get_state(self):
-        """(key uint32[624], pos, status) -- synchronises with the stream the last epoch() ran on."""
-        self._pin.copy_(self.state, non_blocking=True)
-        self._torch.cuda.current_stream(self.device).synchronize()
-        a = self._pin.numpy().view(np.uint32)
-        return a[:624].copy(), int(a[624]), int(a[625])
-
-    def seed(self, seed: int) -> None:
-        rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
-        st = rs.get_state()
-        self.set_state(st[1], st[2])
-
-    def pull_numpy_state(self) -> None:
-        st = np.random.get_state()
-        assert st[0] == "MT19937"
-        self.set_state(st[1], st[2])
-
-    def push_numpy_state(self) -> None:
-        key, pos, status = self.get_state()
-        if status != 0:
-            raise RuntimeError("device sampler: generator state is invalid (epoch status %d)" % status)
-        st = np.random.get_state()
-        np.random.set_state((st[0], key, pos, st[3], st[4]))
-
-    # ---- one epoch
-    def _io(self, out):
-        p = _lib.ptr
-        return _lib.DSamplerIO(p(self.rec_u), p(self.rec_i), self.n, self.n_users, self.n_items, p(self.bits), self.wpu,
-                               p(self.rowptr), p(self.col), p(self.order), p(self.state), p(out[0]), p(out[1]), p(out[2]))
-
-    def snapshot(self) -> None:
-        self._snap_order.copy_(self.order)
-        self._snap_state.copy_(self.state)
-
-    def restore(self) -> None:
-        self.order.copy_(self._snap_order)
-        self.state.copy_(self._snap_state)
-
-    def launch(self, batch_size: int, out=None):
-        """Enqueue one epoch on the CURRENT stream (asynchronous).  Returns the three int32 device tensors."""
-        torch = self._torch
-        if not 1 <= int(batch_size) <= self.max_batch:
-            raise ValueError("device sampler: batch_size %d outside 1..%d" % (batch_size, self.max_batch))
-        if out is None:
-            out = tuple(torch.empty(self.n, dtype=torch.int32, device=self.device) for _ in range(3))
-        need = int(self._L.crh_dsampler_workspace_bytes(self.n, self.n_blocks))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        io = self._io(out)
-        _lib.check(self._L.crh_dsampler_epoch(ctypes.byref(io), int(batch_size), self.n_blocks, _lib.ptr(self._ws),
-                                              self._ws.numel(), _lib.current_stream()), "crh_dsampler_epoch")
-        return out
-
-    def epoch(self, batch_size: int, out=None):
-        """One epoch, checked: if the generated stream turned out too short (status != 0) the epoch is repeated from
-        the snapshot with twice the key blocks.  Synchronises (reads the status back)."""
-        for _ in range(6):
-            self.snapshot()
-            out = self.launch(batch_size, out)
-            _key, _pos, status = self.get_state()
-            if status == 0:
-                return out
-            self.restore()
-            self.n_blocks *= 2
-        raise RuntimeError("device sampler: could not generate enough MT19937 words")
-
-
-class DevicePrefetcher:
-    """EpochPrefetcher's contract with the sampler on the GPU: ``get()`` returns the next epoch's (u, i, j) as DEVICE
-    tensors and advances NumPy's global generator exactly as ``epoch_triples`` would; the following epoch is sampled
-    speculatively on a side stream while the caller trains (taken back by ``close()`` or when somebody used
-    ``np.random`` in between).  The cumulative permutation is taken from / returned to the host sampler, so host and
-    device epochs can be mixed on one dataset."""
-
-    def __init__(self, host_sampler: PairwiseSampler, dsampler: DeviceSampler, batch_size: int, enabled=None):
-        import torch
-        self._torch = torch
-        self.hs, self.ds, self.B = host_sampler, dsampler, int(batch_size)
-        self.enabled = (os.environ.get("CRH_SAMPLER_PREFETCH", "1") != "0") if enabled is None else bool(enabled)
-        self.side = torch.cuda.Stream(self.ds.device)
-        self._bufs = [tuple(torch.empty(self.ds.n, dtype=torch.int32, device=self.ds.device) for _ in range(3))
-                      for _ in range(2)]
-        self._k = 0
-        self._base = None          # NumPy state the outstanding (speculative) epoch started from
-        self._done = None          # event: the outstanding epoch's kernels
-        self._out = None
-        order = np.empty(self.ds.n, np.int32)
-        _lib.check(self.hs._L.crh_sampler_get_order(self.hs._h, order.ctypes.data), "crh_sampler_get_order")
-        self.ds.order.copy_(torch.from_numpy(order))
-        self._dev_state_is = None  # NumPy state the device generator is known to equal
-
-    @staticmethod
-    def _np_state():
-        st = np.random.get_state()
-        return st[1].copy(), int(st[2])
-
-    def _start(self) -> None:
-        torch = self._torch
-        self._base = self._np_state()
-        main = torch.cuda.current_stream(self.ds.device)
-        self.side.wait_stream(main)            # the buffers of this slot were last read by copies enqueued on `main`
-        with torch.cuda.stream(self.side):
-            known = self._dev_state_is
-            if known is None or known[1] != self._base[1] or not np.array_equal(known[0], self._base[0]):
-                self.ds.set_state(*self._base)
-            self.ds.snapshot()
-            self._out = self.ds.launch(self.B, self._bufs[self._k])
-            self._done = torch.cuda.Event()
-            self._done.record(self.side)
-        self._k ^= 1
-
-    def _take_back(self) -> None:
-        torch = self._torch
-        with torch.cuda.stream(self.side):
-            self.ds.restore()
-        self.side.synchronize()
-        self._dev_state_is = None
-        self._base = self._out = self._done = None
-
-    def get(self):
-        torch = self._torch
-        if self._base is not None:
-            key, pos = self._np_state()
-            if pos != self._base[1] or not np.array_equal(key, self._base[0]):     # np.random was used meanwhile
-                self._take_back()
-        for _ in range(6):
-            if self._base is None:
-                self._start()
-            with torch.cuda.stream(self.side):
-                key, pos, status = self.ds.get_state()                             # waits for the epoch's kernels
-            if status == 0:
-                break
-            self._take_back()                                                      # stream too short: more key blocks
-            self.ds.n_blocks *= 2
-        else:
-            raise RuntimeError("device sampler: could not generate enough MT19937 words")
-        st = np.random.get_state()
-        np.random.set_state((st[0], key, pos, st[3], st[4]))
-        self._dev_state_is = (key, pos)
-        out, done = self._out, self._done
-        self._base = self._out = self._done = None
-        torch.cuda.current_stream(self.ds.device).wait_event(done)
-        if self.enabled:
-            self._start()                      # speculate on the following epoch
-        return out
-
-    def close(self) -> None:
-        """Take back a speculative epoch nobody asked for and hand the permutation back to the host sampler."""
-        if self._base is not None:
-            self._take_back()
-        self.side.synchronize()
-        order = self.ds.order.cpu().numpy()
-        _lib.check(self.hs._L.crh_sampler_set_order(self.hs._h, order.ctypes.data), "crh_sampler_set_order")

@@ -238,17 +238,6 @@ class ColdStartDataBuilder(object):
             self._sampler.set_catalogue(len(self.user), self.mapped_cold_item_idx)
         return self._sampler
 
-    def device_sampler(self, device):
-        """The same sampler as a chain of HIP kernels (coldrec_amd/sampler.py DeviceSampler), one per device; None when
-        the catalogue is outside its limits (a single item: NumPy draws nothing then)."""
-        cache = self.__dict__.setdefault('_dsamplers', {})
-        key = str(device)
-        if key not in cache:
-            from ..sampler import DeviceSampler
-            cache[key] = DeviceSampler(self.train_u, self.train_i, self.user_num, len(self.item), device) \
-                if len(self.item) >= 2 and len(self.train_u) >= 1 else None
-        return cache[key]
-
     # ------------------------------------------------------------------ small accessors of the reference
     def training_size(self):
         return len(self.user), len(self.item), len(self.training_data)

@@ -460,46 +460,6 @@ int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host
                       int32_t* pos_out_host, int32_t* neg_out_host);
 
 /*
- * The same sampler ON THE DEVICE (util/utils.py:123-157, NumPy stream bit for bit): the MT19937 words are generated
- * by a kernel, np.random.shuffle's draws are resolved 64 at a time by one wave, the Fisher-Yates swaps are applied in
- * parallel through previous-occurrence chains, np.random.choice's accepted draws are a compaction of the remaining
- * words and the rejection rounds of every batch are data-parallel passes over its slots -- a chain of kernels on
- * `stream`, no host round trip; the triples are written to device memory.  All pointers are DEVICE pointers.
- *   rec_user / rec_item   training records, internal ids, file order (n_records)
- *   rated_bits            users x bits_words_per_user uint32 words, bit (item & 31) of word item >> 5 set = training
- *                         item of that user; or NULL and rated_rowptr (n_users + 1, int64) / rated_col (ascending)
- *   order                 (n_records) cumulative permutation of the records, identity before the first epoch; in/out
- *   state                 626 uint32: key[624], pos (np.random.get_state()), status; in/out.  status (out): 0 ok,
- *                         1 / 2 = the n_blocks generated key blocks were too few (state and order of a failed epoch
- *                         are undefined: keep a copy, retry with more blocks)
- *   user_out / pos_out / neg_out   (n_records) int32: the epoch's batches concatenated, the last one short
- * n_blocks: MT19937 key blocks (624 words) to generate, crh_dsampler_blocks_hint(n_records, n_items, reject_rate)
- * with reject_rate = the probability that a uniform item is one of the slot user's training items;
- * workspace: crh_dsampler_workspace_bytes(n_records, n_blocks).  batch_size <= crh_dsampler_max_batch() (8192),
- * n_items >= 2.
- */
-typedef struct {
-    const int32_t* rec_user;
-    const int32_t* rec_item;
-    int64_t n_records;
-    int32_t n_users, n_items;
-    const uint32_t* rated_bits;
-    int64_t bits_words_per_user;
-    const int64_t* rated_rowptr;
-    const int32_t* rated_col;
-    int32_t* order;
-    uint32_t* state;
-    int32_t* user_out;
-    int32_t* pos_out;
-    int32_t* neg_out;
-} crh_dsampler_io;
-size_t crh_dsampler_workspace_bytes(int64_t n_records, int64_t n_blocks);
-int64_t crh_dsampler_blocks_hint(int64_t n_records, int32_t n_items, double reject_rate);
-int crh_dsampler_max_batch(void);
-int crh_dsampler_epoch(const crh_dsampler_io* io, int64_t batch_size, int64_t n_blocks, void* workspace,
-                       size_t workspace_bytes, void* stream);
-
-/*
  * The other samplers of util/utils.py, same conventions (host pointers, internal ids, one call
  * per epoch, records concatenated in shuffled order, the cumulative shuffle shared with crh_sampler_epoch).
  * They draw from CPython's `random` module stream (set/get_py_state exchange random.getstate()[1] = 624 key

@@ -940,7 +940,8 @@ def g16_runs2():
                          "--cold_object", "item"],
                    per_run=per_run.tolist(), metrics=g["metrics_payload"], block_lines=keep,
                    first_batch_crc=rec["first"], all_triples_crc=rec["allcrc"], n_batches=rec["n_batches"],
-                   console_tail=[ln for ln in buf.getvalue().splitlines() if "±" in ln or ln.startswith(("Top-", "Start round"))]),
+                   console_tail=[ln for ln in buf.getvalue().splitlines()
+                                 if ("±" in ln and not ln.startswith("Time:")) or ln.startswith(("Top-", "Start round"))]),
               open(out("g16_runs2.json"), "w"), indent=1, ensure_ascii=False)
     print("g16 runs2: per-run NDCG@20 overall", per_run[0, -1, 3].tolist(), "first-batch crcs", rec["first"])
 

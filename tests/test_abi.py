@@ -54,9 +54,12 @@ def test_workspace_query_follows_the_route_of_the_call():
     # 131 072 x 262 144: seeded with the clamped prefix: 131 072 x 4 096 x 4 B = 2 GiB of stage-1 block, not 8 GiB
     assert L.crh_score_topk_workspace_bytes(131072, 262144, 128, 20) <= 2.1 * GiB
     assert L.crh_score_topk_workspace_bytes(131072, 1_250_000, 128, 20) <= 2.1 * GiB
-    # fp16 (config 5 shape): the user block fills the chip, no cuts, no small-catalogue rule -> no seed term
+    # fp16 (config 5 shape): the user block fills the chip and nothing is cut, but at 16x the MFMA rate the slow-path events
+    # are worth removing: a 4 096-item prefix seeds the lists (round 5) -> the prefix's 2 GiB score block, not more
     f16 = L.crh_score_topk_f16_workspace_bytes(131072, 50_000_000, 256, 20)
-    assert f16 <= lists + 50_000_032 * 256 * 2 + (16 << 20)
+    assert f16 <= lists + 50_000_032 * 256 * 2 + (32 << 20) + 131072 * 20 * 8 + 1
+    # ... and a user block too small for the workgroup kernels keeps the old rule
+    assert L.crh_score_topk_f16_workspace_bytes(16384, 50_000_000, 256, 20) <= 64 * 16384 * 20 * 8 + 50_000_032 * 256 * 2 + 2.2 * GiB
 
 
 def test_ops_refuse_cpu_tensors():
@@ -78,7 +81,7 @@ def test_the_library_reports_its_route():
     assert shard["prefix_items"] == 4096 and shard["kernel"] == "score_topk_kernel"
     assert shard["code"] != head["code"]
     f16 = ops.score_topk_route(131072, 50_000_000, 256, 20, half=True)       # configs[4]: the LDS-DMA workgroup kernel
-    assert f16["route"] == "fused-dma" and f16["kernel"] == "score_topk_dma_kernel" and not f16["seeded"]
+    assert f16["route"] == "fused-dma" and f16["kernel"] == "score_topk_dma_kernel" and f16["seeded"] and f16["prefix_items"] == 4096
     f16_shard = ops.score_topk_route(131072, 6_250_000, 256, 20, half=True)
     assert f16_shard["route"] == "fused-dma"
     assert ops.score_topk_route(131072, 50_000_000, 256, 21, half=True)["route"] == "fused-wg"   # k > 20: the lists leave no room for 4 slots

@@ -395,53 +395,6 @@ def test_cgrc_try_limit_and_lara_guard():
         s.epoch_lara(1)
 
 
-@pytest.mark.parametrize("n_u,n_i,nrec,bs,seed", [(30, 50, 400, 64, 2024), (100, 37, 1500, 256, 1), (700, 100, 6000, 1024, 38192),
-                                                    (5, 3, 9, 4, 7)])
-def test_device_sampler_algorithm_restated_in_numpy_matches_np_random(n_u, n_i, nrec, bs, seed):
-    """The ALGORITHM of csrc/sampler_dev.hip (oracle/dsampler_np.py: 64 draws classified at once with a serial
-    fallback, Fisher-Yates through previous-occurrence chains, compaction of the accepted item draws, rejection rounds)
-    reproduces np.random's own shuffle / choice stream: triples of three epochs and the stream position."""
-    from oracle import dsampler_np as dnp
-    rng = np.random.default_rng(nrec)
-    pairs = np.unique(np.stack([rng.integers(0, n_u, nrec), rng.integers(0, n_i, nrec)], 1), axis=0)
-    rng.shuffle(pairs)
-    ru, ri = pairs[:, 0], pairs[:, 1]
-    np.random.seed(seed)
-    ref = orc.PairwiseSampler(ru, ri, n_i, n_u)
-    raw = np.random.RandomState(seed)._bit_generator.random_raw(40 * len(ru) + 4000).astype(np.uint32)
-    order, base = np.arange(len(ru)), 0
-    for _ in range(3):
-        want = [np.concatenate(x) for x in zip(*ref.epoch(bs))]
-        order, u, p, neg, used = dnp.epoch(raw[base:], order, ru, ri, ref.rated, n_i, bs)
-        assert np.array_equal(u, want[0]) and np.array_equal(p, want[1]) and np.array_equal(neg, want[2])
-        base += used
-        nxt = np.random.RandomState()
-        nxt.set_state(np.random.get_state())
-        assert int(nxt._bit_generator.random_raw(1)[0]) == int(raw[base])        # same position in the stream
-
-
-def test_shuffle_scan_groups_of_64_equal_the_serial_draws():
-    """Fuzz of the speculative scan alone, including the mask change that falls on the last accept of a group."""
-    from oracle import dsampler_np as dnp
-    rng = np.random.default_rng(0)
-    for _ in range(120):
-        n = int(rng.integers(1, 5000))
-        raw = rng.integers(0, 2 ** 32, size=3 * n + 2000, dtype=np.uint64).astype(np.uint32)
-        J = np.zeros(n, np.int64)
-        q, i = 0, n - 1
-        while i >= 1:
-            mask = dnp.pow2mask(i)
-            while True:
-                v = int(raw[q]) & mask
-                q += 1
-                if v <= i:
-                    break
-            J[i] = v
-            i -= 1
-        got, used, _, _ = dnp.shuffle_scan(raw, n)
-        assert used == q and np.array_equal(got, J), n
-
-
 def test_destroy_while_a_background_epoch_is_running_returns():
     """ADVICE.md (round 2): crh_sampler_destroy during a RUNNING background epoch used to hang -- the finishing job
     overwrote the shutdown flag.  Destroy now lets the epoch finish (the worker owns the output arrays until then),

@@ -21,6 +21,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k(const f16x8* in, float* out, int
     for (int i = 0; i < NB; ++i)
         for (int u = 0; u < NACC; ++u) b[i][u] = in[((threadIdx.x >> 6) * 31 + i * NACC + u) * 64 % 4096 + lane];
     for (int i = threadIdx.x; i < 16 * 64; i += 64 * NW) reinterpret_cast<f16x8*>(smem)[i] = in[(blockIdx.x * 7 * 64 + i) % (4096 * 64)];
+#ifdef PIN_B_AGPR    // the DMA scoring kernel's register split: B fragments in AGPRs, accumulators in VGPRs (build with
+    for (int i = 0; i < NB; ++i)   // -mllvm -amdgpu-mfma-vgpr-form -DPIN_B_AGPR)
+        for (int u = 0; u < NACC; ++u) asm volatile("" : "+a"(b[i][u]));
+#endif
     __syncthreads();
     f16x8 areg[4];
     for (int i = 0; i < 4; ++i) areg[i] = reinterpret_cast<f16x8*>(smem)[i * 64 + lane];
