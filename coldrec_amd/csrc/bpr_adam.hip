@@ -1698,7 +1698,7 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
             if (hb > 512) hb = 512;
             // rows per lane group (grid-stride): the smallest count up to 4 that keeps the launch in one resident
             // round (256 CUs x 5 workgroups at this kernel's ~100 VGPRs); B = 4096: two rows, LightGCN step -4 us
-            static const int force_rows = getenv("CRH_BWD_ROWS") ? atoi(getenv("CRH_BWD_ROWS")) : 0;
+            static const int force_rows = CRH_TUNE_ENV("CRH_BWD_ROWS") ? atoi(CRH_TUNE_ENV("CRH_BWD_ROWS")) : 0;
             int64_t rb = 0;
             for (int r = force_rows > 0 ? force_rows : 1; r <= (force_rows > 0 ? force_rows : 4); ++r) {
                 rb = (3 * batch + per_block * r - 1) / (per_block * r);      // <= 3B touched rows
@@ -1766,9 +1766,9 @@ extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, in
     const int64_t total = s0.n4 + s1.n4;
     int64_t blocks = (total + 255) / 256;
     // measured at S-TRAIN-XL (45 GB per launch): 2048 blocks 8.73 ms, 16384 blocks + nontemporal accesses 8.03 ms
-    static const int max_blocks = getenv("CRH_ADAM_BLOCKS") ? atoi(getenv("CRH_ADAM_BLOCKS")) : 16384;
+    static const int max_blocks = CRH_TUNE_ENV("CRH_ADAM_BLOCKS") ? atoi(CRH_TUNE_ENV("CRH_ADAM_BLOCKS")) : 16384;
     if (blocks > max_blocks) blocks = max_blocks;
-    static const int nt_mode = getenv("CRH_ADAM_NT") ? atoi(getenv("CRH_ADAM_NT")) : 1;
+    static const int nt_mode = CRH_TUNE_ENV("CRH_ADAM_NT") ? atoi(CRH_TUNE_ENV("CRH_ADAM_NT")) : 1;
     const int zg = (zero_grad ? 1 : 0) | ((nt_mode && total * 16 > ((int64_t)256 << 20)) ? 2 : 0);
     hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        s0, s1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/coldrec_hip.h"
 
@@ -41,12 +42,18 @@ __device__ __forceinline__ bool crh_better(float sa, int ia, float sb, int ib) {
 
 // Measurement hooks (parts of a kernel switched off, per-wave clocks) exist only in the -DCRH_PROFILE build that
 // tools/profile_*.sh load (make profile -> lib/libcoldrec_hip_profile.so); in the shipped library they fold to 0.
+// CRH_TUNE_ENV: tuning switches (thresholds, alternative schedules) that only the measurement build reads from the environment;
+// the shipped library compiles their defaults in (the few switches a user or a test can want stay plain getenv: CRH_SCORE_WG,
+// CRH_SCORE_DMA, CRH_SCORE_SEED, CRH_SCORE_SEED_MAX_ITEMS, CRH_SCORE_DENSE_BLOCK_MB, CRH_SPMM_SEG, CRH_SPMM_SLAB).
 #ifdef CRH_PROFILE
 #define CRH_ABLATE(x) (x)
 #define CRH_PROFILE_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#define CRH_TUNE_ENV(name) getenv(name)
 #else
 #define CRH_ABLATE(x) 0
 #define CRH_PROFILE_ENV(name) 0
+static inline const char* crh_no_env(const char*) { return nullptr; }
+#define CRH_TUNE_ENV(name) crh_no_env(name)
 #endif
 
 // One Adam step of one element, op for op what torch/optim/adam.py _single_tensor_adam does.  Shared by the

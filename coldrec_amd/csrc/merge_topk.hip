@@ -481,13 +481,13 @@ extern "C" int crh_mask_topk_f32(float* scores, int64_t n_users, int64_t n_items
     const size_t lds = (size_t)4 * (2 * k + 4) * 4;
     // 16-byte loads in flight per lane: NL = 4 (94 VGPRs, all 16 waves of a CU resident; 8 needs 134 VGPRs, loses a
     // quarter of the waves and runs the 4096 x 1 M block in 5.99 ms instead of 3.36)
-    static const int wpr_rows = getenv("CRH_MASK_WPR_ROWS") ? atoi(getenv("CRH_MASK_WPR_ROWS")) : 4096;
+    static const int wpr_rows = CRH_TUNE_ENV("CRH_MASK_WPR_ROWS") ? atoi(CRH_TUNE_ENV("CRH_MASK_WPR_ROWS")) : 4096;
 #define CRH_MASK_LAUNCH(W, B)                                                                                              \
     hipLaunchKernelGGL((mask_topk_kernel<W, 4>), dim3((unsigned)(B)), dim3(256), lds, st, scores, n_users, n_items, row_stride, \
                        rated_rowptr, rated_col, cand_bitmap, k, item_base, write_back, out_score, out_idx)
     // rows short enough for the insertions to be the cost (and any row of a read-only call up to the limit): chunks in
     // registers, masks first, lane-maximum threshold.  CRH_MASK_CHUNK_ITEMS = largest row that takes this kernel (0: off).
-    static const int64_t chunk_items = getenv("CRH_MASK_CHUNK_ITEMS") ? atoll(getenv("CRH_MASK_CHUNK_ITEMS")) : 65536;
+    static const int64_t chunk_items = CRH_TUNE_ENV("CRH_MASK_CHUNK_ITEMS") ? atoll(CRH_TUNE_ENV("CRH_MASK_CHUNK_ITEMS")) : 65536;
     if (!write_back && k <= 64 && n_items <= chunk_items && !(n_users < wpr_rows && n_items >= 8192)) {
 #ifndef CRH_CHUNK_NV
 #define CRH_CHUNK_NV 16          // 16-byte loads per lane and chunk; 8 (chunks of 2 048 items, 128 VGPRs at four waves) measured slower:

@@ -717,8 +717,8 @@ constexpr size_t DENSE_MAX_BLOCK = (size_t)8 << 30;
 // i.e. dense up to ~5e9 pairs per call; any user count up to 32 768 items (the trainers' validation shapes; with 8 GiB
 // blocks 262 144 / 524 288 users x 32 768 items run at 0.47 dense against 0.44 / 0.45 fused).
 size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
-    static const int64_t max_items = getenv("CRH_SCORE_DENSE_MAX_ITEMS") ? atoll(getenv("CRH_SCORE_DENSE_MAX_ITEMS")) : DENSE_MAX_ITEMS;
-    static const double max_pairs = getenv("CRH_SCORE_DENSE_MAX_PAIRS") ? atof(getenv("CRH_SCORE_DENSE_MAX_PAIRS")) : 5e9;
+    static const int64_t max_items = CRH_TUNE_ENV("CRH_SCORE_DENSE_MAX_ITEMS") ? atoll(CRH_TUNE_ENV("CRH_SCORE_DENSE_MAX_ITEMS")) : DENSE_MAX_ITEMS;
+    static const double max_pairs = CRH_TUNE_ENV("CRH_SCORE_DENSE_MAX_PAIRS") ? atof(CRH_TUNE_ENV("CRH_SCORE_DENSE_MAX_PAIRS")) : 5e9;
     if (n_items > max_items || (n_items > 32768 && (double)n_users * (double)n_items > max_pairs)) return 0;
     const size_t row = (size_t)((n_items + 31) / 32) * 32 * sizeof(float);
     const size_t all = (size_t)n_users * row;
@@ -740,7 +740,7 @@ size_t dense_block_bytes(int64_t n_users, int64_t n_items) {
 // best at its 8 192).
 int64_t seed_prefix_items(int64_t n_items, int64_t n_users) {
     if (n_items < 65536) return 0;
-    const char* pe = getenv("CRH_SCORE_SEED_ITEMS");                  // tuning hook (read per call)
+    const char* pe = CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS");                  // tuning hook (read per call)
     const bool few = n_users <= 16384;
     int64_t p = pe && atoll(pe) >= 1024 ? std::min<int64_t>(atoll(pe), n_items / 4) : n_items / (few ? 8 : 16);
     if (!pe) p = std::max<int64_t>(4096, std::min<int64_t>(n_users <= 4096 ? 65536 : (few ? 32768 : 16384), p));
@@ -789,7 +789,7 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     // The workgroup-cooperative kernel (8 waves share the packed item tiles through LDS) once there are enough
     // user groups to fill the CUs and the workspace holds the packed copy.  fp16: d = 64/128/256, 64 users per
     // wave.  fp32: d = 128 (64 users per wave; +1.5 % over the per-wave kernel and 1/8 of its L2 -> CU traffic).
-    static const int no_pack = getenv("CRH_SCORE_NO_PACK") ? atoi(getenv("CRH_SCORE_NO_PACK")) : 0;
+    static const int no_pack = CRH_TUNE_ENV("CRH_SCORE_NO_PACK") ? atoi(CRH_TUNE_ENV("CRH_SCORE_NO_PACK")) : 0;
     const int wg_mode = getenv("CRH_SCORE_WG") ? atoi(getenv("CRH_SCORE_WG")) : 1;   // per call: tests force 2
     const bool can_pack = !no_pack && has_workspace &&
                           workspace_bytes >= lists_bytes(n_users, k) + packed_bytes(n_items, d, esz);
@@ -827,7 +827,7 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     const int upw = use_dma ? 128 : (use_wg ? wg_upw : users_per_wave(esz, d));
     // two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured at fp32
     // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
-    static const int variant = getenv("CRH_SCORE_OCC") ? atoi(getenv("CRH_SCORE_OCC")) : 2;
+    static const int variant = CRH_TUNE_ENV("CRH_SCORE_OCC") ? atoi(CRH_TUNE_ENV("CRH_SCORE_OCC")) : 2;
     const int occ = esz == 2 ? 2 : ((variant == 2 && d == 128) ? 2 : 1);
     // Small catalogues (the trainers' per-epoch validation: a few thousand users x a few thousand items).  The fused
     // selection is built for catalogues where a candidate above the running threshold is rare; here every user takes
@@ -835,7 +835,7 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     // wave of 64 users being the critical path).  Instead: the same MFMA kernel writes its score tiles to a dense
     // block (bit-identical scores) and crh_mask_topk_f32 -- one wave per user, same masks, same canonical order --
     // ranks it; users go in chunks if the block would pass 8 GiB.  CRH_SCORE_DENSE=0 keeps the fused selection.
-    static const int dense_mode = getenv("CRH_SCORE_DENSE") ? atoi(getenv("CRH_SCORE_DENSE")) : 1;
+    static const int dense_mode = CRH_TUNE_ENV("CRH_SCORE_DENSE") ? atoi(CRH_TUNE_ENV("CRH_SCORE_DENSE")) : 1;
     const size_t dense_b = dense_block_bytes(n_users, n_items);
     r.dense = dense_mode && n_splits == 0 && !seeded && dense_b && has_workspace && workspace_bytes >= dense_b;
     r.use_wg = use_wg;
@@ -897,7 +897,7 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     // the workgroup kernels, stalls the whole CU: 9 % of the launch at 10 M items (profiles/r05_f16_*).  A 4 096-item prefix
     // takes k (1 + ln(P / k)) of every user's k (1 + ln(N / k)) events out of the stream: 282 -> 156 per user at 10 M items
     const bool f16_stream = !cuts && esz == 2 && d == 256 && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
-    if ((small_cat || f16_stream) && !getenv("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
+    if ((small_cat || f16_stream) && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
     if (!(cuts || small_cat || f16_stream || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
     return P;
 }
@@ -1057,7 +1057,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     int rc;
     // XCD soft lockstep (xcd_window_sync): only when every wave is resident at once (one round) and all waves
     // walk the same tile range (no item-range cuts); counters sit behind the packed copy in the workspace
-    static const int sync_win = getenv("CRH_SCORE_SYNC_WINDOW") ? atoi(getenv("CRH_SCORE_SYNC_WINDOW")) : 128;
+    static const int sync_win = CRH_TUNE_ENV("CRH_SCORE_SYNC_WINDOW") ? atoi(CRH_TUNE_ENV("CRH_SCORE_SYNC_WINDOW")) : 128;
     a.xcd_sync = nullptr;
     a.sync_window = sync_win;
     a.sync_stride = 0;

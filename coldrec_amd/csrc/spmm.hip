@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
 // later rounds fill the slots the early ones free (same shape: 1 row 141.6 us per step, 2 rows 142.1, 3 rows 154.5;
 // profiles/r03_lgcn_sweep1.log).  CRH_SPMM_ROWS forces a count.
 int64_t spmm_grid(SpmmArgs& a, int G) {
-    static const int force_rows = getenv("CRH_SPMM_ROWS") ? atoi(getenv("CRH_SPMM_ROWS")) : 0;
+    static const int force_rows = CRH_TUNE_ENV("CRH_SPMM_ROWS") ? atoi(CRH_TUNE_ENV("CRH_SPMM_ROWS")) : 0;
     const int64_t n_work = a.sched.n_seg > 0 ? a.sched.n_seg : a.n_rows;
     const int64_t heavy_blocks = a.sched.n_seg > 0 ? (int64_t)a.sched.n_multi : 0;
     const int rows_per_group = force_rows > 0 ? force_rows : 1;
@@ -445,7 +445,7 @@ namespace {
 // schedule (nnz >= 0), and only while re-reading the edge list once per slice stays below the operand.
 void spmm_shape(int64_t n_rows, int d, int64_t nnz, int* cs_out, int* g_out) {
     const int nvec = d / 4;
-    static const int force_cs = getenv("CRH_SPMM_SLICES") ? atoi(getenv("CRH_SPMM_SLICES")) : 0;
+    static const int force_cs = CRH_TUNE_ENV("CRH_SPMM_SLICES") ? atoi(CRH_TUNE_ENV("CRH_SPMM_SLICES")) : 0;
     int cs = 1;
     const double bytes = (double)n_rows * d * 4;
     if (nnz >= 0 && bytes > 3.0e6 && bytes <= 4 * 3.2e6) {
@@ -482,7 +482,7 @@ int spmm_run(const char* who, const int64_t* rowptr, const int32_t* col, const f
                       "%s: crh_spmm_sched.version = %d, this library reads layout %d (multi_count = n_sub | sub << 8)", who,
                       (int)sched->version, CRH_SPMM_SCHED_VERSION);
         a.sched = *sched;
-        static const int use_desc = getenv("CRH_SPMM_DESC") ? atoi(getenv("CRH_SPMM_DESC")) : 1;
+        static const int use_desc = CRH_TUNE_ENV("CRH_SPMM_DESC") ? atoi(CRH_TUNE_ENV("CRH_SPMM_DESC")) : 1;
         if (!use_desc) a.sched.seg_desc = nullptr;
     } else {
         a.sched.n_seg = 0;

@@ -526,6 +526,7 @@ class SpmmSchedule:
     so the order does not change any result."""
 
     SLAB_MAX_EDGES = 1 << 26          # the record stream is built for graphs up to this many stored edges
+    GIANT = 1024                      # heavy rows above this many edges are cut into 2 (above 4x: 4) column ranges; 0 = never
     SLAB_BUCKETS = 12                 # CRH_SPMM_SLAB_BUCKETS of include/coldrec_hip.h
 
     def __init__(self, rowptr, device, seg: Optional[int] = None, col=None, val=None):
@@ -545,7 +546,7 @@ class SpmmSchedule:
                 seg *= 4
         self.seg = int(seg)
         heavy = deg > seg
-        order = np.argsort(-deg, kind="stable") if os.environ.get("CRH_SPMM_SORT", "1") != "0" else np.arange(len(deg))
+        order = np.argsort(-deg, kind="stable")
         order = np.concatenate([order[~heavy[order]], order[heavy[order]]])
         seg_row = order.astype(np.int32)
         seg_slot = np.where(heavy[order], 0, -1).astype(np.int32)
@@ -553,8 +554,7 @@ class SpmmSchedule:
         # heavy rows: one entry per heavy BLOCK, longest rows first (they lead the grid: the longest chains start with the
         # first wave of workgroups).  Rows above GIANT edges are cut into 2 (4 above 4 * GIANT) column ranges of the slice,
         # one workgroup each with half (a quarter) of the lanes per lane group: multi_count = n_sub | sub << 8.
-        giant = int(os.environ.get("CRH_SPMM_GIANT", "1024"))
-        giant4 = int(os.environ.get("CRH_SPMM_GIANT4", str(4 * giant)))
+        giant, giant4 = self.GIANT, 4 * self.GIANT
         hrows = np.nonzero(heavy)[0]
         hrows = hrows[np.argsort(-deg[hrows], kind="stable")]
         n_sub = np.where(deg[hrows] > giant4, 4, np.where(deg[hrows] > giant, 2, 1)) if giant > 0 else np.ones(len(hrows), np.int64)

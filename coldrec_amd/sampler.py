@@ -172,7 +172,7 @@ class EpochPrefetcher:
         self._base = None          # NumPy state the outstanding epoch started from
         self._slot = None          # buffer slot of the outstanding epoch
         self._async = False
-        self.timing, self._t_sync = ([] if os.environ.get("CRH_PREFETCH_TIMING") else None), 0.0
+        self.timing, self._t_sync = None, 0.0        # set to [] to record (epoch, seconds waited for the sampler) pairs
         self._k = 0
         n = self.s.n_records
         self.device = None

@@ -265,7 +265,7 @@ def test_spmm_segment_schedule_on_skewed_graph(monkeypatch, giant):
     (4 above 4 * giant) column ranges with a workgroup each (giant = 200 exercises both cuts, 0 switches them off); the
     other rows are work items ordered by descending length."""
     from coldrec_amd import ops
-    monkeypatch.setenv("CRH_SPMM_GIANT", str(giant))
+    monkeypatch.setattr(ops.SpmmSchedule, "GIANT", giant)
     rng = np.random.default_rng(11)
     n_u, n_i, d = 3000, 500, 64
     w = 1.0 / np.arange(1, n_i + 1) ** 1.1
@@ -396,7 +396,7 @@ def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, 
     with pytest.raises(RuntimeError, match="version"):
         ops.spmm_csr(rp, cl, vl, tX, y=Ys, sched=slab)
     slab.c.version = _lib.SPMM_SCHED_VERSION
-    monkeypatch.setenv("CRH_SPMM_GIANT", "0")                           # and under another heavy-row layout
+    monkeypatch.setattr(ops.SpmmSchedule, "GIANT", 0)                   # and under another heavy-row layout
     again = ops.SpmmSchedule(rowptr, DEV, col=col, val=val)
     Y2 = torch.empty_like(tX)
     ops.spmm_csr(rp, cl, vl, tX, y=Y2, sched=again)
