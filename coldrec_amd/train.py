@@ -320,7 +320,8 @@ class LGCNEngine(_TableState):
         self.sched = self.k.SpmmSchedule(np.asarray(rowptr), dev, col=np.asarray(col), val=np.asarray(val))
         # bind the engine's device arrays to the schedule's record stream NOW (one checksum pass): the first launch may
         # already be inside a stream capture, where the check cannot run and the graph would keep the descriptor path
-        self.sched.for_launch(self.E.shape[0], self.E.shape[1], self.col, self.val)
+        if hasattr(self.sched, "for_launch"):              # (the CPU stand-in backend of the gloo tests has no record stream)
+            self.sched.for_launch(self.E.shape[0], self.E.shape[1], self.col, self.val)
         self.X = [torch.empty_like(self.E) for _ in range(2)]   # layer ping-pong
         self.OUT = torch.empty_like(self.E)                     # mean of the layer outputs
         self.dOUT = torch.zeros_like(self.E)
@@ -341,7 +342,8 @@ class LGCNEngine(_TableState):
         self.L = int(n_layers)
         self.rowptr, self.col, self.val = rowptr.contiguous(), col.contiguous(), val.contiguous()
         self.sched = self.k.SpmmSchedule(self.rowptr.cpu().numpy(), self.device, seg=seg, col=self.col, val=self.val)
-        self.sched.for_launch(self.E.shape[0], self.E.shape[1], self.col, self.val)      # eager binding (see __init__)
+        if hasattr(self.sched, "for_launch"):
+            self.sched.for_launch(self.E.shape[0], self.E.shape[1], self.col, self.val)  # eager binding (see __init__)
         self.X = [torch.empty_like(self.E) for _ in range(2)]
         self.OUT = torch.empty_like(self.E)
         self.dOUT = torch.zeros_like(self.E)
@@ -377,7 +379,7 @@ class LGCNEngine(_TableState):
         # "light" on the other would differ in its fp32 association
         self.rs_sched = self.k.SpmmSchedule(self.rs_rowptr.cpu().numpy(), dev, seg=self.sched.seg, col=self.rs_col,
                                              val=self.rs_val) if r1 > r0 else None
-        if self.rs_sched is not None:
+        if self.rs_sched is not None and hasattr(self.rs_sched, "for_launch"):
             self.rs_sched.for_launch(r1 - r0, d, self.rs_col, self.rs_val)               # eager binding (see __init__)
         self.rs = (rows, r0, r1)
         pad = G * rows
