@@ -31,7 +31,7 @@ def pmc(path):
     except (OSError, ValueError):
         return None
     for name, v in rec.items():
-        if "score_topk_wg_kernel" in name and ("F16" in name or "Float16" in name) and v.get("_Grid_Size") == 131072.0 \
+        if ("score_topk_dma_kernel" in name or "score_topk_wg_kernel" in name) and ("F16" in name or "Float16" in name) \
                 and v.get("_duration_ns", 0) > 1e9:                  # the 50 M-item launch, not the shard's
             cyc = v["GRBM_GUI_ACTIVE"] / XCDS
             busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc)
@@ -70,11 +70,12 @@ for key, f_leg, f_pmc in (("shipped", "f16_shipped.json", "profiles/%s_f16_pmc.j
         if p:
             entry["counters"] = p
     res[key] = entry
-ceil_same = max([b["frac"] for b in best.values() if "2 acc, A from LDS" in b["variant"] and "8 waves" in b["variant"]] or [None])
-ceil_128 = max([b["frac"] for b in best.values() if "4 acc, A from LDS" in b["variant"]] or [None])
+ceil_same = max([b["frac"] for b in best.values() if b["variant"] == "4 waves, 4 acc, A from LDS"] or [None])
+ceil_128 = max([b["frac"] for b in best.values() if b["variant"] == "4 waves, 4 acc, A in registers"] or [None])
 res["reading"] = {
-    "bare_loop_of_this_kernels_shape (8 waves, 2 accumulators, A from LDS)": ceil_same,
-    "bare_loop_128_users_per_wave (4 accumulators per A fragment)": ceil_128,
+    "bare_loop_of_this_kernels_shape (4 waves, 4 accumulators, A from LDS)": ceil_same,
+    "bare_loop_register_fed (4 waves, 4 accumulators, A in registers)": ceil_128,
+    "shipped_over_register_fed_bare_loop": (res["shipped"].get("frac_of_nominal_unprofiled") or 0) / ceil_128 if ceil_128 else None,
     "shipped_over_its_bare_loop": (res["shipped"].get("frac_of_nominal_unprofiled") or 0) / ceil_same if ceil_same else None,
     "ablated_over_its_bare_loop": (res["ablated_selection"].get("frac_of_nominal_unprofiled") or 0) / ceil_same if ceil_same else None,
 }

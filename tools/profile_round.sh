@@ -1,13 +1,14 @@
 #!/bin/bash
-# Round-4 profile (on the GPU box, from the repo root): bash tools/profile_round4.sh <tag> [parts]
+# One round's profile (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [parts]      e.g. r05_z "eval f16"
 #   parts: any of  eval f16 train xl mx  (default: all)
 #   eval   rocprofv3 kernel stats of the DEFAULT bench command (every leg) + separate PMC passes of the headline kernel
-#   f16    VERDICT r3 #5, the ceiling record of the fp16 scoring kernel: the bare MFMA(+LDS) loops on THIS box, the shipped
-#          kernel and the SAME kernel with the selection epilogue ablated (-DCRH_PROFILE build), each with
-#          SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (matrix-pipe occupancy and effective clock)
+#   f16    the ceiling record of the fp16 scoring kernel (configs[4]): the bare MFMA(+LDS) loops on THIS box, the shipped
+#          kernel and the SAME kernel with the selection ablated (-DCRH_PROFILE build), each with
+#          SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (matrix-pipe occupancy and effective clock); + the feature-ladder
+#          probe of the kernel's MFMA stream (tools/probes/dma_stream_probe.hip)
 #   train  kernel stats + FETCH / WRITE of the train legs;  xl / mx: S-TRAIN-XL LightGCN / BPR-MF steps likewise
 set -u
-TAG=${1:-r04_a}
+TAG=${1:-r05_a}
 PARTS=${2:-"eval f16 train xl mx"}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -32,6 +33,8 @@ if has f16; then
 # (a) bare loops on this box (tools/probes/mfma_energy_probe.hip; built here if the binary did not travel)
 [ -x tools/probes/mfma_energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_energy_probe tools/probes/mfma_energy_probe.hip
 $T ./tools/probes/mfma_energy_probe > "$OUT/f16_bare_loops.log" 2>&1
+[ -x tools/probes/dma_stream_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -mllvm -amdgpu-mfma-vgpr-form -o tools/probes/dma_stream_probe tools/probes/dma_stream_probe.hip
+$T ./tools/probes/dma_stream_probe > "$OUT/f16_stream_ladder.log" 2>&1
 # (b) the leg as shipped and with the selection ablated, un-profiled (wall numbers must not come from a profiled pass)
 F16="--no-cpu-baseline --no-verify --steps 1 --warmup 0 --legs eval_f16"
 PLIB=$PWD/coldrec_amd/lib/libcoldrec_hip_profile.so
