@@ -815,12 +815,13 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     const bool fp32_wg_ok = n_items >= 2000000 && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
     const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
                         (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
-    // 512-byte rows: the LDS-DMA form (four waves of 128 users, score_topk_dma_kernel).  CRH_SCORE_DMA (read per call):
-    // 0 never, 1 fp16 (default), 2 fp32 as well
+    // 512-byte rows (fp16 d=256, fp32 d=128): the LDS-DMA form (four waves of 128 users, score_topk_dma_kernel) wherever a
+    // workgroup kernel runs and k <= 20.  Same box, 131 072 x 10 M: fp16 0.577 vs 0.535 for the ring kernel, fp32 0.920 vs 0.910.
+    // CRH_SCORE_DMA (read per call): 0 never, anything else (default) on
     const int dma_mode = getenv("CRH_SCORE_DMA") ? atoi(getenv("CRH_SCORE_DMA")) : 1;
     const size_t dma_lds = score_dma_lds_bytes(d * esz, k);
     const size_t tb_off = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);   // the tiles' candidate bits
-    const bool use_dma = use_wg && dma_mode && d * esz == 512 && dma_lds <= 160 * 1024 && (esz == 2 || dma_mode == 2) &&
+    const bool use_dma = use_wg && dma_mode && d * esz == 512 && dma_lds <= 160 * 1024 &&
                          (!has_bitmap || workspace_bytes >= tb_off + tbits_bytes(n_items));
     const int wg_waves_l = use_dma ? 4 : wg_waves;                    // waves of the workgroup that is launched
     const int wg_slots_l = use_dma ? 256 : wg_slots;                  // ... and how many of them are resident per round

@@ -238,7 +238,16 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 #pragma unroll
     for (int q = 0; q < NCH; ++q)
 #pragma unroll
-        for (int u = 0; u < UW; ++u) asm volatile("" : "+a"(b[q][u]));
+        for (int u = 0; u < UW; ++u) {
+            if constexpr (sizeof(T) == 4) {     // fp32 MFMAs take ONE dword per operand: pinned as a 4-vector hipcc copies every
+                asm volatile("" : "+a"(b[q][u].x));   // component to a VGPR first (v_accvgpr_read per MFMA, 23 spills); as four
+                asm volatile("" : "+a"(b[q][u].y));   // scalars the MFMA reads a[N] directly
+                asm volatile("" : "+a"(b[q][u].z));
+                asm volatile("" : "+a"(b[q][u].w));
+            } else {
+                asm volatile("" : "+a"(b[q][u]));
+            }
+        }
 #endif
 
     const char* packed = reinterpret_cast<const char*>(a.packed);

@@ -74,8 +74,8 @@ def test_the_library_reports_its_route():
     dispatcher's own predicates), instead of re-deriving the dispatcher in Python.  Pinned here, on the CPU: the shapes of the
     bench line."""
     from coldrec_amd import ops
-    head = ops.score_topk_route(131072, 10_000_000, 128, 20)                 # the headline: 8-wave workgroups through the LDS ring
-    assert head["route"] == "fused-wg" and not head["seeded"] and head["kernel"] == "score_topk_wg_kernel" and head["n_splits"] == 1
+    head = ops.score_topk_route(131072, 10_000_000, 128, 20)                 # the headline: 4-wave workgroups fed by LDS-DMA
+    assert head["route"] == "fused-dma" and not head["seeded"] and head["kernel"] == "score_topk_dma_kernel" and head["n_splits"] == 1
     shard = ops.score_topk_route(131072, 1_250_000, 128, 20)                 # one rank's shard of the 8-GPU split: below the
     assert shard["route"] == "fused-wave" and shard["seeded"]                # 2 M-item gate -> per-wave kernel, seeded (4 096-item prefix)
     assert shard["prefix_items"] == 4096 and shard["kernel"] == "score_topk_kernel"
@@ -85,6 +85,7 @@ def test_the_library_reports_its_route():
     f16_shard = ops.score_topk_route(131072, 6_250_000, 256, 20, half=True)
     assert f16_shard["route"] == "fused-dma"
     assert ops.score_topk_route(131072, 50_000_000, 256, 21, half=True)["route"] == "fused-wg"   # k > 20: the lists leave no room for 4 slots
+    assert ops.score_topk_route(131072, 10_000_000, 128, 21)["route"] == "fused-wg"
     assert ops.score_topk_route(131072, 50_000_000, 256, 50, half=True)["route"] == "fused-wave"  # ... k = 50: nor for a workgroup's lists
     val = ops.score_topk_route(6040, 3706, 128, 20)                          # a trainer's validation block: dense block + ranking
     assert val["route"] == "dense" and val["n_splits"] == 1
