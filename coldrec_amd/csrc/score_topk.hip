@@ -191,23 +191,40 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     // per chunk).  Rows past the split end are clamped / padded: always a valid address.
     const int64_t T_all = (a.n_items + 31) >> 5;
     constexpr int QSTRIDE = PK ? 1024 : 32;    // bytes between this lane's consecutive chunks
-    auto tile_ptr = [&](int64_t t) -> const char* {
+    // A tile's address = a wave-uniform base (scalar registers) + a 32-bit lane offset: global_load's saddr form.  As one
+    // 64-bit pointer per lane it cost a register pair the 256-register budget of two waves per SIMD does not have (hipcc
+    // spilled it and reloaded it from scratch behind an s_waitcnt vmcnt(0) in front of EVERY tile: r04 kernel table, 24 B/lane).
+    auto tile_base = [&](int64_t t) -> const char* {
         if (CRH_ABLATE(a.ablate) & 2) t = 0;   // measurement only: every load hits the same (cached) tile
         if constexpr (PK) {
             if (t >= T_all) t = T_all - 1;
-            return reinterpret_cast<const char*>(a.packed) + (t * NCH * 64 + lane) * 16;
+            return reinterpret_cast<const char*>(a.packed) + t * (NCH * 1024);
         } else {
-            int64_t row = (t << 5) + i;
-            if (row >= split_end) row = split_end - 1;
-            return reinterpret_cast<const char*>(a.item_emb) + row * ROWB + 16 * h;
+            return reinterpret_cast<const char*>(a.item_emb) + (t << 5) * ROWB;
+        }
+    };
+    auto lane_off = [&](int64_t t) -> unsigned {
+        if constexpr (PK) {
+            unsigned o = (unsigned)lane * 16u;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(o));   // opaque per tile: keeps hipcc from folding it back into one hoisted 64-bit lane pointer
+#endif
+            return o;
+        } else {   // rows past the split end are clamped to its last row: always a valid address
+            if (CRH_ABLATE(a.ablate) & 2) t = 0;
+            const int64_t left = split_end - (t << 5);                 // wave-uniform, >= 1 for every tile of the split
+            const int row = left > i ? i : (int)(left > 0 ? left - 1 : 0);
+            return (unsigned)row * (unsigned)ROWB + 16u * (unsigned)h;
         }
     };
     auto load_tile = [&](f32x4(&dst)[NCH], int64_t t) {
-        const char* vp = tile_ptr(t);
+        const char* vp = tile_base(t);
+        const unsigned off = lane_off(t);
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) dst[q] = load16(vp + QSTRIDE * q);
+        for (int q = 0; q < NCH; ++q) dst[q] = load16(vp + QSTRIDE * q + off);
     };
-    auto do_tile = [&](f32x4(&src)[NCH], int64_t t, const char* vnext) {
+    unsigned long long slow_ticks = 0, slow_events = 0;   // profile build only (CRH_SCORE_TIMING)
+    auto do_tile = [&](f32x4(&src)[NCH], int64_t t, const char* vnext, unsigned off_next) {
         f32x16 acc[UW];
 #pragma unroll
         for (int u = 0; u < UW; ++u)
@@ -219,11 +236,11 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             if constexpr (SWAP && !PK) chunk_swap(c);   // packed tiles are stored in fragment order already
             Elem<T>::template mma<UW>(acc, c, b[q]);
             if (OCC > 1) {   // ring: the chunk just consumed is refilled with the next tile's rows
-                src[q] = load16(vnext + QSTRIDE * q);
+                src[q] = load16(vnext + QSTRIDE * q + off_next);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (CRH_ABLATE(a.ablate) & 1) {   // keep the products live, skip selection (roofline ablation, results invalid)
+        if ((CRH_ABLATE(a.ablate) & 1) && !a.dense) {   // keep the products live, skip selection (roofline ablation, results invalid)
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -239,7 +256,12 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             for (int u = 0; u < UW; ++u) {
                 const int64_t slot = ug * UPW + 32 * u + i;
                 if (slot < a.n_users) {
-                    float* row = a.dense + slot * a.dense_stride + (t << 5) + 4 * h;
+                    // uniform base + 32-bit lane offset (the dispatcher keeps 32 rows of the block under 4 GiB)
+                    unsigned ro = (unsigned)i * (unsigned)a.dense_stride + 4u * (unsigned)h;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(ro));   // see lane_off
+#endif
+                    float* row = a.dense + (ug * UPW + 32 * u) * a.dense_stride + (t << 5) + ro;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         *reinterpret_cast<f32x4*>(row + 8 * g) =
@@ -252,12 +274,17 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
             const float m = max16(acc[u]);
-            if (__ballot(m > tau[u]) != 0ull)
+            if (__ballot(m > tau[u]) != 0ull) {
+                unsigned long long c0 = 0;
+                if (CRH_ABLATE(a.wave_clock != nullptr)) c0 = wall_clock64();
                 tile_slow_path<UPW>(acc[u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a, t << 5, split_end,
-                                    lane);
+                                    lane, PK);
+                if (CRH_ABLATE(a.wave_clock != nullptr)) { slow_ticks += wall_clock64() - c0; ++slow_events; }
+            }
         }
     };
 
+    if (CRH_ABLATE(a.wave_clock != nullptr) && lane == 0) a.wave_clock[2 * (a.n_ugroups * S) + 2 * vb] = wall_clock64();
     if (t0 < t1) {
         if constexpr (OCC == 1) {
             f32x4 ta[NCH], tb[NCH];
@@ -265,11 +292,11 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             for (int64_t t = t0; t < t1; t += 2) {
                 load_tile(tb, t + 1);   // rows past the split end are clamped: always a valid address
                 __builtin_amdgcn_sched_barrier(0);
-                do_tile(ta, t, nullptr);
+                do_tile(ta, t, nullptr, 0u);
                 if (t + 1 >= t1) break;
                 load_tile(ta, t + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                do_tile(tb, t + 1, nullptr);
+                do_tile(tb, t + 1, nullptr, 0u);
             }
         } else {
             f32x4 ta[NCH];
@@ -288,12 +315,16 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
                                 __hip_atomic_fetch_add(sync_cnt + 1 + wdw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                do_tile(ta, t, tile_ptr(t + 1));
+                do_tile(ta, t, tile_base(t + 1), lane_off(t + 1));
             }
         }
     }
 
-    if (CRH_ABLATE(a.wave_clock != nullptr) && lane == 0) a.wave_clock[2 * vb + 1] = wall_clock64();
+    if (CRH_ABLATE(a.wave_clock != nullptr) && lane == 0) {
+        a.wave_clock[2 * (a.n_ugroups * S) + 2 * vb + 1] = wall_clock64();
+        a.wave_clock[4 * (a.n_ugroups * S) + 2 * vb] = slow_ticks;
+        a.wave_clock[4 * (a.n_ugroups * S) + 2 * vb + 1] = slow_events;
+    }
     if (a.dense) return;
     // ---- write this split's lists: [split][slot][k], padded with (-inf, PAD)
     for (int j = 0; j < UPW; ++j) {
@@ -307,6 +338,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         else
             wave_list_store(w.ls + j * K, w.li + j * K, n, K, a.out_score + o, a.out_idx + o, lane);
     }
+    if (CRH_ABLATE(a.wave_clock != nullptr) && lane == 0) a.wave_clock[2 * vb + 1] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -469,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void score_topk_wg_kernel(ScoreArg
                 const float m = max16(acc[tt][u]);
                 if (__ballot(m > tau[u]) != 0ull)
                     tile_slow_path<UPW>(acc[tt][u], tau[u], w, K, 32 * u, ug * UPW + 32 * u, a,
-                                        (t0 + j * TT + tt) << 5, split_end, lane);
+                                        (t0 + j * TT + tt) << 5, split_end, lane, true);
             }
     };
 
@@ -1010,6 +1042,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
         a.out_score = out_score;      // not written by the kernel on this route
         a.out_idx = out_idx;
         a.dense = reinterpret_cast<float*>(workspace);
+        CRH_CHECK_ARG(stride < ((int64_t)1 << 25), "%s: dense block rows of %lld scores exceed the kernel's 32-bit lane offsets", who, (long long)stride);
         a.dense_stride = stride;
         if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
         for (int64_t u0 = 0; u0 < n_users; u0 += chunk) {
@@ -1090,7 +1123,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 #ifdef CRH_PROFILE
     static const int timing = CRH_PROFILE_ENV("CRH_SCORE_TIMING");
     const int64_t n_waves = a.n_ugroups * a.n_splits;
-    if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 16));   // profile build only
+    if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 48));   // profile build only: [wave][start,end], [wave][loop start,end], [wave][event ticks,events]
     if (timing && use_dma) {   // DMA kernel: per-tile duration histograms of the first 16 workgroups' waves (64 buckets of 128 cycles)
         CRH_HIP(hipMalloc(&a.wave_clock, (size_t)16 * 4 * 64 * 8));
         CRH_HIP(hipMemsetAsync(a.wave_clock, 0, (size_t)16 * 4 * 64 * 8, st));
@@ -1132,9 +1165,11 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     }
     if (timing && !use_wg) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
         CRH_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)n_waves * 2);
+        std::vector<unsigned long long> h((size_t)n_waves * 6);
         CRH_HIP(hipMemcpy(h.data(), a.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));
         CRH_HIP(hipFree(a.wave_clock));
+        if (timing == 2)   // raw (start, end) pairs of the LAST launch, wave-major, for offline analysis
+            if (FILE* f = fopen("/tmp/crh_wave_clock.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         unsigned long long t0 = ~0ull, t1 = 0;
         for (int64_t wv = 0; wv < n_waves; ++wv) { t0 = std::min(t0, h[2 * wv]); t1 = std::max(t1, h[2 * wv + 1]); }
         std::vector<double> st_(n_waves), en_(n_waves);
@@ -1148,6 +1183,24 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
                 st_[3 * n_waves / 4] / tot, st_[n_waves - 1] / tot, en_[0] / tot, en_[n_waves / 10] / tot,
                 en_[n_waves / 4] / tot, en_[n_waves / 2] / tot, en_[3 * n_waves / 4] / tot, en_[9 * n_waves / 10] / tot,
                 en_[n_waves - 1] / tot);
+        // phases of a wave (medians, 10 ns ticks) and what its slow-path events took: [2n..4n) loop start/end, [4n..6n) ticks/events
+        std::vector<double> in_(n_waves), lp_(n_waves), so_(n_waves);
+        double ev_ticks = 0, ev = 0, lp_sum = 0;
+        for (int64_t wv = 0; wv < n_waves; ++wv) {
+            in_[wv] = (double)(h[2 * n_waves + 2 * wv] - h[2 * wv]);
+            lp_[wv] = (double)(h[2 * n_waves + 2 * wv + 1] - h[2 * n_waves + 2 * wv]);
+            so_[wv] = (double)(h[2 * wv + 1] - h[2 * n_waves + 2 * wv + 1]);
+            ev_ticks += (double)h[4 * n_waves + 2 * wv];
+            ev += (double)h[4 * n_waves + 2 * wv + 1];
+            lp_sum += lp_[wv];
+        }
+        std::sort(in_.begin(), in_.end());
+        std::sort(lp_.begin(), lp_.end());
+        std::sort(so_.begin(), so_.end());
+        fprintf(stderr, "[crh timing] median ticks: list setup %.0f, tile loop %.0f, list store %.0f; %.0f slow-path events per wave, "
+                        "%.0f ticks each = %.3f of the loop\n",
+                in_[n_waves / 2], lp_[n_waves / 2], so_[n_waves / 2], ev / (double)n_waves, ev > 0 ? ev_ticks / ev : 0.0,
+                lp_sum > 0 ? ev_ticks / lp_sum : 0.0);
     }
 #endif
     if (a.n_splits > 1)

@@ -202,10 +202,13 @@ __device__ __forceinline__ float pick16(const f32x16& v, int r) {
 template <int UPW>
 __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg, const WaveLds<UPW>& w,
                                                int K, int ucol0, int64_t slot0, const ScoreArgs& a,
-                                               int64_t item0, int64_t split_end, int lane) {
+                                               int64_t item0, int64_t split_end, int lane, bool rows_zeroed = false) {
     const int64_t g0 = a.item_base + item0;          // global id of the tile's first item
     unsigned blo = 0u, bhi = 0u;
-    if (a.bitmap) {
+    // rows_zeroed: the tiles come from the packed copy, whose bitmap-masked rows are zero (pack_row_masked): such an item
+    // scores exactly 0 and is a candidate only of a user whose threshold is negative.  No such user in this group of 32 =
+    // no masked candidate: the tile's bitmap window (a memory round trip on the event's critical path) is not needed.
+    if (a.bitmap && !(rows_zeroed && __ballot(tau_reg < 0.0f) == 0ull)) {
         const int64_t last = (a.item_base + a.n_items - 1) >> 5;
         const int64_t w0 = (g0 >> 5) < last ? (g0 >> 5) : last, w1 = w0 < last ? w0 + 1 : last;
         blo = a.bitmap[w0];
@@ -222,6 +225,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
     if (tau_reg > CRH_NEG_INF) cm &= ~m16;
     const unsigned bm = cm & m16;
     unsigned long long lanes = __ballot(cm != 0u);
+    const bool wide = K > 64;                         // lane t holds entries t and t + 64 of a list (k <= 128)
     while (lanes) {
         const int L = __builtin_ctzll(lanes);
         lanes &= lanes - 1;
@@ -241,29 +245,60 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
             // r is wave-uniform: pick the accumulator register with a select tree (static indices only),
             // then read lane L
             float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
+            // the user's threshold may have moved since the candidate masks were built (an earlier candidate of this event)
+            if (!(sc > __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tau_reg), jl)))) continue;
             const int gi = (int)(a.item_base + il);
-            // one batch of LDS reads: fill, tail entry, filter word
+            // ONE batch of LDS reads per candidate: fill, filter word and the whole list (entries past the fill are stale
+            // and overridden below); the insert position, the shifted entries and the user's new threshold all come out of
+            // these registers
             const unsigned hsh = rated_hash(gi);
             const int n_raw = w.cnt[ul];
-            const float ks_raw = lsu[K - 1];
-            const int ki_raw = liu[K - 1];
             const unsigned fw_raw = a.rated_rowptr ? w.rfilter[ul * 8 + (hsh >> 5)] : 0u;
-            const int n = __builtin_amdgcn_readfirstlane(n_raw);
-            if (n >= K) {
-                const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ks_raw)));
-                const int ki = __builtin_amdgcn_readfirstlane(ki_raw);
-                if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;   // cannot enter a full list
+            float es = CRH_NEG_INF, es2 = CRH_NEG_INF;
+            int ei = CRH_PAD_IDX, ei2 = CRH_PAD_IDX;
+            if (lane < K) {
+                es = lsu[lane];
+                ei = liu[lane];
             }
+            if (wide && lane + 64 < K) {
+                es2 = lsu[lane + 64];
+                ei2 = liu[lane + 64];
+            }
+            const int n = __builtin_amdgcn_readfirstlane(n_raw);
             bool masked = (bmL >> r) & 1u;
             if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u))
                 masked = wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, nullptr, lane);
             if (masked) sc = CRH_MASKED_SCORE;
-            wave_list_insert(lsu, liu, w.cnt + ul, K, sc, gi, lane);
+            int p = __popcll(__ballot(lane < n && crh_better(es, ei, sc, gi)));
+            if (wide) p += __popcll(__ballot(lane + 64 < n && crh_better(es2, ei2, sc, gi)));
+            if (p < K) {
+                // every shifted entry is in registers, so the stores cannot overtake a load
+                if (lane >= p && lane < n && lane + 1 < K) {
+                    lsu[lane + 1] = es;
+                    liu[lane + 1] = ei;
+                }
+                if (wide && lane + 64 >= p && lane + 64 < n && lane + 65 < K) {
+                    lsu[lane + 65] = es2;
+                    liu[lane + 65] = ei2;
+                }
+                const int n2 = n < K ? n + 1 : K;
+                if (lane == 0) {
+                    lsu[p] = sc;
+                    liu[p] = gi;
+                    w.cnt[ul] = n2;
+                }
+                if (n2 >= K) {   // full: the k-th entry is now the old (k-1)-th, or the candidate itself
+                    const int q = K >= 2 ? K - 2 : 0;
+                    const float prev = __builtin_bit_cast(float, q < 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, es), q)
+                                                                        : __builtin_amdgcn_readlane(__builtin_bit_cast(int, es2), q - 64));
+                    const float kth = (p == K - 1) ? sc : prev;
+                    // never above what a masked (-1e9) candidate could beat (wave_list_tau)
+                    if ((lane & 31) == jl) tau_reg = kth >= CRH_MASKED_SCORE ? kth : CRH_NEG_INF;
+                }
+            }
         }
     }
-    const int my = ucol0 + (lane & 31);
-    // a padding column (slot past the block) never takes a candidate: +inf keeps it out of the threshold ballot
-    tau_reg = slot0 + (lane & 31) < a.n_users ? wave_list_tau(w.ls + my * K, w.cnt[my], K) : __builtin_inff();
+    // (no read-back of the thresholds: every insert updated its user's lanes; padding columns keep their +inf)
 }
 
 // Soft lockstep of the waves of one XCD.  Every wave streams the same item tiles, but left alone the waves
