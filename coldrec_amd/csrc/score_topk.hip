@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void tile_bits_kernel(const uint32_t* __restri
 //   1: two register tiles (A double-buffered), ~320 VGPR+AGPR, one wave per SIMD;
 //   2: one register tile reloaded chunk by chunk right behind its last use, <= 256 registers, so a
 //      second wave on the SIMD fills the matrix pipe while this one selects / waits / inserts.
-template <typename T, int D, int UW, int OCC, bool PK>
+// DN = a block launch (small catalogues and the seed prefix): the tile goes to a.dense, no lists.  Its own instantiation: in one
+// body with the selection the staging code's registers pushed a spill into the slow path of the two-waves-per-SIMD kernels.
+template <typename T, int D, int UW, int OCC, bool PK, bool DN>
 __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
     constexpr int WPW = 1;
     constexpr int ROWB = D * (int)sizeof(T);   // bytes per table row
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
 
     WaveLds<UPW> w;
     wave_lds_carve<UPW>(w, smem + (size_t)wave * wave_lds_bytes<UPW>(K), K);
-    wave_lds_init<UPW>(w, a, ug * UPW, (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end), a.dense == nullptr, lane);
+    // (a block launch keeps no lists: nothing to stage)
+    if constexpr (!DN) wave_lds_init<UPW>(w, a, ug * UPW, (int)(a.item_base + (t0 << 5)), (int)(a.item_base + split_end), true, lane);
 
     // ---- hot user block -> registers (B fragments, already pair-swapped)
     f32x4 b[NCH][UW];
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if ((CRH_ABLATE(a.ablate) & 1) && !a.dense) {   // keep the products live, skip selection (roofline ablation, results invalid)
+        if ((CRH_ABLATE(a.ablate) & 1) && !DN) {   // keep the products live, skip selection (roofline ablation, results invalid)
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -249,13 +252,14 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             }
             return;
         }
-        if (a.dense) {
+        if constexpr (DN) {
             // small catalogue: the tile goes to memory as it is.  acc[r] = item row (r&3) + 8*(r>>2) + 4h of user
-            // column i: four 16-B pieces per lane, columns 8g + 4h .. +3 of the tile
+            // column i: four 16-B pieces per lane, columns 8g + 4h .. +3 of the tile.  (Turned through LDS so that a store
+            // writes whole 128-B rows it ran 3-6 % slower at the validation shapes: the stores are ~10 % of a block launch.)
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
                 const int64_t slot = ug * UPW + 32 * u + i;
-                if (slot < a.n_users) {
+                if (slot < a.n_users && (!(CRH_ABLATE(a.ablate) & 8) || acc[u][0] == 123.f)) {   // (8: measurement only, no block stores)
                     // uniform base + 32-bit lane offset (the dispatcher keeps 32 rows of the block under 4 GiB)
                     unsigned ro = (unsigned)i * (unsigned)a.dense_stride + 4u * (unsigned)h;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -324,8 +328,9 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         a.wave_clock[2 * (a.n_ugroups * S) + 2 * vb + 1] = wall_clock64();
         a.wave_clock[4 * (a.n_ugroups * S) + 2 * vb] = slow_ticks;
         a.wave_clock[4 * (a.n_ugroups * S) + 2 * vb + 1] = slow_events;
+        if (DN) a.wave_clock[2 * vb + 1] = wall_clock64();
     }
-    if (a.dense) return;
+    if constexpr (DN) return;
     // ---- write this split's lists: [split][slot][k], padded with (-inf, PAD)
     for (int j = 0; j < UPW; ++j) {
         const int64_t slot = ug * UPW + j;
@@ -587,21 +592,22 @@ int launch_score_wg(const ScoreArgs& a, hipStream_t stream) {
     return CRH_OK;
 }
 
-template <typename T, int D, int UW, int OCC, bool PK>
+template <typename T, int D, int UW, int OCC, bool PK, bool DN>
 int launch_score_pk(const ScoreArgs& a, hipStream_t stream);
 
 template <typename T, int D, int UW, int OCC>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
-    if (a.packed) return launch_score_pk<T, D, UW, OCC, true>(a, stream);
-    return launch_score_pk<T, D, UW, OCC, false>(a, stream);
+    if (a.dense) return a.packed ? launch_score_pk<T, D, UW, OCC, true, true>(a, stream) : launch_score_pk<T, D, UW, OCC, false, true>(a, stream);
+    if (a.packed) return launch_score_pk<T, D, UW, OCC, true, false>(a, stream);
+    return launch_score_pk<T, D, UW, OCC, false, false>(a, stream);
 }
 
-template <typename T, int D, int UW, int OCC, bool PK>
+template <typename T, int D, int UW, int OCC, bool PK, bool DN>
 int launch_score_pk(const ScoreArgs& a, hipStream_t stream) {
     constexpr int UPW = 32 * UW;
     constexpr int WPW = 1;
-    const size_t lds = wave_lds_bytes<UPW>(a.k) * WPW;
-    auto kern = score_topk_kernel<T, D, UW, OCC, PK>;
+    const size_t lds = DN ? 0 : wave_lds_bytes<UPW>(a.k) * WPW;   // (a block launch keeps no lists)
+    auto kern = score_topk_kernel<T, D, UW, OCC, PK, DN>;
     if (lds > 64 * 1024)
         CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -977,6 +983,51 @@ int score_topk_any(int esz, const void* user_emb, const int32_t* users, int64_t 
                            ev_kernel_stop, who, nullptr, nullptr);
 }
 
+#ifdef CRH_PROFILE
+// CRH_SCORE_TIMING (profile build): per-wave start/end distribution of a per-wave-kernel launch (100 MHz wall clock), its phases
+// and what its slow-path events took, printed to stderr; dev = [wave][start,end], [wave][loop start,end], [wave][event ticks,events]
+int print_wave_timing(unsigned long long* dev, int64_t n_waves, int timing, hipStream_t st) {
+        CRH_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)n_waves * 6);
+        CRH_HIP(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
+        CRH_HIP(hipFree(dev));
+        if (timing == 2)   // raw (start, end) pairs of the LAST launch, wave-major, for offline analysis
+            if (FILE* f = fopen("/tmp/crh_wave_clock.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int64_t wv = 0; wv < n_waves; ++wv) { t0 = std::min(t0, h[2 * wv]); t1 = std::max(t1, h[2 * wv + 1]); }
+        std::vector<double> st_(n_waves), en_(n_waves);
+        for (int64_t wv = 0; wv < n_waves; ++wv) { st_[wv] = (double)(h[2 * wv] - t0); en_[wv] = (double)(h[2 * wv + 1] - t0); }
+        std::sort(st_.begin(), st_.end());
+        std::sort(en_.begin(), en_.end());
+        const double tot = (double)(t1 - t0);
+        fprintf(stderr, "[crh timing] waves=%lld span=%.0f ticks; start quantiles 0/25/50/75/100%%: %.3f %.3f %.3f %.3f %.3f; "
+                        "end quantiles 0/10/25/50/75/90/100%%: %.3f %.3f %.3f %.3f %.3f %.3f %.3f (fraction of span)\n",
+                (long long)n_waves, tot, st_[0] / tot, st_[n_waves / 4] / tot, st_[n_waves / 2] / tot,
+                st_[3 * n_waves / 4] / tot, st_[n_waves - 1] / tot, en_[0] / tot, en_[n_waves / 10] / tot,
+                en_[n_waves / 4] / tot, en_[n_waves / 2] / tot, en_[3 * n_waves / 4] / tot, en_[9 * n_waves / 10] / tot,
+                en_[n_waves - 1] / tot);
+        // phases of a wave (medians, 10 ns ticks) and what its slow-path events took: [2n..4n) loop start/end, [4n..6n) ticks/events
+        std::vector<double> in_(n_waves), lp_(n_waves), so_(n_waves);
+        double ev_ticks = 0, ev = 0, lp_sum = 0;
+        for (int64_t wv = 0; wv < n_waves; ++wv) {
+            in_[wv] = (double)(h[2 * n_waves + 2 * wv] - h[2 * wv]);
+            lp_[wv] = (double)(h[2 * n_waves + 2 * wv + 1] - h[2 * n_waves + 2 * wv]);
+            so_[wv] = (double)(h[2 * wv + 1] - h[2 * n_waves + 2 * wv + 1]);
+            ev_ticks += (double)h[4 * n_waves + 2 * wv];
+            ev += (double)h[4 * n_waves + 2 * wv + 1];
+            lp_sum += lp_[wv];
+        }
+        std::sort(in_.begin(), in_.end());
+        std::sort(lp_.begin(), lp_.end());
+        std::sort(so_.begin(), so_.end());
+        fprintf(stderr, "[crh timing] median ticks: list setup %.0f, tile loop %.0f, list store %.0f; %.0f slow-path events per wave, "
+                        "%.0f ticks each = %.3f of the loop\n",
+                in_[n_waves / 2], lp_[n_waves / 2], so_[n_waves / 2], ev / (double)n_waves, ev > 0 ? ev_ticks / ev : 0.0,
+                lp_sum > 0 ? ev_ticks / lp_sum : 0.0);
+    return CRH_OK;
+}
+#endif
+
 int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t n_users, const void* item_emb,
                     int64_t n_items, int d, const int64_t* rated_rowptr, const int32_t* rated_col,
                     const uint32_t* cand_bitmap, int k, int64_t item_base, float* out_score, int32_t* out_idx,
@@ -1039,6 +1090,9 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
         a.sync_window = 0;
         a.sync_stride = 0;
         a.wave_clock = nullptr;
+#ifdef CRH_PROFILE
+        static const int timing_d = CRH_PROFILE_ENV("CRH_SCORE_TIMING");
+#endif
         a.out_score = out_score;      // not written by the kernel on this route
         a.out_idx = out_idx;
         a.dense = reinterpret_cast<float*>(workspace);
@@ -1055,8 +1109,20 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
             // fill the wave slots of the chip once
             a.n_splits = (int)std::max<int64_t>(1, std::min<int64_t>(T, (1024 * occ) / a.n_ugroups));
             a.rated_rowptr = rated_rowptr ? rated_rowptr + u0 : nullptr;
+#ifdef CRH_PROFILE
+            if (timing_d) {
+                CRH_HIP(hipMalloc(&a.wave_clock, (size_t)a.n_ugroups * a.n_splits * 48));
+                CRH_HIP(hipMemsetAsync(a.wave_clock, 0, (size_t)a.n_ugroups * a.n_splits * 48, st));
+            }
+#endif
             const int rc1 = launch_score_per_wave(esz, d, occ, a, st);
             if (rc1 != CRH_OK) return rc1;
+#ifdef CRH_PROFILE
+            if (timing_d) {
+                const int trc = print_wave_timing(a.wave_clock, a.n_ugroups * a.n_splits, timing_d, st);
+                if (trc != CRH_OK) return trc;
+            }
+#endif
             const int rc2 = crh_mask_topk_f32(a.dense, cu, n_items, stride, a.rated_rowptr, rated_col, cand_bitmap, k,
                                               item_base, 0, out_score + u0 * k, out_idx + u0 * k, stream);
             if (rc2 != CRH_OK) return rc2;
@@ -1163,44 +1229,9 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
             fprintf(stderr, "\n");
         }
     }
-    if (timing && !use_wg) {   // per-wave start/end distribution (100 MHz wall clock), printed to stderr
-        CRH_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)n_waves * 6);
-        CRH_HIP(hipMemcpy(h.data(), a.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));
-        CRH_HIP(hipFree(a.wave_clock));
-        if (timing == 2)   // raw (start, end) pairs of the LAST launch, wave-major, for offline analysis
-            if (FILE* f = fopen("/tmp/crh_wave_clock.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (int64_t wv = 0; wv < n_waves; ++wv) { t0 = std::min(t0, h[2 * wv]); t1 = std::max(t1, h[2 * wv + 1]); }
-        std::vector<double> st_(n_waves), en_(n_waves);
-        for (int64_t wv = 0; wv < n_waves; ++wv) { st_[wv] = (double)(h[2 * wv] - t0); en_[wv] = (double)(h[2 * wv + 1] - t0); }
-        std::sort(st_.begin(), st_.end());
-        std::sort(en_.begin(), en_.end());
-        const double tot = (double)(t1 - t0);
-        fprintf(stderr, "[crh timing] waves=%lld span=%.0f ticks; start quantiles 0/25/50/75/100%%: %.3f %.3f %.3f %.3f %.3f; "
-                        "end quantiles 0/10/25/50/75/90/100%%: %.3f %.3f %.3f %.3f %.3f %.3f %.3f (fraction of span)\n",
-                (long long)n_waves, tot, st_[0] / tot, st_[n_waves / 4] / tot, st_[n_waves / 2] / tot,
-                st_[3 * n_waves / 4] / tot, st_[n_waves - 1] / tot, en_[0] / tot, en_[n_waves / 10] / tot,
-                en_[n_waves / 4] / tot, en_[n_waves / 2] / tot, en_[3 * n_waves / 4] / tot, en_[9 * n_waves / 10] / tot,
-                en_[n_waves - 1] / tot);
-        // phases of a wave (medians, 10 ns ticks) and what its slow-path events took: [2n..4n) loop start/end, [4n..6n) ticks/events
-        std::vector<double> in_(n_waves), lp_(n_waves), so_(n_waves);
-        double ev_ticks = 0, ev = 0, lp_sum = 0;
-        for (int64_t wv = 0; wv < n_waves; ++wv) {
-            in_[wv] = (double)(h[2 * n_waves + 2 * wv] - h[2 * wv]);
-            lp_[wv] = (double)(h[2 * n_waves + 2 * wv + 1] - h[2 * n_waves + 2 * wv]);
-            so_[wv] = (double)(h[2 * wv + 1] - h[2 * n_waves + 2 * wv + 1]);
-            ev_ticks += (double)h[4 * n_waves + 2 * wv];
-            ev += (double)h[4 * n_waves + 2 * wv + 1];
-            lp_sum += lp_[wv];
-        }
-        std::sort(in_.begin(), in_.end());
-        std::sort(lp_.begin(), lp_.end());
-        std::sort(so_.begin(), so_.end());
-        fprintf(stderr, "[crh timing] median ticks: list setup %.0f, tile loop %.0f, list store %.0f; %.0f slow-path events per wave, "
-                        "%.0f ticks each = %.3f of the loop\n",
-                in_[n_waves / 2], lp_[n_waves / 2], so_[n_waves / 2], ev / (double)n_waves, ev > 0 ? ev_ticks / ev : 0.0,
-                lp_sum > 0 ? ev_ticks / lp_sum : 0.0);
+    if (timing && !use_wg) {
+        const int trc = print_wave_timing(a.wave_clock, n_waves, timing, st);
+        if (trc != CRH_OK) return trc;
     }
 #endif
     if (a.n_splits > 1)
