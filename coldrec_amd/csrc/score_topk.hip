@@ -739,6 +739,10 @@ int launch_score_per_wave(int esz, int d, int occ, const ScoreArgs& a, hipStream
     }
 }
 
+// fp32 catalogues from here on take a workgroup kernel (when the users fill its 512-user workgroups), shorter ones the per-wave
+// kernel with seeded lists.  Same box, 131 072 users, seeded per-wave / workgroup (LDS-DMA): 2 M items 0.888 / 0.864 (unseeded),
+// 3 M 0.8835 / 0.8952 (seeded), 4 M 0.8876 / 0.9052, 10 M 0.898 (unseeded) / 0.9285.
+constexpr int64_t FP32_WG_MIN_ITEMS = 2500000;
 // Small and mid-size blocks are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any).
 constexpr int64_t DENSE_MAX_ITEMS = 262144;
 // users go in chunks when the block would exceed this: 8 GiB (1 GiB chunks ran the same shapes at 0.37-0.43 of the MFMA peak
@@ -846,11 +850,10 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     const int wg_slots = wg_waves == 8 ? 256 : 512;                   // workgroups resident per round
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
     // fp32: the lockstep of 8 waves makes every slow-path event a stall of the whole CU, so the workgroup kernel only
-    // pays on long streams (>= 2 M items: 0.852 vs 0.845 of peak at 2 M, 0.912 vs 0.891 at 10 M; at 262 144 items the
-    // per-wave kernel is 0.705 vs 0.655) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
+    // pays on long streams (FP32_WG_MIN_ITEMS) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
     // at 0.33 against 0.60 per wave)
     const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
-    const bool fp32_wg_ok = n_items >= 2000000 && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
+    const bool fp32_wg_ok = n_items >= FP32_WG_MIN_ITEMS && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
     const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
                         (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
     // 512-byte rows (fp16 d=256, fp32 d=128): the LDS-DMA form (four waves of 128 users, score_topk_dma_kernel) wherever a
@@ -931,13 +934,18 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     const int64_t n_ug = (n_users + upw - 1) / upw;
     const bool cuts = pick_splits(n_ug, n_items, 2) > 1;
     const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
-    const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : (int64_t)1999999);
+    const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : FP32_WG_MIN_ITEMS - 1);
     // fp16, 512-byte rows (configs[4]): at 16x the fp32 MFMA rate a slow-path event costs as much as a whole tile and, in
     // the workgroup kernels, stalls the whole CU: 9 % of the launch at 10 M items (profiles/r05_f16_*).  A 4 096-item prefix
     // takes k (1 + ln(P / k)) of every user's k (1 + ln(N / k)) events out of the stream: 282 -> 156 per user at 10 M items
     const bool f16_stream = !cuts && esz == 2 && d == 256 && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
+    // fp32, 512-byte rows on the workgroup kernels (the headline): the same, worth less at the fp32 rate -- 131 072 x 3 M 0.883 ->
+    // 0.895, x 4 M 0.895 -> 0.905, x 10 M 0.9245 -> 0.9285 (16 384-item prefix; 4 096 / 8 192 at 10 M: +0.35 / +0.38 %).  8 192 items
+    // keep the prefix's score block (4.3 GB at 131 072 users) inside what the packed copy of such a shard takes anyway
+    const bool f32_stream = !cuts && esz == 4 && d == 128 && n_users >= 32768 && n_items >= FP32_WG_MIN_ITEMS;
     if ((small_cat || f16_stream) && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
-    if (!(cuts || small_cat || f16_stream || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
+    if (f32_stream && !small_cat && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 8192) P = 8192;
+    if (!(cuts || small_cat || f16_stream || f32_stream || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
     return P;
 }
 

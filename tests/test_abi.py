@@ -48,9 +48,10 @@ def test_workspace_query_follows_the_route_of_the_call():
     L = _lib.lib()
     GiB = float(1 << 30)
     lists = 64 * 131072 * 20 * 8
-    # headline: fused, never seeded -> partial lists + packed copy (+ lockstep counters), nothing else
+    # headline: fused, lists seeded from an 8 192-item prefix whose 4 GiB score block fits where the packed copy goes afterwards
+    # -> partial lists + packed copy (+ lockstep counters, tile bits) + the seed lists, nothing else
     head = L.crh_score_topk_workspace_bytes(131072, 10_000_000, 128, 20)
-    assert lists + 10_000_000 * 128 * 4 <= head <= lists + 10_000_032 * 128 * 4 + (4 << 20)
+    assert lists + 10_000_000 * 128 * 4 <= head <= lists + 10_000_032 * 128 * 4 + (4 << 20) + 131072 * 20 * 8 + 256
     # 131 072 x 262 144: seeded with the clamped prefix: 131 072 x 4 096 x 4 B = 2 GiB of stage-1 block, not 8 GiB
     assert L.crh_score_topk_workspace_bytes(131072, 262144, 128, 20) <= 2.1 * GiB
     assert L.crh_score_topk_workspace_bytes(131072, 1_250_000, 128, 20) <= 2.1 * GiB
@@ -75,9 +76,10 @@ def test_the_library_reports_its_route():
     bench line."""
     from coldrec_amd import ops
     head = ops.score_topk_route(131072, 10_000_000, 128, 20)                 # the headline: 4-wave workgroups fed by LDS-DMA
-    assert head["route"] == "fused-dma" and not head["seeded"] and head["kernel"] == "score_topk_dma_kernel" and head["n_splits"] == 1
+    assert head["route"] == "fused-dma" and head["kernel"] == "score_topk_dma_kernel" and head["n_splits"] == 1
+    assert head["seeded"] and head["prefix_items"] == 8192                   # (lists seeded from an 8 192-item prefix: round 5)
     shard = ops.score_topk_route(131072, 1_250_000, 128, 20)                 # one rank's shard of the 8-GPU split: below the
-    assert shard["route"] == "fused-wave" and shard["seeded"]                # 2 M-item gate -> per-wave kernel, seeded (4 096-item prefix)
+    assert shard["route"] == "fused-wave" and shard["seeded"]                # 2.5 M-item gate -> per-wave kernel, seeded (4 096-item prefix)
     assert shard["prefix_items"] == 4096 and shard["kernel"] == "score_topk_kernel"
     assert shard["code"] != head["code"]
     f16 = ops.score_topk_route(131072, 50_000_000, 256, 20, half=True)       # configs[4]: the LDS-DMA workgroup kernel
