@@ -202,8 +202,9 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
         if constexpr (PK) {
             if (t >= T_all) t = T_all - 1;
             return reinterpret_cast<const char*>(a.packed) + t * (NCH * 1024);
-        } else {
-            return reinterpret_cast<const char*>(a.item_emb) + (t << 5) * ROWB;
+        } else {   // (the tile fetched ahead of the split's last one: clamped to it -- always a valid address)
+            const int64_t t_last = (split_end - 1) >> 5;
+            return reinterpret_cast<const char*>(a.item_emb) + ((t < t_last ? t : t_last) << 5) * ROWB;
         }
     };
     auto lane_off = [&](int64_t t) -> unsigned {
@@ -215,8 +216,9 @@ __global__ __launch_bounds__(64, OCC) void score_topk_kernel(ScoreArgs a) {
             return o;
         } else {   // rows past the split end are clamped to its last row: always a valid address
             if (CRH_ABLATE(a.ablate) & 2) t = 0;
-            const int64_t left = split_end - (t << 5);                 // wave-uniform, >= 1 for every tile of the split
-            const int row = left > i ? i : (int)(left > 0 ? left - 1 : 0);
+            const int64_t t_last = (split_end - 1) >> 5;
+            const int64_t left = split_end - ((t < t_last ? t : t_last) << 5);   // wave-uniform, >= 1
+            const int row = left > i ? i : (int)(left - 1);
             return (unsigned)row * (unsigned)ROWB + 16u * (unsigned)h;
         }
     };

@@ -245,8 +245,10 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
             // r is wave-uniform: pick the accumulator register with a select tree (static indices only),
             // then read lane L
             float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
-            // the user's threshold may have moved since the candidate masks were built (an earlier candidate of this event)
-            if (!(sc > __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tau_reg), jl)))) continue;
+            // the user's threshold may have moved since the candidate masks were built (an earlier candidate of this event).
+            // Strictly below it = out; a TIE is decided by the ids further down: within a tile the candidates of a user do not
+            // come in id order (rows 0-3, 8-11, ... of one half-wave, then 4-7, 12-15, ... of the other)
+            if (sc < __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tau_reg), jl))) continue;
             const int gi = (int)(a.item_base + il);
             // ONE batch of LDS reads per candidate: fill, filter word and the whole list (entries past the fill are stale
             // and overridden below); the insert position, the shifted entries and the user's new threshold all come out of
@@ -265,6 +267,13 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
                 ei2 = liu[lane + 64];
             }
             const int n = __builtin_amdgcn_readfirstlane(n_raw);
+            if (n >= K) {   // full list: the candidate must beat its last entry under the canonical key
+                const int q1 = K - 1;
+                const float ks = __builtin_bit_cast(float, q1 < 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, es), q1)
+                                                                   : __builtin_amdgcn_readlane(__builtin_bit_cast(int, es2), q1 - 64));
+                const int ki = q1 < 64 ? __builtin_amdgcn_readlane(ei, q1) : __builtin_amdgcn_readlane(ei2, q1 - 64);
+                if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;
+            }
             bool masked = (bmL >> r) & 1u;
             if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u))
                 masked = wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, nullptr, lane);

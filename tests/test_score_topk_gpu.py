@@ -127,6 +127,20 @@ def test_adversarial_orders_and_ties():
     Vq = rng.integers(-2, 3, (5000, 8)).astype(np.float32) / 4
     for splits in (1, 4, 9):
         _same(_gpu_score_topk(Uq, None, Vq, 20, n_splits=splits), _oracle(Uq, None, Vq, 20))
+    # a tie at the k-th place INSIDE one tile: a lane holds rows 0-3, 8-11, ... of a 32-row tile, its partner in the other
+    # half-wave rows 4-7, 12-15, ..., so a user's candidates of one tile are not met in id order -- item 104 enters first,
+    # item 100 (same score) must still displace it (a fuzz case of round 5: the threshold re-check inside an event was strict)
+    for k in (2, 20):
+        Vt = np.zeros((4096, 32), np.float32)
+        Vt[:k, 0] = 1.0                                   # fills every list
+        for t in range(3, 120, 7):                        # tiles with (top, tie, tie) at rows 0, 8, 4 and again at 16+
+            Vt[32 * t + 0, 0] = 3.0 + t
+            Vt[32 * t + 8, 0] = Vt[32 * t + 4, 0] = 2.0 + t
+            Vt[32 * t + 27, 0] = Vt[32 * t + 21, 0] = Vt[32 * t + 18, 0] = 2.0 + t
+        Ut = np.zeros((70, 32), np.float32)
+        Ut[:, 0] = 1.0
+        for splits in (0, 1, 3):
+            _same(_gpu_score_topk(Ut, None, Vt, k, n_splits=splits), _oracle(Ut, None, Vt, k))
     # all scores equal (zeros): the k lowest indices
     Z = np.zeros((5, 16), np.float32)
     s, i = _gpu_score_topk(Z, None, np.zeros((300, 16), np.float32), 20)
