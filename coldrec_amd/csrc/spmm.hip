@@ -395,6 +395,12 @@ template <int G>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(SpmmArgs a) {
     spmm_body<G>(a);
 }
+// The same body under its own name when the optimiser rides in the epilogue (crh_spmm_csr_adam_f32 / _sgd_f32): the launch also
+// reads and writes p, m, v, and a profile that averages both flavours under one name describes neither.
+template <int G>
+__global__ __launch_bounds__(256) void spmm_csr_opt_kernel(SpmmArgs a) {
+    spmm_body<G>(a);
+}
 
 // Grid of a launch (sets use_slab / light_blocks in `a`; a.cs and a.sched must be final).
 // Rows per lane group.  Rounds 1-2 took the smallest count (up to 4) that made the whole launch resident at once, because
@@ -420,7 +426,8 @@ int64_t spmm_grid(SpmmArgs& a, int G) {
 template <int G>
 int launch_spmm(SpmmArgs a, hipStream_t st) {
     const int64_t grid = spmm_grid(a, G);
-    hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    if (a.adam_p) hipLaunchKernelGGL(spmm_csr_opt_kernel<G>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(spmm_csr_kernel<G>, dim3((unsigned)grid), dim3(256), 0, st, a);
     CRH_HIP(hipGetLastError());
     return CRH_OK;
 }
