@@ -211,7 +211,8 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         tr = None
         if layers:
             tr = measured_traffic("spmm_csr_kernel<8>", None)
-            what = "spmm_csr_kernel<8> (FETCH_SIZE x2 + WRITE_SIZE) per launch; a step has %d such launches" % (2 * layers)
+            what = ("spmm_csr_kernel<8> (FETCH_SIZE x2 + WRITE_SIZE) per launch; a step has %d such launches + one "
+                    "spmm_csr_opt_kernel<8> (the last backward product, optimiser in its epilogue: its own profile row)" % (2 * layers - 1))
         elif getattr(eng, "fused", False):
             tr = measured_traffic("mf_step_kernel<32, %d>" % (1 if optim == "sgd" else 0), float(ops_parts(n_u + n_i, d) * 256))
             what = "mf_step_kernel<32> = the whole step (FETCH_SIZE x2 + WRITE_SIZE); it keeps no gradient table"
