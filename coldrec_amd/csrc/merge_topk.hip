@@ -356,8 +356,14 @@ __global__ __launch_bounds__(256, CRH_CHUNK_OCC) void mask_topk_chunk_kernel(con
             }
             // one threshold for both tests of a candidate, v >= tau0 (the chunk's bound) and v > tau (strict: the list's k-th
             // score): v > tau <=> v >= the next float above tau (-FLT_MAX for tau = -inf), and both are wave-uniform.  Items past
-            // the row's end were loaded as -inf and stay below it.
-            const float thr = fmaxf(order_key_inv(cur), order_key_inv(order_key(tau) + 1u));
+            // the row's end were loaded as -inf and stay below it.  The edges of "next float" (ADVICE r4): a zero threshold is
+            // taken as +0.0 whatever its sign (the successor of -0.0 is +0.0, and v >= +0.0 would admit every zero of a row of
+            // cold items -- more candidates than lanes, one by one -- where v > 0 admits none); fp32 denormals are kept by this
+            // build, so the successor of +0.0 (the smallest denormal) compares as it should; nothing is above +inf (its
+            // successor is a NaN that fmaxf would drop).  Ties that slip through are re-filtered by crh_better either way.
+            if (tau == __builtin_inff()) continue;
+            const float tau_c = tau == 0.0f ? 0.0f : tau;
+            const float thr = fmaxf(order_key_inv(cur), order_key_inv(order_key(tau_c) + 1u));
             // The chunk's candidates (>= tau0, and > the list's k-th score: list entries come from earlier chunks, i.e. lower
             // ids) are compacted into LDS; if they and the list fit one entry per lane, the new list is a RANK SORT of the
             // union -- every lane counts the entries that beat its own (canonical order, ids are distinct) and stores it at

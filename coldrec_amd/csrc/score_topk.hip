@@ -788,6 +788,9 @@ int64_t seed_prefix_items(int64_t n_items, int64_t n_users) {
     const bool few = n_users <= 16384;
     int64_t p = pe && atoll(pe) >= 1024 ? std::min<int64_t>(atoll(pe), n_items / 4) : n_items / (few ? 8 : 16);
     if (!pe) p = std::max<int64_t>(4096, std::min<int64_t>(n_users <= 4096 ? 65536 : (few ? 32768 : 16384), p));
+    // the longer prefixes of small user blocks are worth 0.6-2 % of the peak: not more than 1 GiB of stage-1 score block for
+    // them (a trainer keeps the workspace resident beside its training state)
+    while (!pe && p > 16384 && (size_t)n_users * (size_t)p * sizeof(float) > ((size_t)1 << 30)) p >>= 1;
     return p & ~(int64_t)31;
 }
 size_t seed_bytes(int64_t n_users, int k) { return (((size_t)n_users * k * 8) + 255) & ~(size_t)255; }

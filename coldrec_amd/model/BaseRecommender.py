@@ -209,9 +209,19 @@ class BaseColdStartTrainer(ABC):
             return c, np.zeros((0, self.max_N), np.float32), np.zeros((0, self.max_N), np.int32)
         return c, s.cpu().numpy(), i.cpu().numpy()
 
-    def _topk_device(self, data_set: Dict, data_type: str):
-        """(cache, scores (n,k), internal item ids (n,k)) as device tensors; (cache, None, None) for an empty split."""
-        c = self._get_eval_cache(data_set, data_type)
+    def invalidate_eval_cache(self):
+        """Drop the per-dataset evaluation arrays.  The cache entry of a ground-truth dict stands while its user and pair COUNTS
+        are unchanged (the reference re-reads the dict at every evaluation); a plugin that swaps users or items in place with
+        the same counts calls this."""
+        self._eval_cache.clear()
+        if hasattr(self.data, 'truth_csr_invalidate'):
+            self.data.truth_csr_invalidate()
+
+    def _topk_device(self, data_set: Dict, data_type: str, c=None):
+        """(cache, scores (n,k), internal item ids (n,k)) as device tensors; (cache, None, None) for an empty split.
+        c: the cache entry when the caller already looked it up (the lookup walks the dict: O(users) of Python)."""
+        if c is None:
+            c = self._get_eval_cache(data_set, data_type)
         if len(c['users']) == 0:        # an empty warm / cold / valid split: the reference reports zeros, no kernel runs
             return c, None, None
         fused = self.fused_eval
@@ -297,7 +307,7 @@ class BaseColdStartTrainer(ABC):
         t0 = self._tick('_before', time.perf_counter())
         c = self._get_eval_cache(data_set, data_type)
         t0 = self._tick('cache_s', t0)
-        c, _s, i = self._topk_device(data_set, data_type)
+        c, _s, i = self._topk_device(data_set, data_type, c)
         t0 = self._tick('rank_s', t0)
         if self.eval_timing is not None:
             self.eval_timing['last_topk'] = (_s, i)

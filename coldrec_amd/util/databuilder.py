@@ -149,6 +149,10 @@ class ColdStartDataBuilder(object):
             return None
         return hit[1]
 
+    def truth_csr_invalidate(self):
+        """Forget the arrays of this builder's valid / test dicts (BaseColdStartTrainer.invalidate_eval_cache)."""
+        self._truth_csr.clear()
+
     # ------------------------------------------------------------------ id mapping
     def _map(self, table: Dict[int, int], ids, what: str) -> np.ndarray:
         ids = np.asarray(ids).reshape(-1)

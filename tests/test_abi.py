@@ -55,6 +55,9 @@ def test_workspace_query_follows_the_route_of_the_call():
     # 131 072 x 262 144: seeded with the clamped prefix: 131 072 x 4 096 x 4 B = 2 GiB of stage-1 block, not 8 GiB
     assert L.crh_score_topk_workspace_bytes(131072, 262144, 128, 20) <= 2.1 * GiB
     assert L.crh_score_topk_workspace_bytes(131072, 1_250_000, 128, 20) <= 2.1 * GiB
+    # few users: the longer prefixes (32 768 / 65 536 items) stop at 1 GiB of stage-1 block: 16 384 users keep 16 384 items
+    GiB1 = 1 << 30
+    assert L.crh_score_topk_workspace_bytes(16384, 1_000_000, 128, 20) <= GiB1 + 1_000_032 * 128 * 4 + 64 * 16384 * 20 * 8 + (8 << 20)
     # fp16 (config 5 shape): the user block fills the chip and nothing is cut, but at 16x the MFMA rate the slow-path events
     # are worth removing: a 4 096-item prefix seeds the lists (round 5) -> the prefix's 2 GiB score block, not more
     f16 = L.crh_score_topk_f16_workspace_bytes(131072, 50_000_000, 256, 20)

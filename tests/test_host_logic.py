@@ -336,6 +336,9 @@ def test_builder_truth_csr_equals_the_dict_walk(name):
     assert d.truth_csr_cached(s) is None                       # an item added to one user's truth
     del s[u0][-12345]
     assert s[u0].get(it0) == 1.0 and d.truth_csr_cached(s) is not None
+    # same-count in-place swaps are not detected by the (users, pairs) fingerprint: the documented hook drops the arrays
+    d.truth_csr_invalidate()
+    assert d.truth_csr_cached(s) is None
     # duplicates and interleaved users
     p = np.array([[5, 9], [3, 9], [5, 7], [5, 9], [3, 1], [5, 7], [4, 9]], np.int64)
     import types

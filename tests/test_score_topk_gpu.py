@@ -262,6 +262,32 @@ def test_mask_topk_register_chunk_kernel(n_users, n_items, base, k, mask_frac):
     np.testing.assert_array_equal(tS.cpu().numpy(), S)            # read-only call left the block alone
 
 
+@pytest.mark.parametrize("zero", [0.0, -0.0])
+def test_mask_topk_rows_of_exact_zeros(zero):
+    """rows dominated by exact zeros of either sign (cold items with all-zero embeddings): once the list's k-th score
+    is a zero, no later zero may enter (ties lose to lower ids) -- the chunk kernel's "next float above tau" threshold must not
+    admit them by the thousand.  A few positives (fewer than k), a few negatives, three chunks."""
+    from coldrec_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    n_users, n_items, k = 40, 9000, 20
+    S = np.full((n_users, n_items), zero, np.float32)
+    for u in range(n_users):
+        S[u, rng.choice(n_items, 7, replace=False)] = rng.random(7).astype(np.float32) + 0.5
+        S[u, rng.choice(n_items, 50, replace=False)] = -1.0
+        S[u, rng.choice(n_items, 30, replace=False)] = -zero            # the other zero mixed in
+    rated = [np.unique(rng.integers(0, n_items, 15)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    bm = np.where(rng.random(n_items) < 0.1)[0]
+    srp, src = orc.sort_rated(rowptr, col)
+    ws, wi = orc.mask_topk(S.copy(), k, rowptr, col, orc.make_bitmap(n_items, bm), write_back=False)
+    ds, di = ops.mask_topk(torch.from_numpy(S.copy()).to(dev), k, torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev),
+                           ops.make_bitmap(n_items, bm, dev), write_back=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(di.cpu().numpy(), wi) and np.array_equal(ds.cpu().numpy(), ws)      # (values: -0.0 == 0.0)
+
+
 def test_full_size_properties_eval_config():
     """BASELINE config 4 shape on one GPU, scaled to what a test may take: 4096 users x 1M items,
     d=128.  Size-independent properties: (1) independent of the item-range split count,
