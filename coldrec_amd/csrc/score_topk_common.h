@@ -213,6 +213,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
         const int64_t w0 = (g0 >> 5) < last ? (g0 >> 5) : last, w1 = w0 < last ? w0 + 1 : last;
         blo = a.bitmap[w0];
         bhi = a.bitmap[w1];
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // landed HERE, inside the branch: a wait behind the join would be paid by every event (see below)
     }
     unsigned cm = 0;
 #pragma unroll
@@ -275,8 +276,14 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
                 if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;
             }
             bool masked = (bmL >> r) & 1u;
-            if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u))
+            if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u)) {
                 masked = wave_is_masked_at(gi, w.rlo[ul], w.rhi[ul], a.rated_col, nullptr, lane);
+                // every load of the search has landed before the loop goes round: otherwise hipcc, seeing a load that may still
+                // be pending on some exit, guards the next candidate's registers with s_waitcnt vmcnt(0) -- and vmcnt counts in
+                // order, so EVERY event then waited for the next tile's whole prefetch (16 loads issued a moment ago): ~2 of an
+                // event's ~3 us
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+            }
             if (masked) sc = CRH_MASKED_SCORE;
             int p = __popcll(__ballot(lane < n && crh_better(es, ei, sc, gi)));
             if (wide) p += __popcll(__ballot(lane + 64 < n && crh_better(es2, ei2, sc, gi)));
