@@ -461,7 +461,7 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
 @pytest.mark.parametrize("dtype,n_items,n_splits,k", [("f16", 200_003, 1, 20), ("f16", 200_003, 0, 20), ("f16", 70_001, 2, 50),
                                                      ("f32", 200_003, 1, 20), ("f32", 70_001, 3, 20)])
 def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits, k, monkeypatch):
-    """The LDS-DMA workgroup kernel (512-byte rows: fp16 d=256 by default, fp32 d=128 with CRH_SCORE_DMA=2) against the
+    """The LDS-DMA workgroup kernel (512-byte rows: fp16 d=256, fp32 d=128) against the
     register-staged ring kernel (CRH_SCORE_DMA=0) on thousands of tiles with continuous embeddings: every list of every
     user bit-identical (a tile read before its DMA landed, or overwritten while a slower wave still reads it, shows up
     here), plus sampled users against the oracle."""
@@ -481,7 +481,7 @@ def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits
     rp, rc = torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev)
     bm = ops.make_bitmap(n_items, cold, dev)
     monkeypatch.setenv("CRH_SCORE_WG", "2")
-    monkeypatch.setenv("CRH_SCORE_DMA", "2")
+    monkeypatch.setenv("CRH_SCORE_DMA", "1")
     s1, i1 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
     monkeypatch.setenv("CRH_SCORE_DMA", "0")
     s0, i0 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
