@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP scoring/top-k path, called through
 the C ABI, against the CPU oracle (bit-exact scores and indices) and against the golden
 vectors captured from the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -699,3 +701,20 @@ def test_seeded_route_for_users_that_fill_the_chip_on_a_catalogue_below_2_20_ite
     ws, wi = orc.score_topk(U.cpu().numpy(), pick.astype(np.int64), V.cpu().numpy(), k, sub_rp, sub_col,
                             orc.make_bitmap(n_items, cold))
     assert np.array_equal(i0.cpu().numpy()[pick], wi) and np.array_equal(s0.cpu().numpy()[pick].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed,wg", [(77, "2"), (5, None)])
+def test_fuzzer_short_run(seed, wg):
+    """Half a minute of tests/fuzz/fuzz_score_topk.py per arm inside the suite (round 5: both regressions of the slow-path /
+    addressing rewrite -- a strict tie re-check, a fetch one tile past the last split -- were found by it, none by the fixed
+    cases above): seed 77 under CRH_SCORE_WG=2 met the tie case at its 252nd draw."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if wg:
+        env["CRH_SCORE_WG"] = wg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_score_topk.py"), "--minutes", "0.5", "--seed", str(seed)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-1500:])
+
