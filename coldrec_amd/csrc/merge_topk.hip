@@ -299,33 +299,41 @@ __global__ __launch_bounds__(256, CRH_CHUNK_OCC) void mask_topk_chunk_kernel(con
                     for (int c = 0; c < 4; ++c) v[u][c] = e0 + c < n_items ? srow[e0 + c] : CRH_NEG_INF;
                 }
             }
+            // What the mask pass of this chunk will want is requested NOW, beside the row's scores: the chunk's bitmap words and
+            // the next 64 ids of the rated list.  A row is one latency chain per wave (a validation block is ONE chunk per row,
+            // one row per wave): asked for one after the other -- list bounds, scores, bitmap words, rated ids -- the chain was
+            // four memory round trips long, now two.  (A chunk that turns out to need no masks has fetched 0.8 KB beside its 16.)
+            const int64_t g0 = item_base + base;              // global id of the chunk's first item
+            constexpr int WJ = (WORDS + 63) / 64;
+            unsigned blo[WJ], bhi[WJ];
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+                const int64_t wi = (g0 >> 5) + lane + 64 * j;
+                blo[j] = bitmap && lane + 64 * j < WORDS && wi <= last_word ? bitmap[wi] : 0u;
+                bhi[j] = bitmap && lane + 64 * j < WORDS && wi + 1 <= last_word ? bitmap[wi + 1] : 0u;
+            }
+            const int64_t rp_pre = rp;
+            const int cid_pre = rp + lane < rhi ? rated_col[rp + lane] : 0;
             float m = CRH_NEG_INF;
 #pragma unroll
             for (int u = 0; u < NV; ++u) m = fmaxf(m, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
             // masking only lowers a score (to -1e9 <= a finite tau): a chunk whose raw maximum cannot beat the list is done
             if (__ballot(m > tau) == 0ull) continue;
             if (have_masks) {
-                const int64_t g0 = item_base + base;              // global id of the chunk's first item
 #pragma unroll
-                for (int j = 0; j < (WORDS + 63) / 64; ++j) {
+                for (int j = 0; j < WJ; ++j) {
                     const int w = lane + 64 * j;
                     if (w >= WORDS) break;
-                    unsigned word = 0;
-                    if (bitmap) {
-                        const int64_t wi = (g0 >> 5) + w;
-                        const unsigned lo = wi <= last_word ? bitmap[wi] : 0u;
-                        const unsigned hi = wi + 1 <= last_word ? bitmap[wi + 1] : 0u;
-                        const int sh = (int)(g0 & 31);
-                        word = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-                    }
-                    bm[w] = word;
+                    const int sh = (int)(g0 & 31);
+                    bm[w] = sh ? (blo[j] >> sh) | (bhi[j] << (32 - sh)) : blo[j];
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (rp < rhi) {
                     const int64_t g1 = g0 + CH;
                     for (;;) {
                         const int64_t e = rp + lane;
-                        const int64_t cid = e < rhi ? (int64_t)rated_col[e] : ((int64_t)1 << 62);   // past the end: never behind
+                        const int64_t cid = e >= rhi ? ((int64_t)1 << 62)                            // past the end: never behind
+                                                     : (int64_t)(rp == rp_pre ? cid_pre : rated_col[e]);
                         if (cid >= g0 && cid < g1) atomicOr(&bm[(cid - g0) >> 5], 1u << ((cid - g0) & 31));
                         const int behind = __popcll(__ballot(cid < g1));
                         rp += behind;
