@@ -1235,9 +1235,10 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
             std::vector<unsigned long long> b(64, 0);
             for (int blk = 0; blk < 16; ++blk)
                 for (int q = 0; q < 64; ++q) b[q] += h[((size_t)blk * 4 + wv) * 64 + q];
-            for (int q = 0; q < 64; ++q) { tot += b[q]; wsum += b[q] * (unsigned long long)(q * 128 + 64); }
-            fprintf(stderr, "[crh dma timing] wave %d: %llu tiles, mean %.0f cycles; histogram (128-cycle buckets from 0):", wv, tot,
-                    tot ? (double)wsum / (double)tot : 0.0);
+            const unsigned long long bw = esz == 4 ? 512 : 128;     // bucket width in cycles per tile
+            for (int q = 0; q < 64; ++q) { tot += b[q]; wsum += b[q] * (q * bw + bw / 2); }
+            fprintf(stderr, "[crh dma timing] wave %d: %llu tiles, mean %.0f cycles; histogram (%llu-cycle buckets from 0):", wv, tot,
+                    tot ? (double)wsum / (double)tot : 0.0, bw);
             for (int q = 0; q < 64; ++q) fprintf(stderr, " %llu", b[q]);
             fprintf(stderr, "\n");
         }

@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
             if (a.wave_clock != nullptr && blockIdx.x < 16) {
                 const unsigned long long t_now = __builtin_amdgcn_s_memtime();
                 if (j >= 64 && lane == 0) {
-                    unsigned long long dt = (t_now - t_prev) >> 8;      // two tiles per trip: 256-cycle units = 128 per tile
+                    // two tiles per trip: 256-cycle units = 128 per tile (fp16); fp32 tiles are 4x as long: 512 per tile
+                    unsigned long long dt = (t_now - t_prev) >> (sizeof(T) == 4 ? 10 : 8);
                     if (dt > 63) dt = 63;
                     atomicAdd(&a.wave_clock[((size_t)blockIdx.x * 4 + wave) * 64 + dt], 1ull);
                 }
