@@ -377,11 +377,12 @@ __global__ __launch_bounds__(256, CRH_CHUNK_OCC) void mask_topk_chunk_kernel(con
             // union -- every lane counts the entries that beat its own (canonical order, ids are distinct) and stores it at
             // that rank -- instead of one wave-serial insertion per candidate.
             {
+                // (the launch is instruction-bound: a candidate's slot = running count + v_mbcnt of the ballot, clamped to the
+                // last slot instead of tested -- beyond 64 candidates the slots are not used, see below)
                 int nc = 0;
-                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int id0 = (int)(item_base + base) + lane * 4;
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
-                    const int64_t e0 = base + u * 256 + lane * 4;
                     const float mu = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
                     if (__ballot(mu >= thr) == 0ull) continue;
                     const float vc[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
@@ -390,11 +391,10 @@ __global__ __launch_bounds__(256, CRH_CHUNK_OCC) void mask_topk_chunk_kernel(con
                         const bool pr = vc[c] >= thr;
                         const unsigned long long bal = __ballot(pr);
                         if (pr) {
-                            const int pos = nc + __popcll(bal & lt);
-                            if (pos < 64) {
-                                cs[pos] = vc[c];
-                                ci[pos] = (int)(item_base + e0 + c);
-                            }
+                            const int pos = min(nc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)), 63);
+                            cs[pos] = vc[c];
+                            ci[pos] = id0 + u * 256 + c;
                         }
                         nc += __popcll(bal);
                     }
@@ -413,11 +413,16 @@ __global__ __launch_bounds__(256, CRH_CHUNK_OCC) void mask_topk_chunk_kernel(con
                         ms = cs[lane - n];
                         mi = ci[lane - n];
                     }
+                    // crh_better as ONE unsigned 64-bit compare: (order key of the score, zeros of either sign alike) above the
+                    // complemented id -- half the instructions of the three-compare form in the launch's longest loop
+                    const unsigned long long mykey =
+                        ((unsigned long long)order_key(ms == 0.0f ? 0.0f : ms) << 32) | (unsigned)(0x7fffffff - mi);
+                    const unsigned klo = (unsigned)mykey, khi = (unsigned)(mykey >> 32);
                     int rank = 0;
                     for (int j = 0; j < tot_n; ++j) {
-                        const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), j));
-                        const int ij = __builtin_amdgcn_readlane(mi, j);
-                        rank += crh_better(sj, ij, ms, mi) ? 1 : 0;
+                        const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, j) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readlane((int)klo, j);
+                        rank += kj > mykey ? 1 : 0;
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (lane < tot_n && rank < K) {
