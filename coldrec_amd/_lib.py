@@ -97,8 +97,6 @@ SIGNATURES = {
     "crh_sampler_set_state": (_i32, [_vp, _vp, _i32]),
     "crh_sampler_get_state": (_i32, [_vp, _vp, _vp]),
     "crh_sampler_num_records": (_i64, [_vp]),
-    "crh_sampler_get_order": (_i32, [_vp, _vp]),
-    "crh_sampler_set_order": (_i32, [_vp, _vp]),
     "crh_sampler_snapshot": (_i32, [_vp]),
     "crh_sampler_restore": (_i32, [_vp]),
     "crh_sampler_epoch": (_i32, [_vp, _i64, _vp, _vp, _vp]),

@@ -333,27 +333,6 @@ extern "C" int crh_sampler_restore(crh_sampler* s) {
     return CRH_OK;
 }
 
-// The cumulative permutation of the records (what np.random.shuffle(data.training_data) has done so far), so that the
-// host sampler and the device sampler (sampler_dev.hip) can hand an epoch sequence over to each other.
-extern "C" int crh_sampler_get_order(const crh_sampler* s, int32_t* order_out_host) {
-    CRH_CHECK_ARG(s && order_out_host, "crh_sampler_get_order: NULL pointer");
-    memcpy(order_out_host, s->order.data(), s->order.size() * sizeof(int32_t));
-    return CRH_OK;
-}
-
-extern "C" int crh_sampler_set_order(crh_sampler* s, const int32_t* order_host) {
-    CRH_CHECK_ARG(s && order_host, "crh_sampler_set_order: NULL pointer");
-    const size_t n = s->order.size();
-    std::vector<uint8_t> seen(n, 0);
-    for (size_t k = 0; k < n; ++k) {
-        const int32_t r = order_host[k];
-        CRH_CHECK_ARG(r >= 0 && (size_t)r < n && !seen[r], "crh_sampler_set_order: not a permutation of the records");
-        seen[r] = 1;
-    }
-    memcpy(s->order.data(), order_host, n * sizeof(int32_t));
-    return CRH_OK;
-}
-
 extern "C" int64_t crh_sampler_num_records(const crh_sampler* s) { return s ? (int64_t)s->order.size() : -1; }
 
 // One epoch: all batches concatenated (the last one is short).  Output arrays hold n_records int32.

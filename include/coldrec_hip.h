@@ -449,10 +449,6 @@ int64_t crh_sampler_num_records(const crh_sampler* s);
 int crh_sampler_epoch_async(crh_sampler* s, int64_t batch_size, int32_t* user_out_host, int32_t* pos_out_host,
                             int32_t* neg_out_host, int snapshot_first);   /* != 0: crh_sampler_snapshot on the worker first */
 int crh_sampler_epoch_wait(crh_sampler* s);
-/* the cumulative permutation of the records so far (n_records int32): a second sampler object (or a caller's own sampler)
- * continues this one's epoch sequence from it */
-int crh_sampler_get_order(const crh_sampler* s, int32_t* order_out_host);
-int crh_sampler_set_order(crh_sampler* s, const int32_t* order_host);
 /* save / bring back everything an epoch call advances (generators + cumulative permutation): speculative sampling */
 int crh_sampler_snapshot(crh_sampler* s);
 int crh_sampler_restore(crh_sampler* s);
