@@ -46,8 +46,6 @@ SIGNATURES = {
     "crh_bpr_workspace_bytes": (_sz, [_i64]),
     "crh_bpr_plan_ints": (_i64, [_i64]),
     "crh_bpr_heavy_threshold": (_i32, []),
-    "crh_bpr_plan_heavy_workspace_bytes": (_sz, [_i64]),
-    "crh_bpr_plan_heavy_lists": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp]),
     "crh_bpr_plan_build_host": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "crh_bpr_plan_build": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "crh_bpr_plan_build_large_workspace_bytes": (_sz, [_i64, _i64]),
@@ -96,7 +94,6 @@ SIGNATURES = {
     "crh_sampler_seed": (_i32, [_vp, ctypes.c_uint32]),
     "crh_sampler_set_state": (_i32, [_vp, _vp, _i32]),
     "crh_sampler_get_state": (_i32, [_vp, _vp, _vp]),
-    "crh_sampler_num_records": (_i64, [_vp]),
     "crh_sampler_snapshot": (_i32, [_vp]),
     "crh_sampler_restore": (_i32, [_vp]),
     "crh_sampler_epoch": (_i32, [_vp, _i64, _vp, _vp, _vp]),

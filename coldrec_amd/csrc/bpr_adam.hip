@@ -1471,11 +1471,11 @@ extern "C" int64_t crh_bpr_plan_ints(int64_t batch) { return batch > 0 ? plan_in
 extern "C" int crh_bpr_heavy_threshold(void) { return BPR_HEAVY; }
 
 // (Re)build the heavy-row lists of n_batches plans whose header and row lists are in place.
-extern "C" size_t crh_bpr_plan_heavy_workspace_bytes(int64_t n_batches) {
+static size_t crh_bpr_plan_heavy_workspace_bytes(int64_t n_batches) {   // (internal: crh_bpr_plan_build_large)
     return n_batches > 0 ? (size_t)n_batches * HV_BLOCKS * sizeof(int32_t) : 0;
 }
 
-extern "C" int crh_bpr_plan_heavy_lists(int32_t* plans, int64_t n_batches, int64_t layout_batch, void* workspace,
+static int crh_bpr_plan_heavy_lists(int32_t* plans, int64_t n_batches, int64_t layout_batch, void* workspace,
                                         size_t workspace_bytes, void* stream) {
     CRH_CHECK_ARG(plans && n_batches > 0 && n_batches <= 65535 && layout_batch > 0, "crh_bpr_plan_heavy_lists: bad arguments");
     if (!workspace || workspace_bytes < crh_bpr_plan_heavy_workspace_bytes(n_batches)) {

@@ -333,8 +333,6 @@ extern "C" int crh_sampler_restore(crh_sampler* s) {
     return CRH_OK;
 }
 
-extern "C" int64_t crh_sampler_num_records(const crh_sampler* s) { return s ? (int64_t)s->order.size() : -1; }
-
 // One epoch: all batches concatenated (the last one is short).  Output arrays hold n_records int32.
 extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host,
                                  int32_t* pos_out_host, int32_t* neg_out_host) {

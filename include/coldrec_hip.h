@@ -166,11 +166,6 @@ int crh_merge_topk(const float* in_score, const int32_t* in_idx, int n_lists, in
 size_t crh_bpr_workspace_bytes(int64_t batch);
 int64_t crh_bpr_plan_ints(int64_t batch);
 int crh_bpr_heavy_threshold(void);   /* a row with more entries than this is on the plan's heavy list */
-/* (re)build the heavy-row lists of n_batches device plans whose header and row lists are in place (plans built
- * outside crh_bpr_plan_build, e.g. batches beyond its LDS sort) */
-size_t crh_bpr_plan_heavy_workspace_bytes(int64_t n_batches);
-int crh_bpr_plan_heavy_lists(int32_t* plans, int64_t n_batches, int64_t layout_batch, void* workspace,
-                             size_t workspace_bytes, void* stream);
 int crh_bpr_plan_build_host(const int32_t* user_idx_host, const int32_t* pos_idx_host,
                             const int32_t* neg_idx_host, int64_t batch, int64_t layout_batch,
                             int32_t* plan_out_host);   /* crh_bpr_plan_ints(layout_batch) ints */
@@ -442,7 +437,6 @@ void crh_sampler_destroy(crh_sampler* s);
 int crh_sampler_seed(crh_sampler* s, uint32_t seed);
 int crh_sampler_set_state(crh_sampler* s, const uint32_t* key624_host, int pos);
 int crh_sampler_get_state(const crh_sampler* s, uint32_t* key624_host, int* pos_host);
-int64_t crh_sampler_num_records(const crh_sampler* s);
 /* One epoch in the background: _async queues it for the sampler's persistent worker thread (kept spinning between
  * epochs so that its core stays at speed) and returns; _wait blocks until the epoch is complete and returns its code.
  * Between the two calls the output arrays and the sampler belong to the worker. */
