@@ -24,8 +24,10 @@ struct ScoreArgs {
     int64_t n_ugroups;
     float* out_score;   // [n_splits][n_users][k]
     int32_t* out_idx;
-    int ablate;         // measurement only (CRH_SCORE_ABLATE): 1 = skip the selection epilogue, 4 = skip the workgroup barriers
-    unsigned long long* wave_clock;   // measurement only (CRH_SCORE_TIMING): [wave][2] start/end wall clock
+    int ablate;         // measurement only (CRH_SCORE_ABLATE, profile build; results invalid): 1 no selection, 2 every fetch hits one
+                        // cached tile, 4 no workgroup barriers, 8 no fragment waits (DMA kernel) / no block stores (block
+                        // launch), 16 no DMA wait
+    unsigned long long* wave_clock;   // measurement only (CRH_SCORE_TIMING): per-wave clocks, see print_wave_timing / the DMA histogram
     unsigned* xcd_sync;     // [8 XCD][1 + n_windows] zeroed counters, or NULL: keeps the waves of an XCD within
     int sync_window;        // two windows of `sync_window` tiles of each other (see xcd_window_sync)
     int64_t sync_stride;    // counters per XCD
