@@ -152,15 +152,16 @@ def measured_traffic(kernel_prefix, grid_threads, prefer=None):
 def bare_mfma_loops():
     """What a bare v_mfma_f32_32x32x16_f16 stream sustains ON THIS BOX IN THIS RUN (tools/probes/mfma_energy_probe, ~1 s, run
     as a child process): the chip is power-limited under random fp16 operands and boxes differ by +-8 %, so the fp16 leg
-    reports its kernel against these in-run figures beside the nominal 2.5 PF.  None when the probe cannot be built / run."""
+    reports its kernel against these in-run figures beside the nominal 2.5 PF.  None when the probe binary is absent or fails."""
     import re
     import subprocess
     exe = os.path.join(ROOT, "tools", "probes", "mfma_energy_probe")
+    if not os.path.exists(exe):        # built by __graft_entry__.build() / tools/profile_round.sh, never from inside a leg: under
+        return None                    # rocprofv3 a compiler started here would be a GPU-initialised process that execs
+    # the probe is an ordinary child; a profiler's preload (LD_PRELOAD / ROCP*) is not handed down to it
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
     try:
-        if not os.path.exists(exe):
-            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-o", exe, exe + ".hip"], check=True,
-                           timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        out = subprocess.run([exe], check=True, timeout=120, capture_output=True, text=True).stdout
+        out = subprocess.run([exe], check=True, timeout=120, capture_output=True, text=True, env=env).stdout
     except (OSError, subprocess.SubprocessError):
         return None
     best = {}

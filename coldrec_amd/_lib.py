@@ -124,7 +124,7 @@ SPMM_SCHED_VERSION = 4       # CRH_SPMM_SCHED_VERSION of include/coldrec_hip.h
 
 def build(force: bool = False) -> str:
     """Compile every HIP source for gfx950 into coldrec_amd/lib/ (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]   # (flags live there)
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "coldrec_hip.h"))
     stale = not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

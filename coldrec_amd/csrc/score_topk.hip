@@ -853,28 +853,32 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     const int wg_waves = (wg_mode != 4 && wg8_lds <= 160 * 1024) ? 8 : 4;
     const int wg_upw = 64;
     const int wg_slots = wg_waves == 8 ? 256 : 512;                   // workgroups resident per round
-    const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : (d == 128 && wg_waves == 8);
+    // 512- and 256-byte rows (fp16 d=256 / 128, fp32 d=128 / 64): the LDS-DMA form (four waves of 128 users, score_topk_dma_kernel)
+    // wherever a workgroup kernel runs and its lists fit beside the four ring slots (k <= 20 at 512-byte rows, k <= 28 at 256).
+    // Same box, 131 072 x 10 M: fp16 d=256 0.577 vs 0.535 for the ring kernel, fp32 d=128 0.920 vs 0.910.
+    // CRH_SCORE_DMA (read per call): 0 never, anything else (default) on
+    const int dma_mode = getenv("CRH_SCORE_DMA") ? atoi(getenv("CRH_SCORE_DMA")) : 1;
+    const size_t tb_off = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);   // the tiles' candidate bits
+    const bool dma_shape = dma_mode && (d * esz == 512 || d * esz == 256) && score_dma_lds_bytes(d * esz, k) <= 160 * 1024 &&
+                           (!has_bitmap || workspace_bytes >= tb_off + tbits_bytes(n_items));
+    // fp32 d=64 (the reference's default width) has no register-staged ring kernel: a workgroup kernel only as the DMA form
+    const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : ((d == 128 && wg_waves == 8) || (d == 64 && dma_shape));
     // fp32: the lockstep of 8 waves makes every slow-path event a stall of the whole CU, so the workgroup kernel only
     // pays on long streams (FP32_WG_MIN_ITEMS) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
     // at 0.33 against 0.60 per wave)
     const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
     const bool fp32_wg_ok = n_items >= FP32_WG_MIN_ITEMS && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
-    const bool use_wg = wg_mode && can_pack && wg_shape && (wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
+    const bool use_wg = wg_mode && can_pack && wg_shape && (dma_shape || wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
                         (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
-    // 512-byte rows (fp16 d=256, fp32 d=128): the LDS-DMA form (four waves of 128 users, score_topk_dma_kernel) wherever a
-    // workgroup kernel runs and k <= 20.  Same box, 131 072 x 10 M: fp16 0.577 vs 0.535 for the ring kernel, fp32 0.920 vs 0.910.
-    // CRH_SCORE_DMA (read per call): 0 never, anything else (default) on
-    const int dma_mode = getenv("CRH_SCORE_DMA") ? atoi(getenv("CRH_SCORE_DMA")) : 1;
-    const size_t dma_lds = score_dma_lds_bytes(d * esz, k);
-    const size_t tb_off = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);   // the tiles' candidate bits
-    const bool use_dma = use_wg && dma_mode && d * esz == 512 && dma_lds <= 160 * 1024 &&
-                         (!has_bitmap || workspace_bytes >= tb_off + tbits_bytes(n_items));
+    const bool use_dma = use_wg && dma_shape;
     const int wg_waves_l = use_dma ? 4 : wg_waves;                    // waves of the workgroup that is launched
     const int wg_slots_l = use_dma ? 256 : wg_slots;                  // ... and how many of them are resident per round
     const int upw = use_dma ? 128 : (use_wg ? wg_upw : users_per_wave(esz, d));
     // two waves per SIMD hide the selection / slow path behind the partner's MFMAs (+8 % measured at fp32
     // d=128); CRH_SCORE_OCC=1 selects the double-buffered one-wave-per-SIMD fp32 build (tuning hook)
     static const int variant = CRH_TUNE_ENV("CRH_SCORE_OCC") ? atoi(CRH_TUNE_ENV("CRH_SCORE_OCC")) : 2;
+    // (fp32 d=64 at two waves per SIMD -- 128 users per wave, <float, 64, 4, 2> -- spills 13 registers into its tile loop: 131 072 x
+    // 10 M ran at 0.466 of the fp32 MFMA peak against 0.884 for the one-wave form, 131 072 x 1.25 M 0.442 against 0.824; round 6)
     const int occ = esz == 2 ? 2 : ((variant == 2 && d == 128) ? 2 : 1);
     // Small catalogues (the trainers' per-epoch validation: a few thousand users x a few thousand items).  The fused
     // selection is built for catalogues where a candidate above the running threshold is rare; here every user takes
@@ -943,11 +947,11 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     // fp16, 512-byte rows (configs[4]): at 16x the fp32 MFMA rate a slow-path event costs as much as a whole tile and, in
     // the workgroup kernels, stalls the whole CU: 9 % of the launch at 10 M items (profiles/r05_f16_*).  A 4 096-item prefix
     // takes k (1 + ln(P / k)) of every user's k (1 + ln(N / k)) events out of the stream: 282 -> 156 per user at 10 M items
-    const bool f16_stream = !cuts && esz == 2 && d == 256 && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
+    const bool f16_stream = !cuts && esz == 2 && (d == 256 || d == 128) && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
     // fp32, 512-byte rows on the workgroup kernels (the headline): the same, worth less at the fp32 rate -- 131 072 x 3 M 0.883 ->
     // 0.895, x 4 M 0.895 -> 0.905, x 10 M 0.9245 -> 0.9285 (16 384-item prefix; 4 096 / 8 192 at 10 M: +0.35 / +0.38 %).  8 192 items
     // keep the prefix's score block (4.3 GB at 131 072 users) inside what the packed copy of such a shard takes anyway
-    const bool f32_stream = !cuts && esz == 4 && d == 128 && n_users >= 32768 && n_items >= FP32_WG_MIN_ITEMS;
+    const bool f32_stream = !cuts && esz == 4 && (d == 128 || d == 64) && n_users >= 32768 && n_items >= FP32_WG_MIN_ITEMS;
     if ((small_cat || f16_stream) && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
     if (f32_stream && !small_cat && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 8192) P = 8192;
     if (!(cuts || small_cat || f16_stream || f32_stream || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;
@@ -1210,7 +1214,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 #endif
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
     if (use_dma) {
-        rc = launch_score_dma(esz, a, st);
+        rc = launch_score_dma(esz, d, a, st);
     } else if (esz == 4 && use_wg) {
         rc = launch_score_wg<float, 128, 2, 8>(a, st);
     } else if (use_wg) {
@@ -1235,7 +1239,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
             std::vector<unsigned long long> b(64, 0);
             for (int blk = 0; blk < 16; ++blk)
                 for (int q = 0; q < 64; ++q) b[q] += h[((size_t)blk * 4 + wv) * 64 + q];
-            const unsigned long long bw = esz == 4 ? 512 : 128;     // bucket width in cycles per tile
+            const unsigned long long bw = (esz == 4 ? 512 : 128) >> (d * esz == 256 ? 1 : 0);     // bucket width in cycles per tile
             for (int q = 0; q < 64; ++q) { tot += b[q]; wsum += b[q] * (q * bw + bw / 2); }
             fprintf(stderr, "[crh dma timing] wave %d: %llu tiles, mean %.0f cycles; histogram (%llu-cycle buckets from 0):", wv, tot,
                     tot ? (double)wsum / (double)tot : 0.0, bw);

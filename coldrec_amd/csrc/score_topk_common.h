@@ -345,8 +345,8 @@ __device__ __forceinline__ bool xcd_window_sync(unsigned* cnt, int64_t win, int 
 
 constexpr int WG_RING = 3;   // item-tile slots in LDS (workgroup kernels)
 
-// score_topk_dma.hip (built with -mllvm -amdgpu-mfma-vgpr-form): the LDS-DMA workgroup kernel for 512-byte rows
-__attribute__((visibility("hidden"))) int launch_score_dma(int esz, const ScoreArgs& a, hipStream_t stream);
+// score_topk_dma.hip (built with -mllvm -amdgpu-mfma-vgpr-form): the LDS-DMA workgroup kernel for 512- and 256-byte rows
+__attribute__((visibility("hidden"))) int launch_score_dma(int esz, int d, const ScoreArgs& a, hipStream_t stream);
 __attribute__((visibility("hidden"))) size_t score_dma_lds_bytes(int row_bytes, int k);
 
 }  // namespace crh_score

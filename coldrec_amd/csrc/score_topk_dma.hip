@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
                 const unsigned long long t_now = __builtin_amdgcn_s_memtime();
                 if (j >= 64 && lane == 0) {
                     // two tiles per trip: 256-cycle units = 128 per tile (fp16); fp32 tiles are 4x as long: 512 per tile
-                    unsigned long long dt = (t_now - t_prev) >> (sizeof(T) == 4 ? 10 : 8);
+                    unsigned long long dt = (t_now - t_prev) >> ((sizeof(T) == 4 ? 10 : 8) - (ROWB == 256 ? 1 : 0));
                     if (dt > 63) dt = 63;
                     atomicAdd(&a.wave_clock[((size_t)blockIdx.x * 4 + wave) * 64 + dt], 1ull);
                 }
@@ -498,8 +498,11 @@ size_t score_dma_lds_bytes(int row_bytes, int k) {
     return (size_t)DMA_RING * (row_bytes / 32) * 1024 + TBITS_B + DMA_NW * dma_wave_lds_bytes(k);
 }
 
-int launch_score_dma(int esz, const ScoreArgs& a, hipStream_t stream) {
-    return esz == 4 ? launch_score_dma_t<float, 128>(a, stream) : launch_score_dma_t<_Float16, 256>(a, stream);
+// 512-byte rows (fp32 d=128: the headline; fp16 d=256: configs[4]) and 256-byte rows (fp32 d=64: the reference's default
+// width, main.py:97 --emb_size 64 = configs[0]; fp16 d=128): half the ring, half the B registers, the same loop.
+int launch_score_dma(int esz, int d, const ScoreArgs& a, hipStream_t stream) {
+    if (esz == 4) return d == 128 ? launch_score_dma_t<float, 128>(a, stream) : launch_score_dma_t<float, 64>(a, stream);
+    return d == 256 ? launch_score_dma_t<_Float16, 256>(a, stream) : launch_score_dma_t<_Float16, 128>(a, stream);
 }
 
 }  // namespace crh_score

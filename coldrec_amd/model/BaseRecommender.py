@@ -14,12 +14,12 @@ is honoured: its dense block goes through crh_mask_topk_f32.  Either way the ord
 """
 from __future__ import annotations
 
+import dis
 import inspect
 import math
-import re
 import time
 from abc import ABC, abstractmethod
-from collections.abc import Mapping
+from collections.abc import ItemsView, KeysView, ValuesView
 from typing import Any, Dict, List, Tuple
 
 import numpy as np
@@ -36,18 +36,31 @@ def _truth_pairs(data_set: Dict) -> int:
     return int(fast) if fast is not None else sum(map(len, data_set.values()))
 
 
-class RecList(Mapping):
+def _structural(name):
+    """a dict method that changes the key set (or reads all of it): RecList builds every list first"""
+    def method(self, *a, **kw):
+        self._materialise()
+        return getattr(dict, name)(self, *a, **kw)
+    method.__name__ = name
+    return method
+
+
+class RecList(dict):
     """What ``_evaluate`` / ``valid`` / ``test`` return: ``{user: [(original item id, np.float32 score), ...]}`` exactly as
-    model/BaseRecommender.py:185-187 builds it -- same keys in the same order, same lists on access -- but held as the
-    ``(users, k)`` score / id arrays the ranking kernel wrote, and materialised one user at a time when somebody looks.
-    The eager dict was 2e6 Python tuples per 1e5 users (0.55 s beside 1.95 s of ranking); callers that only hand the result
-    to ``full_evaluation`` (every reference model does) never pay for it: ``full_evaluation`` takes the arrays.  A plugin
-    that edits lists assigns into it (``rec[u] = [...]``): such users are kept as plain lists and win over the arrays."""
+    model/BaseRecommender.py:185-187 builds it -- a ``dict`` with the same keys in the same order and the same lists -- but
+    held as the ``(users, k)`` score / id arrays the ranking kernel wrote.  A user's list is built when somebody first looks
+    at it and KEPT (``__missing__``), so the object handed out is the object looked up later: a plugin that edits a list in
+    place (``rec[u].sort()``, ``rec[u][:] = ...``, ``.pop()``) or assigns one (``rec[u] = [...]``) is scored on its edit, as
+    with the reference's plain dict.  The eager dict was 2e6 Python tuples per 1e5 users (0.55 s beside 1.95 s of ranking);
+    callers that only hand the result to ``full_evaluation`` (every reference model does) never pay for it: the metrics take
+    the arrays, and walk only the lists that were handed out.  A structural edit (``del``, ``pop``, ``update``, a new key)
+    turns it into the plain dict it imitates (every list built, ``_full``)."""
 
     def __init__(self, users, scores: np.ndarray, idx: np.ndarray, item_keys: np.ndarray):
+        super().__init__()
         self.users, self.scores, self.idx, self._item_keys = users, scores, idx, item_keys
         self._row = None            # user -> row, built on first keyed access
-        self._edited: Dict[Any, list] = {}
+        self._full = False          # every list is in the dict storage: an ordinary dict from then on
 
     def _rows(self):
         if self._row is None:
@@ -58,50 +71,130 @@ class RecList(Mapping):
         names = self._item_keys[np.minimum(self.idx[r], len(self._item_keys) - 1)].tolist()
         return list(zip(names, self.scores[r]))
 
-    def __getitem__(self, user):
-        if user in self._edited:
-            return self._edited[user]
-        return self._list(self._rows()[user])
+    def __missing__(self, user):    # dict.__getitem__ lands here for a user whose list has not been handed out yet
+        if self._full:
+            raise KeyError(user)
+        lst = self._list(self._rows()[user])
+        dict.__setitem__(self, user, lst)
+        return lst
+
+    def _materialise(self):
+        """every list into the dict storage, in the users' order; plain-dict behaviour afterwards"""
+        if self._full:
+            return
+        handed = dict(dict.items(self))
+        dict.clear(self)
+        for r, u in enumerate(self.users):
+            dict.__setitem__(self, u, handed[u] if u in handed else self._list(r))
+        self._full = True
 
     def __setitem__(self, user, value):
-        if user not in self._rows():
-            raise KeyError(user)
-        self._edited[user] = value
+        if not self._full and user not in self._rows():
+            self._materialise()
+        dict.__setitem__(self, user, value)
 
     def __iter__(self):
-        return iter(self.users)
+        return dict.__iter__(self) if self._full else iter(self.users)
 
     def __len__(self):
-        return len(self.users)
+        return dict.__len__(self) if self._full else len(self.users)
 
     def __contains__(self, user):
-        return user in self._rows()
+        return dict.__contains__(self, user) if self._full else user in self._rows()
+
+    def get(self, user, default=None):
+        return self[user] if user in self else default
+
+    def keys(self):
+        return dict.keys(self) if self._full else KeysView(self)
 
     def items(self):
-        for r, u in enumerate(self.users):
-            yield u, (self._edited[u] if u in self._edited else self._list(r))
+        return dict.items(self) if self._full else ItemsView(self)
 
     def values(self):
-        for _, v in self.items():
-            yield v
+        return dict.values(self) if self._full else ValuesView(self)
+
+    def __eq__(self, other):
+        self._materialise()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self) if self._full else f"RecList({len(self.users)} users x {self.idx.shape[1] if self.idx.ndim == 2 else 0})"
+
+    def copy(self):
+        self._materialise()
+        return dict(self)
+
+    __delitem__, pop, popitem, clear = _structural('__delitem__'), _structural('pop'), _structural('popitem'), _structural('clear')
+    update, setdefault, __ior__ = _structural('update'), _structural('setdefault'), _structural('__ior__')
+    __or__, __ror__, __reversed__ = _structural('__or__'), _structural('__ror__'), _structural('__reversed__')
 
     @property
     def untouched(self) -> bool:
-        """no list was replaced: the arrays ARE the lists"""
-        return not self._edited
+        """no list was handed out, replaced or removed: the arrays ARE the lists"""
+        return not self._full and dict.__len__(self) == 0
+
+    def handed_out(self):
+        """(user, list) of every list somebody holds a reference to (and may have edited in place) or assigned"""
+        return list(dict.items(self))
 
 
-_STOCK_PREDICT = re.compile(
-    r"score=torch\.matmul\(self\.user_emb\[users\],self\.item_emb\.transpose\(0,1\)\)returnscore$")
+# ---- is a plugin's batch_predict the stock one (model/MF.py:58-63, copied 22-fold across model/*.py)?
+# Decided on the function's BYTECODE against templates compiled here in the running interpreter: formatting, comments,
+# docstrings and local names do not matter, a plugin shipped without source (.pyc) is recognised too, and anything that
+# computes something else (a second product, a scale, a sign) differs in its instruction stream.
+_STOCK_ITEM_T = ("self.item_emb.transpose(0, 1)", "self.item_emb.transpose(1, 0)", "self.item_emb.T", "self.item_emb.t()",
+                 "self.item_emb.mT", "self.item_emb.permute(1, 0)", "torch.transpose(self.item_emb, 0, 1)",
+                 "torch.t(self.item_emb)")
+_STOCK_PRODUCT = ("torch.matmul({a}, {b})", "torch.mm({a}, {b})", "{a} @ {b}", "{a}.matmul({b})", "{a}.mm({b})")
+_stock_codes = None
+
+
+def _norm_code(code) -> tuple:
+    """instruction stream with local names numbered by first use"""
+    local: Dict[str, int] = {}
+    out = []
+    for ins in dis.get_instructions(code):
+        arg = ins.argval
+        if ins.opname in ('LOAD_FAST', 'STORE_FAST', 'DELETE_FAST'):
+            arg = local.setdefault(arg, len(local))
+        elif ins.opname.startswith(('JUMP', 'POP_JUMP', 'SETUP', 'FOR_ITER')):
+            arg = ins.arg
+        out.append((ins.opname, arg if isinstance(arg, (str, int, float, tuple, type(None))) else repr(arg)))
+    return tuple(out)
+
+
+def _stock_templates():
+    global _stock_codes
+    if _stock_codes is None:
+        codes = set()
+        for prod in _STOCK_PRODUCT:
+            for bt in _STOCK_ITEM_T:
+                expr = prod.format(a="self.user_emb[users]", b=bt)
+                for tail in (f"score = {expr}\n{{i}}return score", f"return {expr}"):
+                    for grad in (True, False):
+                        ind = "        " if grad else "    "
+                        for head in ("users = self.data.get_user_id_list(users)\n{i}users = torch.tensor(users, device=self.device)",
+                                     "users = torch.as_tensor(self.data.get_user_id_list(users), device=self.device)"):
+                            src = "def batch_predict(self, users):\n" + ("    with torch.no_grad():\n" if grad else "") + \
+                                  ind + head.format(i=ind) + "\n" + ind + tail.format(i=ind) + "\n"
+                            ns: Dict[str, Any] = {}
+                            exec(compile(src, "<stock batch_predict>", "exec"), ns)
+                            codes.add(_norm_code(ns["batch_predict"].__code__))
+        _stock_codes = codes
+    return _stock_codes
 
 
 def _is_stock_batch_predict(fn) -> bool:
-    """True when ``batch_predict`` is the 22-fold copy of model/MF.py:58-63."""
+    """True when ``batch_predict`` is the 22-fold copy of model/MF.py:58-63, in any spelling of the same product
+    (``torch.matmul`` / ``torch.mm`` / ``@``; ``.transpose(0, 1)`` / ``.T`` / ``.t()`` ...), with or without source."""
     try:
-        src = re.sub(r"\s+", "", inspect.getsource(fn))
-    except (OSError, TypeError):
+        code = inspect.unwrap(fn).__code__
+    except (AttributeError, ValueError):
         return False
-    return bool(_STOCK_PREDICT.search(src)) and src.count("matmul") == 1
+    return _norm_code(code) in _stock_templates()
 
 
 class BaseColdStartTrainer(ABC):
@@ -228,7 +321,11 @@ class BaseColdStartTrainer(ABC):
         if fused is None:
             fused = _is_stock_batch_predict(type(self).batch_predict)
         ue, ie = getattr(self, 'user_emb', None), getattr(self, 'item_emb', None)
+        stock = bool(fused)
         fused = fused and torch.is_tensor(ue) and torch.is_tensor(ie) and ue.is_cuda and ue.dim() == 2
+        if not getattr(self, '_route_told', False):
+            self._route_told = True
+            self._tell_route(fused, stock, c)
         if fused:
             dp = dp_from_env()
             tdt = torch.float16 if getattr(self.args, 'score_dtype', 'fp32') == 'fp16' else torch.float32
@@ -277,6 +374,30 @@ class BaseColdStartTrainer(ABC):
             s, i = torch.cat(parts_s), torch.cat(parts_i)
         return c, s, i
 
+    DENSE_BLOCK_WARN_BYTES = 4 << 30
+
+    def _tell_route(self, fused: bool, stock: bool, c) -> None:
+        """One line at a trainer's first evaluation: which route ranks -- the fused kernel the LIBRARY names for the shape
+        (crh_score_topk_route) or batch_predict's dense block -- and a warning when that block is catalogue-sized."""
+        n_items = int(self.data.item_num) if hasattr(self.data, 'item_num') else len(self.data.item)
+        if fused:
+            ie = self.item_emb
+            half = getattr(self.args, 'score_dtype', 'fp32') == 'fp16'
+            r = ops.score_topk_route(min(len(c['users']), self.EVAL_USER_BLOCK), int(ie.shape[0]), int(ie.shape[1]), self.max_N,
+                                     half=half, has_bitmap=c['bitmap'] is not None)
+            print(f"Evaluation route: fused HIP scoring + masks + top-{self.max_N} ({r['kernel']}, {r['route']}"
+                  f"{', seeded from a %d-item prefix' % r['prefix_items'] if r['seeded'] else ''}); no score block is written")
+            return
+        block = int(self.batch_size) * n_items * 4
+        why = ("user_emb / item_emb are not 2-D device tensors" if stock else
+               "batch_predict is not the stock user_emb[users] @ item_emb.T (set fused_eval = True on the trainer if it is)")
+        print(f"Evaluation route: batch_predict -> ({self.batch_size} x {n_items}) fp32 score block "
+              f"({block / 2 ** 30:.2f} GiB) -> crh_mask_topk_f32; {why}")
+        if block > self.DENSE_BLOCK_WARN_BYTES:
+            import warnings
+            warnings.warn(f"evaluation materialises a {block / 2 ** 30:.1f} GiB score block per {self.batch_size} users: "
+                          f"lower --bs, or set fused_eval = True if batch_predict is user_emb[users] @ item_emb.T", RuntimeWarning)
+
     def _evaluate(self, data_set: Dict, data_type: str = 'all') -> Dict[Any, List[Tuple[Any, float]]]:
         t0 = self._tick('_before', time.perf_counter())
         c, s, i = self._topk_arrays(data_set, data_type)
@@ -284,7 +405,6 @@ class BaseColdStartTrainer(ABC):
         # {user: [(original item id, np.float32 score), ...]} as model/BaseRecommender.py:185-187 builds it, as a Mapping over
         # the arrays that materialises a user's list on access (RecList)
         out = RecList(c['users'], s, i, self.data.item_keys)
-        out._ranked_for = (id(data_set), data_type)
         self._tick('evaluate_dict_s', t0)
         return out
 
@@ -366,14 +486,22 @@ class BaseColdStartTrainer(ABC):
         """Metrics of a caller-supplied ``{user: [(item, score), ...]}`` (what ``test()`` returns, possibly
         post-processed by a plugin) -- the reference's ranking_evaluation(test_set, rec_list, topN) on arrays."""
         c = self._get_eval_cache(data_set, data_type)
-        if isinstance(rec_list, RecList) and rec_list.untouched and rec_list.idx.shape[0] == len(c['users']) and \
-                rec_list.idx.shape[1] >= max(topn) and list(rec_list.users) == list(c['users']):
-            # the lists are the ranking kernel's own arrays (internal ids): no Python tuple is built on the way to the metrics
-            return ranking_metrics(c['gt_rowptr'], c['gt_items'], rec_list.idx.astype(np.int64), topn, dense=c['gt_dense'])
         item_id = self.data.item
-        pred = np.full((len(c['users']), max(topn)), np.iinfo(np.int32).max, np.int64)
+        pad = np.iinfo(np.int32).max
+        if isinstance(rec_list, RecList) and not rec_list._full and rec_list.idx.shape[0] == len(c['users']) and \
+                rec_list.idx.shape[1] >= max(topn) and list(rec_list.users) == list(c['users']):
+            # the lists are the ranking kernel's own arrays (internal ids): no Python tuple is built on the way to the metrics.
+            # Lists somebody was handed (and may have edited in place) or assigned are read back from the lists themselves
+            pred = rec_list.idx.astype(np.int64)
+            if not rec_list.untouched:
+                rows = rec_list._rows()
+                for u, lst in rec_list.handed_out():
+                    row = [item_id.get(it, pad) for it, _ in lst[: pred.shape[1]]]
+                    pred[rows[u]] = row + [pad] * (pred.shape[1] - len(row))
+            return ranking_metrics(c['gt_rowptr'], c['gt_items'], pred, topn, dense=c['gt_dense'])
+        pred = np.full((len(c['users']), max(topn)), pad, np.int64)
         for r, u in enumerate(c['users']):
-            row = [item_id.get(it, np.iinfo(np.int32).max) for it, _ in rec_list[u][: max(topn)]]
+            row = [item_id.get(it, pad) for it, _ in rec_list[u][: max(topn)]]
             pred[r, : len(row)] = row
         return ranking_metrics(c['gt_rowptr'], c['gt_items'], pred, topn, dense=c['gt_dense'])
 

@@ -3,6 +3,7 @@ come from PyTorch-ROCm; all arithmetic happens in libcoldrec_hip.so.  No CPU fal
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 from typing import Optional, Tuple
 
@@ -535,7 +536,7 @@ class SpmmSchedule:
         rp = rowptr.cpu().numpy() if torch.is_tensor(rowptr) else np.asarray(rowptr)
         rp = rp.astype(np.int64)
         self._rp, self._col, self._val, self._device, self._slabs = rp, col, val, device, {}
-        self._bound, self._baked = {}, None
+        self._checked, self._baked = None, None
         deg = np.diff(rp)
         if seg is None:
             # heavy threshold: crh_spmm_segment_edges() (64) for sparse graphs; for dense ones (MovieLens shape: mean
@@ -622,36 +623,39 @@ class SpmmSchedule:
     def _same_edges(self, col, val) -> bool:
         """Are the launch's edge arrays the ones the record stream was built from?  The stream bakes (col, val) of the LIGHT
         rows in while the heavy rows read the launch's arrays: a caller that hands a rescaled ``val`` (or another matrix) to
-        a reused schedule would get a mix of both.  Checked once per pair of device buffers (pointer, length,
-        version counter) by two 64-bit checksums against the arrays the schedule was given; a pair that does not match -- or
-        cannot be checked because the stream is being captured -- takes the descriptor path, which reads the launch's arrays."""
+        a reused schedule would get a mix of both (ADVICE r3).  The schedule's own tensors pass by identity + version counter;
+        any other pair is checked by two position-weighted 64-bit checksums against the bake-time sums (one reduction each) --
+        remembered only for the same tensor objects -- and a pair that does not match, or cannot be checked because the stream
+        is being captured, takes the descriptor path, which reads the launch's arrays."""
         if col is None or val is None:
             return True
-        key = (col.data_ptr(), val.data_ptr(), col.numel(), col._version, val._version)
-        ok = self._bound.get(key)
-        if ok is None:
-            baked = getattr(self, "_baked", None)
-            if baked is None:
-                return False                                  # no stream was built: nothing to vouch for
-            same_tensors = torch.is_tensor(self._col) and torch.is_tensor(self._val) and self._col.data_ptr() == col.data_ptr() \
-                and self._val.data_ptr() == val.data_ptr() and self._col.numel() == col.numel()
-            if same_tensors and (col._version, val._version) == baked[:2]:
-                ok = True                                     # the very tensors the stream was baked from, untouched since
-            elif col.is_cuda and torch.cuda.is_current_stream_capturing():
-                if not getattr(self, "_warned_capture", False):
-                    self._warned_capture = True
-                    import warnings
-                    warnings.warn("SpmmSchedule: an edge-array pair met inside a stream capture has not been checked against the "
-                                  "record stream; this launch (and the captured graph) takes the slower descriptor path -- bind the "
-                                  "pair once eagerly (sched.for_launch(n, d, col, val)) before capturing")
-                return False                                  # not cached: an eager launch decides
-            else:                                             # checksums of the launch's arrays against the BAKE-TIME sums
-                ok = (col.numel() == baked[2] and val.numel() == baked[2]
-                      and int(col.sum(dtype=torch.int64)) == baked[3]
-                      and int(val.view(torch.int32).sum(dtype=torch.int64)) == baked[4])
-            if len(self._bound) >= 64:                        # fresh ``val`` tensors every step must not grow this without bound
-                self._bound.clear()
-            self._bound[key] = ok
+        baked = getattr(self, "_baked", None)
+        if baked is None:
+            return False                                      # no stream was built: nothing to vouch for
+        # (1) the very tensor OBJECTS the schedule holds (kept alive by it), untouched since the bake: no device work
+        if col is self._col and val is self._val and (col._version, val._version) == baked[:2]:
+            return True
+        # (2) the pair checked last, still the same objects at the same versions.  Keyed by object identity through weak
+        # references, never by address: a fresh ``val`` every step is usually recycled at the address of the last one
+        # (ADVICE r5: an address-keyed entry then vouched for contents it never saw)
+        last = self._checked
+        if last is not None and last[0]() is col and last[1]() is val and last[2:4] == (col._version, val._version):
+            return last[4]
+        if col.is_cuda and torch.cuda.is_current_stream_capturing():
+            if not getattr(self, "_warned_capture", False):
+                self._warned_capture = True
+                import warnings
+                warnings.warn("SpmmSchedule: an edge-array pair met inside a stream capture has not been checked against the "
+                              "record stream; this launch (and the captured graph) takes the slower descriptor path -- bind the "
+                              "pair once eagerly (sched.for_launch(n, d, col, val)) before capturing")
+            return False                                      # not remembered: an eager launch decides
+        # (3) position-weighted checksums of the launch's arrays against the BAKE-TIME sums (a permutation changes them)
+        ok = col.numel() == baked[2] and val.numel() == baked[2]
+        if ok:
+            w = torch.arange(1, col.numel() + 1, dtype=torch.int64, device=col.device)
+            ok = int((col.to(torch.int64) * w).sum()) == baked[3] and \
+                int((val.view(torch.int32).to(torch.int64) * w).sum()) == baked[4]
+        self._checked = (weakref.ref(col), weakref.ref(val), col._version, val._version, ok)
         return ok
 
     def for_launch(self, n_rows: int, d: int, col=None, val=None):

@@ -155,8 +155,110 @@ def test_rec_list_is_the_references_dict_built_on_demand():
     eager[users[0]] = rec[users[0]]
     assert not rec.untouched and dict(rec) == eager
     assert tr._metrics_from_rec_list(test_set, "all", rec, [10, 20]) == tr._metrics_from_rec_list(test_set, "all", eager, [10, 20])
+    # a list edited IN PLACE is scored as edited (the object handed out is the object kept), on a fresh RecList
+    rec2 = RecList(users, sc, idx, d.item_keys)
+    eager2 = {u: list(zip(d.item_keys[idx[r]].tolist(), sc[r])) for r, u in enumerate(users)}
+    assert isinstance(rec2, dict) and rec2.untouched
+    for u in users[:50]:
+        rec2[u].reverse()
+        eager2[u].reverse()
+    got = rec2.get(users[51])
+    got.pop(0)
+    eager2[users[51]].pop(0)
+    rec2[users[52]][:] = []
+    eager2[users[52]] = []
+    assert rec2[users[0]] is rec2[users[0]] and not rec2.untouched and not rec2._full and len(rec2.handed_out()) == 52
+    edited = tr._metrics_from_rec_list(test_set, "all", rec2, [10, 20])
+    assert edited == tr._metrics_from_rec_list(test_set, "all", eager2, [10, 20]) and edited != fast
+    tr.full_evaluation(rec2, "all")
+    assert tr.overall_test_results == edited
+    for u, lst in rec2.items():                                      # lists seen while iterating are kept too
+        if u == users[60]:
+            lst.clear()
+    assert rec2[users[60]] == []
+    # structural edits: the plain dict it imitates (every list built, keys in the users' order, a new key allowed)
+    rec["no such user"] = []
+    assert rec._full and list(rec)[:-1] == users and len(rec) == len(users) + 1
+    del rec["no such user"]
+    assert rec.pop(users[5]) == eager.pop(users[5]) and rec == eager and len(rec) == len(users) - 1
     with pytest.raises(KeyError):
-        rec["no such user"] = []
+        rec["no such user"]
+
+
+def test_stock_batch_predict_is_recognised_by_bytecode_in_any_spelling(tmp_path):
+    """fused vs dense evaluation must not hang on the source TEXT of batch_predict.  The stock idiom
+    (model/MF.py:58-63) is recognised from the function's bytecode: reformatted, with a docstring, other local names, `.T` /
+    `@` / torch.mm, behind a functools.wraps decorator, and with the source file gone (.pyc only); a different computation is not."""
+    import functools
+    import importlib.util
+    import py_compile
+    from coldrec_amd.model.BaseRecommender import _is_stock_batch_predict
+    src = '''
+import functools
+import torch
+
+def deco(f):
+    @functools.wraps(f)
+    def inner(*a, **k):
+        return f(*a, **k)
+    return inner
+
+class A:
+    def batch_predict(self, users):
+        """the stock one, reformatted"""
+        with torch.no_grad():
+            users = self.data.get_user_id_list( users )
+            users = torch.tensor(users,
+                                 device=self.device)   # a comment
+            s = torch.matmul(self.user_emb[users],
+                             self.item_emb.transpose(0, 1))
+            return s
+
+class B:
+    def batch_predict(self, users):
+        with torch.no_grad():
+            users = self.data.get_user_id_list(users)
+            users = torch.tensor(users, device=self.device)
+            return self.user_emb[users] @ self.item_emb.T
+
+class C:
+    @deco
+    def batch_predict(self, users):
+        users = self.data.get_user_id_list(users)
+        users = torch.tensor(users, device=self.device)
+        score = torch.mm(self.user_emb[users], self.item_emb.t())
+        return score
+
+class Neg:
+    def batch_predict(self, users):
+        with torch.no_grad():
+            users = self.data.get_user_id_list(users)
+            users = torch.tensor(users, device=self.device)
+            score = -torch.matmul(self.user_emb[users], self.item_emb.transpose(0, 1))
+            return score
+
+class Two:
+    def batch_predict(self, users):
+        with torch.no_grad():
+            users = self.data.get_user_id_list(users)
+            users = torch.tensor(users, device=self.device)
+            score = torch.matmul(self.user_emb[users], self.item_emb.transpose(0, 1))
+            score = score + torch.matmul(self.user_aux[users], self.item_aux.transpose(0, 1))
+            return score
+'''
+    path = tmp_path / "plug.py"
+    path.write_text(src)
+    pyc = tmp_path / "plug_nosrc.pyc"
+    py_compile.compile(str(path), cfile=str(pyc))
+    for name, file in (("plug", path), ("plug_nosrc", pyc)):
+        spec = importlib.util.spec_from_file_location(name, str(file))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if name == "plug_nosrc":
+            path.unlink()                                             # no source on disk: inspect.getsource would fail
+        assert all(_is_stock_batch_predict(getattr(mod, c).batch_predict) for c in "ABC"), name
+        assert not _is_stock_batch_predict(mod.Neg.batch_predict) and not _is_stock_batch_predict(mod.Two.batch_predict)
+    assert not _is_stock_batch_predict(len) and not _is_stock_batch_predict(functools.partial(print))
 
 
 def test_trainers_refuse_cpu_and_early_stopping_rules():

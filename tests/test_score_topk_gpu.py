@@ -460,16 +460,19 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
     assert np.array_equal(i[pick], wi) and np.array_equal(s[pick].view(np.uint32), ws.view(np.uint32))
 
 
-@pytest.mark.parametrize("dtype,n_items,n_splits,k", [("f16", 200_003, 1, 20), ("f16", 200_003, 0, 20), ("f16", 70_001, 2, 50),
-                                                     ("f32", 200_003, 1, 20), ("f32", 70_001, 3, 20)])
-def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits, k, monkeypatch):
-    """The LDS-DMA workgroup kernel (512-byte rows: fp16 d=256, fp32 d=128) against the
-    register-staged ring kernel (CRH_SCORE_DMA=0) on thousands of tiles with continuous embeddings: every list of every
+@pytest.mark.parametrize("dtype,n_items,n_splits,k,d", [("f16", 200_003, 1, 20, 256), ("f16", 200_003, 0, 20, 256), ("f16", 70_001, 2, 50, 256),
+                                                       ("f32", 200_003, 1, 20, 128), ("f32", 70_001, 3, 20, 128),
+                                                       ("f32", 200_003, 1, 20, 64), ("f32", 200_003, 0, 20, 64), ("f32", 70_001, 3, 28, 64),
+                                                       ("f16", 200_003, 1, 20, 128), ("f16", 70_001, 2, 10, 128)])
+def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits, k, d, monkeypatch):
+    """The LDS-DMA workgroup kernel (512-byte rows: fp16 d=256, fp32 d=128; 256-byte rows: fp32 d=64 = the reference's default
+    width, fp16 d=128) against the kernel the library runs without it (CRH_SCORE_DMA=0: the register-staged ring kernel; fp32
+    d=64 has none and takes the per-wave kernel) on thousands of tiles with continuous embeddings: every list of every
     user bit-identical (a tile read before its DMA landed, or overwritten while a slower wave still reads it, shows up
     here), plus sampled users against the oracle."""
     from coldrec_amd import ops
     rng = np.random.default_rng(n_items + n_splits)
-    n_users, d = 32768 + 77, (256 if dtype == "f16" else 128)
+    n_users = 32768 + 77
     npdt = np.float16 if dtype == "f16" else np.float32
     U = (rng.standard_normal((n_users, d)) * 0.3).astype(npdt)
     V = (rng.standard_normal((n_items, d)) * 0.3).astype(npdt)
@@ -484,8 +487,11 @@ def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits
     bm = ops.make_bitmap(n_items, cold, dev)
     monkeypatch.setenv("CRH_SCORE_WG", "2")
     monkeypatch.setenv("CRH_SCORE_DMA", "1")
+    if k <= 20 or d * U.itemsize == 256:
+        assert ops.score_topk_route(n_users, n_items, d, k, half=dtype == "f16", n_splits=max(n_splits, 1))["route"] == "fused-dma"
     s1, i1 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
     monkeypatch.setenv("CRH_SCORE_DMA", "0")
+    assert ops.score_topk_route(n_users, n_items, d, k, half=dtype == "f16", n_splits=max(n_splits, 1))["route"] != "fused-dma"
     s0, i0 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
     torch.cuda.synchronize()
     assert torch.equal(i1, i0) and torch.equal(s1.view(torch.int32), s0.view(torch.int32))

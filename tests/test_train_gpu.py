@@ -388,9 +388,14 @@ def test_spmm_record_stream_path_equals_descriptor_path_and_oracle(monkeypatch, 
         vl_d.mul_(1.0 / 3.0)                                               # (x 3 / 3 is not the identity in fp32 for every value:
         same = torch.equal(vl_d, vl)                                       #  whatever it gave, the stream is used iff the bits are back)
         assert bool(dev_sched.for_launch(n, d, cl_d, vl_d).slab) == same
-        for _ in range(200):                                               # fresh value tensors every step: the cache stays bounded
-            dev_sched.for_launch(n, d, cl_d, vl_d.clone())
-        assert len(dev_sched._bound) <= 64
+        # fresh value tensors every step are recycled at ONE address -- a verdict must never be remembered by address.
+        # A fresh tensor with other contents right after a matching one (same address, version 0) takes the descriptor path
+        for step in range(20):
+            fresh = vl_d.clone() if step % 2 == 0 else (vl_d * 2.0)
+            assert bool(dev_sched.for_launch(n, d, cl_d, fresh).slab) == (same and step % 2 == 0), step
+            del fresh
+        perm = torch.arange(cl_d.numel() - 1, -1, -1, device=cl_d.device)    # the same multiset of edges in another order
+        assert not dev_sched.for_launch(n, d, cl_d[perm].contiguous(), vl_d[perm].contiguous()).slab
     # a schedule built for another struct layout is refused by name, not decoded
     slab.c.version = 3
     with pytest.raises(RuntimeError, match="version"):

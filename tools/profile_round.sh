@@ -16,6 +16,10 @@ OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" gpurun_out/profiles_$TAG
 T="timeout 1200"
 has() { [[ " $PARTS " == *" $1 "* ]]; }
+# probes are built HERE, before any rocprofv3 pass: a bench leg never compiles (a compiler started under the profiler's preload
+# would be a GPU-initialised process that execs)
+[ -x tools/probes/mfma_energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_energy_probe tools/probes/mfma_energy_probe.hip
+[ -x tools/probes/dma_stream_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -mllvm -amdgpu-mfma-vgpr-form -o tools/probes/dma_stream_probe tools/probes/dma_stream_probe.hip
 
 if has eval; then
 $T rocprofv3 --kernel-trace --stats -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_stats.json" 2> "$OUT/stats.err"
@@ -30,10 +34,8 @@ echo "eval passes done after $SECONDS s"
 fi
 
 if has f16; then
-# (a) bare loops on this box (tools/probes/mfma_energy_probe.hip; built here if the binary did not travel)
-[ -x tools/probes/mfma_energy_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_energy_probe tools/probes/mfma_energy_probe.hip
+# (a) bare loops on this box (tools/probes/mfma_energy_probe.hip)
 $T ./tools/probes/mfma_energy_probe > "$OUT/f16_bare_loops.log" 2>&1
-[ -x tools/probes/dma_stream_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -mllvm -amdgpu-mfma-vgpr-form -o tools/probes/dma_stream_probe tools/probes/dma_stream_probe.hip
 $T ./tools/probes/dma_stream_probe > "$OUT/f16_stream_ladder.log" 2>&1
 # (b) the leg as shipped and with the selection ablated, un-profiled (wall numbers must not come from a profiled pass)
 F16="--no-cpu-baseline --no-verify --steps 1 --warmup 0 --legs eval_f16"
