@@ -40,9 +40,9 @@ sys.path.insert(0, ROOT)
 
 from bench_legs.common import *  # noqa: E402,F401,F403
 from bench_legs.common import _median_ms, _time_steps, _time_steps_each  # noqa: E402,F401
-from bench_legs.eval_legs import (ArrayTruth, SyntheticEvalData, dropoutnet_generator, eval_e2e_leg, eval_f16_leg,  # noqa: E402,F401
+from bench_legs.eval_legs import (ArrayTruth, SyntheticEvalData, dropoutnet_generator, eval_d64_leg, eval_e2e_leg, eval_f16_leg,  # noqa: E402,F401
                                   mask_topk_leg, midsize_eval_leg, validation_eval_leg)
-from bench_legs.train_legs import (torch_rocm_leg, train_dp_leg, train_legs, train_xl, train_xl_lightgcn, xl_graph)  # noqa: E402,F401
+from bench_legs.train_legs import (torch_rocm_leg, train_dp_leg, train_legs, train_xl, train_xl_dp_leg, train_xl_lightgcn, xl_graph)  # noqa: E402,F401
 
 
 def legs_summary(result):
@@ -64,7 +64,7 @@ def legs_summary(result):
         elif name == "eval_validation":
             for shape, v in leg.items():
                 out["eval_validation." + shape] = [round(v["ms"], 4), round(
-                    2.0 * 128 * v["users"] * v["items"] / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)]
+                    2.0 * v.get("d", 128) * v["users"] * v["items"] / (v["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)]
     if "eval_e2e" in result:
         e = result["eval_e2e"]
         out["eval_e2e.metrics_share_of_ranking"] = [round((e["seconds"]["membership_gpu"] + e["seconds"]["host_metrics"]) * 1e3, 1),
@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--cpu-sample-users", type=int, default=2048,
                     help="users of the CPU baseline (blocks of 256 against the WHOLE item table, SURVEY.md 8(d))")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="the CPU baseline stops after this many seconds")
-    ap.add_argument("--legs", default="eval_f16,mask_topk,train_xl,train_xl_lightgcn,train,eval_validation,eval_midsize,eval_e2e,torch_rocm",
+    ap.add_argument("--legs", default="eval_d64,eval_f16,mask_topk,train_xl,train_xl_lightgcn,train,eval_validation,eval_midsize,eval_e2e,torch_rocm",
                     help="N=1: secondary legs carried in the same JSON line (comma separated; 'none' = headline only)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the last timed step")
     args = ap.parse_args()
@@ -362,6 +362,10 @@ def main():
             leg = train_dp_leg(dev, world, rank)
             if rank == 0:
                 result["train_mf_dp"] = leg
+            torch.cuda.empty_cache()
+            leg = train_xl_dp_leg(dev, world, rank)       # the size SURVEY.md 8(e) names for the scaling figure
+            if rank == 0:
+                result["train_xl_dp"] = leg
         except Exception as e:
             if rank == 0:
                 result["train_mf_dp"] = {"error": repr(e)[:300]}
@@ -371,17 +375,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_train and args.dtype == "f32" and legs:
         del V, U, engine, blocks, out
         torch.cuda.empty_cache()
-        for leg_name, fn in (("eval_f16", lambda: eval_f16_leg(dev)), ("mask_topk", lambda: mask_topk_leg(dev)),
-                             ("train_xl", lambda: {"train_xl": train_xl(dev, 9, 2)}),
-                             ("train_xl_lightgcn", lambda: {"train_xl_lightgcn": train_xl_lightgcn(dev, 2, 1)}),
-                             ("train", lambda: train_legs(dev, not args.no_cpu_baseline)),
-                             ("eval_validation", lambda: validation_eval_leg(dev)),
-                             ("eval_midsize", lambda: midsize_eval_leg(dev)),
-                             ("eval_e2e", lambda: eval_e2e_leg(dev)),
-                             ("torch_rocm", lambda: torch_rocm_leg(dev))):
-            if leg_name in legs:
+        leg_fns = {"eval_d64": lambda: eval_d64_leg(dev), "eval_f16": lambda: eval_f16_leg(dev), "mask_topk": lambda: mask_topk_leg(dev),
+                   "train_xl": lambda: {"train_xl": train_xl(dev, 30, 3)},
+                   "train_xl_lightgcn": lambda: {"train_xl_lightgcn": train_xl_lightgcn(dev, 2, 1)},
+                   "train": lambda: train_legs(dev, not args.no_cpu_baseline),
+                   "eval_validation": lambda: validation_eval_leg(dev), "eval_midsize": lambda: midsize_eval_leg(dev),
+                   "eval_e2e": lambda: eval_e2e_leg(dev), "torch_rocm": lambda: torch_rocm_leg(dev)}
+        for leg_name in legs:                  # in the order --legs names them
+            if leg_name in leg_fns:
                 t_leg = time.perf_counter()
-                result.update(fn())
+                result.update(leg_fns[leg_name]())
                 torch.cuda.empty_cache()
                 wall[leg_name] = round(time.perf_counter() - t_leg, 1)
     shard_leg = result.get("eval_midsize", {}).get("%dx%d" % (Bu, I // 8)) if rank == 0 and world == 1 else None

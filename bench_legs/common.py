@@ -127,6 +127,24 @@ def verify_users(tag, got_s, got_i, users_rows, U_cpu, V_cpu, rowptr_blk, col_bl
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def gpu_clocks():
+    """{"sclk_mhz", "mclk_mhz"} of GPU 0 as rocm-smi reports them right now (an ordinary child process; None when the tool
+    is missing or says nothing parseable): what a bandwidth-bound leg ran at, beside its number."""
+    import re
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", "0", "--showclocks"], capture_output=True, text=True, timeout=20, env=env).stdout
+    except (OSError, subprocess.SubprocessError):
+        return None
+    out = {}
+    for key, name in (("sclk", "sclk_mhz"), ("mclk", "mclk_mhz"), ("fclk", "fclk_mhz")):
+        m = re.search(r"%s clock level:?\s*\S*:?\s*\(?(\d+)\s*Mhz" % key, txt, flags=re.I)
+        if m:
+            out[name] = int(m.group(1))
+    return out or None
+
+
 def measured_traffic(kernel_prefix, grid_threads, prefer=None):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_pmc.json, written by tools/profile_round.sh + tools/prof_summary.py in separate --pmc passes;

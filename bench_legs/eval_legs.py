@@ -25,9 +25,10 @@ def validation_eval_leg(dev):
     from coldrec_amd import ops
     out = {}
     rng = np.random.default_rng(11)
-    for name, n_users, n_items, mean_rated in (("movielens", 6040, 3706, 108), ("citeulike", 5551, 16980, 23)):
-        U = xavier_(n_users, 128, 21, dev, n_items)
-        V = xavier_(n_items, 128, 22, dev, n_users)
+    for name, n_users, n_items, mean_rated, d in (("movielens", 6040, 3706, 108, 128), ("citeulike", 5551, 16980, 23, 128),
+                                                  ("movielens.d64", 6040, 3706, 108, 64), ("citeulike.d64", 5551, 16980, 23, 64)):
+        U = xavier_(n_users, d, 21, dev, n_items)
+        V = xavier_(n_items, d, 22, dev, n_users)
         rated = [np.unique(rng.integers(0, n_items, mean_rated)) for _ in range(n_users)]
         rp, rc = ops.rated_csr(rated, dev)
         bm = ops.make_bitmap(n_items, np.where(rng.random(n_items) < 0.2)[0], dev)
@@ -35,26 +36,82 @@ def validation_eval_leg(dev):
         spread = {}
         for tag, ns, reps in (("library", 0, 50), ("fused_selection", 1, 5)):
             ms[tag], spread[tag] = _median_ms(lambda: ops.score_topk(U, None, V, 20, rp, rc, bm, n_splits=ns), reps)
-        out[name] = {"users": n_users, "items": n_items, "ms": ms["library"], "items_per_s": n_users * n_items / ms["library"] * 1e3,
+        out[name] = {"users": n_users, "items": n_items, "d": d, "ms": ms["library"], "items_per_s": n_users * n_items / ms["library"] * 1e3,
                      "ms_min_max": [spread["library"]["min"], spread["library"]["max"]], "timed_calls": 50,
                      "ms_fused_selection": ms["fused_selection"]}
     return {"eval_validation": out}
+
+
+def eval_d64_leg(dev, steps=3, warmup=1, n_items=10_000_000, d=64, Bu=131072, k=20):
+    """the headline's shape at the REFERENCE'S DEFAULT WIDTH (main.py:97 --emb_size 64; BASELINE configs[0] is
+    d=64): 131 072 users x 10 M items, fp32 d=64, rated CSR + 20 % cold bitmap, k=20.  Half the MFMA work per tile for the
+    same selection, so every non-MFMA cycle weighs twice; 64 users of the last step re-ranked by the oracle, bit for bit."""
+    from coldrec_amd import ops
+    V = item_shard(n_items, d, 0, n_items, dev)
+    n_blocks = 2
+    U = xavier_(Bu * n_blocks, d, 17, dev, 1_000_000)
+    rowptr, col = rated_lists(Bu * n_blocks, n_items, 50, seed=4)
+    cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
+    bitmap = ops.make_bitmap(n_items, cold, dev)
+    blocks = []
+    for b in range(n_blocks):
+        u0 = b * Bu
+        blocks.append((torch.arange(u0, u0 + Bu, dtype=torch.int32, device=dev),
+                       torch.from_numpy(rowptr[u0:u0 + Bu + 1] - rowptr[u0]).to(dev),
+                       torch.from_numpy(col[rowptr[u0]:rowptr[u0 + Bu]]).to(dev)))
+    events = HipEvents(steps)
+    for w in range(warmup):
+        ops.score_topk(U, *blocks[w % n_blocks][:1], V, k, *blocks[w % n_blocks][1:], bitmap)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        users, rp, rc = blocks[(warmup + s_) % n_blocks]
+        out = ops.score_topk(U, users, V, k, rp, rc, bitmap, kernel_events=events.pairs[s_])
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    kern_ms = float(np.mean(events.elapsed_ms()))
+    b_last = (warmup + steps - 1) % n_blocks
+    u0 = b_last * Bu
+    verified = verify_users("eval_d64", out[0].cpu().numpy(), out[1].cpu().numpy(), np.arange(u0, u0 + Bu, dtype=np.int64),
+                            U.cpu().numpy(), V.cpu().numpy(), rowptr[u0:u0 + Bu + 1] - rowptr[u0],
+                            col[rowptr[u0]:rowptr[u0 + Bu]], cold, k, n_check=64, seed=31)
+    flops = 2.0 * d * Bu * n_items
+    rt = route_of(Bu, n_items, d, k)
+    leg = {"metric": "ranked items/sec (full-catalogue eval)", "value": Bu * n_items / sec, "unit": "items/s",
+           "ms_per_step": sec * 1e3, "steps": steps, "dtype": "f32", "verified_users": verified,
+           "config": {"workload": "the headline's shape at the reference's default width: %d users x %d items per step, d=%d, "
+                                  "k=%d, fp32, rated CSR + 20%% cold-item bitmap" % (Bu, n_items, d, k)},
+           "roofline": {"bound": "mfma", "kernel": rt["label"], "route": rt["route"], "seeded": rt["seeded"],
+                        "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernel_ms": kern_ms,
+                        "flops_per_launch": flops, "traffic": None,
+                        "note": "v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate on the vector lanes: every VALU instruction of "
+                                "the selection costs its full issue time beside it (tools/probes/dma_stream_probe_f32.hip: the "
+                                "kernel's bare stream reaches 0.943 at d=64, 0.963 at d=128; DESIGN.md 4.1.3)"}}
+    tr = measured_traffic(rt["profile_patterns"], rt["grid_threads"])
+    if tr:
+        leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1]})
+    del V, U, out
+    return {"eval_d64": leg}
 
 
 def midsize_eval_leg(dev):
     """Mid-size catalogues (65 K - 1 M items, fp32 d=128, masks, k=20): the shapes between the trainers' validation and
     the headline, where the fused selection's slow path, not MFMA, sets the time.  Whatever route the
     library picks (dense block + wave-per-user ranking, per-wave kernel, workgroup kernel); 2 users per shape are
-    re-checked against the canonical oracle, bit for bit."""
+    re-checked against the canonical oracle, bit for bit.  Round 6: two shapes at the reference's default width (d=64) and
+    one at k=50 (lists too long for the LDS-DMA kernel's ring: the fallback route gets a number)."""
     from coldrec_amd import ops
     from oracle import oracle_np as orc
     out = {}
-    for n_users, n_items in ((8192, 262144), (65536, 131072), (131072, 262144), (131072, 1048576),
-                             (4096, 10_000_000),        # the reference's own user block (--bs 4096) on the S-EVAL catalogue
-                             (131072, 1_250_000)):      # one rank's item shard of the 8-GPU run
-
-        U = xavier_(n_users, 128, 31, dev, n_items)
-        V = item_shard(n_items, 128, 0, n_items, dev)
+    for n_users, n_items, d, k in ((8192, 262144, 128, 20), (65536, 131072, 128, 20), (131072, 262144, 128, 20),
+                                   (131072, 1048576, 128, 20),
+                                   (4096, 10_000_000, 128, 20),        # the reference's own user block (--bs 4096) on the S-EVAL catalogue
+                                   (131072, 1_250_000, 128, 20),       # one rank's item shard of the 8-GPU run
+                                   (8192, 262144, 64, 20), (131072, 1_250_000, 64, 20),   # main.py:97 --emb_size 64
+                                   (65536, 1048576, 128, 50)):         # main.py:95 --topN is free-form
+        U = xavier_(n_users, d, 31, dev, n_items)
+        V = item_shard(n_items, d, 0, n_items, dev)
         rowptr, col = rated_lists(n_users, n_items, 50, seed=4)
         cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
         bm = ops.make_bitmap(n_items, cold, dev)
@@ -62,7 +119,7 @@ def midsize_eval_leg(dev):
         hold = {}
 
         def call():
-            hold["res"] = ops.score_topk(U, None, V, 20, rp, rc, bm)
+            hold["res"] = ops.score_topk(U, None, V, k, rp, rc, bm)
 
         ms, sp = _median_ms(call, 5 if n_users * n_items < 4e10 else 3)
         res = hold["res"]
@@ -70,14 +127,15 @@ def midsize_eval_leg(dev):
         sub_rp = np.concatenate([[0], np.cumsum([rowptr[u + 1] - rowptr[u] for u in pick])]).astype(np.int64)
         sub_col = np.concatenate([col[rowptr[u]:rowptr[u + 1]] for u in pick]).astype(np.int64)
         ws, wi = orc.score_topk(U[torch.from_numpy(pick).to(dev)].cpu().numpy(), np.arange(len(pick), dtype=np.int64),
-                                V.cpu().numpy(), 20, sub_rp, sub_col, orc.make_bitmap(n_items, cold))
+                                V.cpu().numpy(), k, sub_rp, sub_col, orc.make_bitmap(n_items, cold))
         gs, gi = res[0][torch.from_numpy(pick).to(dev)].cpu().numpy(), res[1][torch.from_numpy(pick).to(dev)].cpu().numpy()
         if not (np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))):
             print(json.dumps({"error": "eval_midsize %d x %d differs from the oracle" % (n_users, n_items)}), flush=True)
             raise SystemExit(3)
-        tf = 2.0 * 128 * n_users * n_items / (ms * 1e-3) / 1e12
-        rt = route_of(n_users, n_items, 128, 20)
-        out["%dx%d" % (n_users, n_items)] = {"ms": ms, "items_per_s": n_users * n_items / ms * 1e3,
+        tf = 2.0 * d * n_users * n_items / (ms * 1e-3) / 1e12
+        rt = route_of(n_users, n_items, d, k)
+        tag = "%dx%d" % (n_users, n_items) + ("" if d == 128 else ".d%d" % d) + ("" if k == 20 else ".k%d" % k)
+        out[tag] = {"ms": ms, "items_per_s": n_users * n_items / ms * 1e3, "d": d, "k": k,
                                              "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, "verified_users": int(len(pick)),
                                              "route": {q: rt[q] for q in ("route", "seeded", "prefix_items", "n_splits", "kernel")}}
         del U, V, res

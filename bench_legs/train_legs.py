@@ -121,10 +121,16 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
     from coldrec_amd import ops as _ops
     from coldrec_amd.util.databuilder import bipartite_norm_adj_csr
     out = {}
-    B, d = 4096, 128
+    B = 4096
     data_cache = {}
-    for name, shape, layers, optim in (("train_mf", "movielens", 0, "adam"), ("train_mf_sgd", "movielens", 0, "sgd"),
-                                       ("train_lightgcn", "citeulike", 3, "adam")):
+    # the last two: the REFERENCE'S DEFAULT width and depth (main.py:97 --emb_size 64, :94 --layers 2; config/model_param.py),
+    # VERDICT r5 #1 -- kernel-side and end-to-end rates only (no second CPU baseline, half the epochs)
+    for name, shape, layers, optim, d, cpu_ok, n_timed, n_e2e in (
+            ("train_mf", "movielens", 0, "adam", 128, True, timed_epochs, e2e_epochs),
+            ("train_mf_sgd", "movielens", 0, "sgd", 128, True, timed_epochs, e2e_epochs),
+            ("train_lightgcn", "citeulike", 3, "adam", 128, True, timed_epochs, e2e_epochs),
+            ("train_mf_d64", "movielens", 0, "adam", 64, False, timed_epochs // 2, e2e_epochs // 2),
+            ("train_lightgcn_L2_d64", "citeulike", 2, "adam", 64, False, timed_epochs // 2, e2e_epochs // 2)):
         if shape not in data_cache:
             split = make_dataset(shape, "item", seed=1 if layers == 0 else 2, with_content=False)
             tr = split.warm_train
@@ -159,7 +165,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         # timed: EVERY epoch on its own (per epoch: the plans kernel + per-step factors + one graph replay), event to
         # event on the stream the epochs run on, host never waiting in between; the MEDIAN epoch is the leg's number and
         # the spread is reported -- one stalled epoch (a box hiccup) must not own a 20 ms window
-        n_ep = timed_epochs
+        n_ep = n_timed
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_ep + 1)]
         marks[0].record()
         for e in range(n_ep):
@@ -179,10 +185,10 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
             runner.run(*pref.get())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(e2e_epochs):
+        for _ in range(n_e2e):
             runner.run(*pref.get())
         torch.cuda.synchronize()
-        sec_e2e = (time.perf_counter() - t0) / e2e_epochs
+        sec_e2e = (time.perf_counter() - t0) / n_e2e
         pref.close()
         N, nnz = n_u + n_i, (len(val) if layers else 0)
         opt_bytes = 8 if optim == "sgd" else 32                        # dense Adam moves 32 B per element;
@@ -190,7 +196,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         if layers:                                                     # + 2L SpMM + layer mean fwd/bwd + dOUT zero
             bytes_step += 2 * layers * (nnz * 8 + (N + 1) * 8 + 2 * N * d * 4) + 2 * (layers + 2) * N * d * 4
         leg = {"metric": "BPR triples/sec (train)", "value": B / sec * (n / (len(steps) * B)), "unit": "triples/s",
-               "value_end_to_end": n / sec_e2e, "ms_per_epoch_end_to_end": sec_e2e * 1e3, "end_to_end_epochs": e2e_epochs,
+               "value_end_to_end": n / sec_e2e, "ms_per_epoch_end_to_end": sec_e2e * 1e3, "end_to_end_epochs": n_e2e,
                "ms_per_step": sec * 1e3, "steps_per_epoch": len(steps), "timed_epochs": n_ep,
                "ms_per_step_spread": {"median": float(np.median(ep_ms)) / len(steps), "min": float(ep_ms.min()) / len(steps),
                                       "max": float(ep_ms.max()) / len(steps), "mean": float(ep_ms.mean()) / len(steps),
@@ -199,7 +205,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
                                       "how": "each of %d hipGraph epochs timed event to event; ms_per_step = median epoch "
                                              "/ steps per epoch" % n_ep},
                "config": {"workload": "configs[%d] %s, %s-shaped synthetic (%d users x %d items, %d train triples), "
-                                      "d=%d, B=%d, %s" % (2 if layers else 1, "LightGCN L=3" if layers else "BPR-MF",
+                                      "d=%d, B=%d, %s" % (2 if layers else 1, "LightGCN L=%d" % layers if layers else "BPR-MF",
                                                           shape, n_u, n_i, n, d, B,
                                                           "plain SGD (torch.optim.SGD defaults)" if optim == "sgd" else "dense Adam")},
                "sampler": "host (csrc/sampler.hip, persistent worker thread, pinned async upload)",
@@ -218,7 +224,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
             what = "mf_step_kernel<32> = the whole step (FETCH_SIZE x2 + WRITE_SIZE); it keeps no gradient table"
         if tr:
             leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1], "traffic_note": what})
-        if with_cpu:
+        if with_cpu and cpu_ok:
             from oracle import ref_port
 
             def make_port():
@@ -305,6 +311,52 @@ def train_dp_leg(dev, world, rank):
                                    % (d, B, world, (n_u + n_i) * d * 4), "parallelism": "dp%d" % world}}
 
 
+def train_xl_dp_leg(dev, world, rank, steps=12, warm=3):
+    """N > 1 only: data-parallel training at the size SURVEY.md 8(e) names for it (S-TRAIN-XL: 1 M users x 10 M items, d=128,
+    global B = 65 536) with the touched-rows optimiser: row-ownership split of the backward, ONE all-gather of (row id, row)
+    slots per step (MFEngine._lazy_step_dp) instead of the dense split's 5.6 GB gradient all-reduce.  Tables, moments and
+    step counters are replicated (22.5 GB per rank); the plan, the catch-up, the forward and the optimiser run on every
+    replica, the backward is cut G ways.  When several ranks share one GPU (the gloo test hook) beyond two, the tables
+    are an eighth of the size -- named in the workload."""
+    import torch.distributed as dist
+    from coldrec_amd.train import DPContext, MFEngine
+    shared_gpu = os.environ.get("CRH_BENCH_BACKEND", "nccl") != "nccl"
+    scale = 8 if (shared_gpu and world > 2) else 1
+    n_u, n_i, d, B = 1_000_000 // scale, 10_000_000 // scale, 128, 65536
+    eng = MFEngine.from_table(xavier_(n_u + n_i, d, 1, dev, n_i), n_u, 1e-3, 1e-4)
+    eng.enable_data_parallel(DPContext(world, rank))
+    eng.enable_lazy_adam()
+    g = torch.Generator(device=dev).manual_seed(3)                   # same stream on every rank: replicated sampler
+    tri = [(torch.randint(0, n_u, (B,), generator=g, device=dev, dtype=torch.int32),
+            torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32),
+            torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32)) for _ in range(8)]
+    for s_ in range(warm):
+        eng.step(*tri[s_ % 8])
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        eng.step(*tri[(warm + s_) % 8])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    sec = float(dt.item()) / steps
+    eng.sync_tables()
+    chk = eng.E.view(torch.int32).to(torch.int64).sum().reshape(1)          # bit-level checksum of the flushed parameters
+    lo_, hi_ = chk.clone(), chk.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    return {"metric": "BPR triples/sec (train)", "value": B / sec, "unit": "triples/s", "ms_per_step": sec * 1e3, "steps": steps,
+            "scaling": "strong", "replicas_identical": bool(lo_.item() == hi_.item()),
+            "exchange_bytes_per_step": eng.exchange_bytes_per_step,
+            "dense_gradient_allreduce_bytes_it_replaces": (n_u + n_i) * d * 4,
+            "config": {"workload": "S-TRAIN-XL%s BPR-MF: %d users x %d items, d=%d, global B=%d, dense Adam replayed on touched "
+                                   "rows; backward split by row ownership over %d ranks, one all-gather of (row id, row) slots "
+                                   "per step" % (" / %d (ranks share one GPU)" % scale if scale > 1 else "", n_u, n_i, d, B, world),
+                       "parallelism": "dp%d" % world}}
+
+
 def train_xl(dev, steps, warm, lazy=False):
     """HBM-roofline case for the training kernels: tables far beyond every cache.  ``lazy``: the touched-rows
     replay of dense Adam (same bits, crh_adam_rows_f32) instead of the dense pass; the per-batch reverse index
@@ -319,9 +371,11 @@ def train_xl(dev, steps, warm, lazy=False):
     tri = [(torch.randint(0, n_u, (B,), generator=g, device=dev, dtype=torch.int32),
             torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32),
             torch.randint(0, n_i, (B,), generator=g, device=dev, dtype=torch.int32)) for _ in range(8)]
+    clocks0 = gpu_clocks()
     sec, spread = _time_steps_each(lambda s: eng.step(*tri[s % 8]), steps, warm)
+    clocks1 = gpu_clocks()
     out = {"metric": "BPR triples/sec (train)", "value": B / sec, "unit": "triples/s", "ms_per_step": sec * 1e3,
-           "ms_per_step_spread": spread,
+           "ms_per_step_spread": spread, "gpu_clocks_before_after": [clocks0, clocks1],
            "config": {"workload": "S-TRAIN-XL: BPR-MF, 1M users x 10M items, d=128, B=65536, %s"
                                   % ("dense Adam replayed on touched rows (bit-identical)" if lazy else "dense Adam")}}
     if lazy:
@@ -342,12 +396,21 @@ def train_xl(dev, steps, warm, lazy=False):
                                  "would move %d bytes per step" % (24 * d * B + 32 * (n_u + n_i) * d)}})
     else:
         bytes_step = 24 * d * B + 32 * (n_u + n_i) * d
+        # in-run normaliser (this leg reads 0.60 or 0.71 of the 8 TB/s peak depending on the box and on what ran
+        # before it): a plain device-to-device copy of one 5.6 GB table, same process, same moment -- read + write bytes per second
+        # -- and the step's traffic as a fraction of it
+        cp_ms, _ = _median_ms(lambda: eng.G.copy_(eng.M), 7, warm=2)
+        copy_gbs = 2.0 * eng.M.numel() * 4 / (cp_ms * 1e-3) / 1e9
+        eng.G.zero_()
         tr = measured_traffic("adam_dense_kernel", float(16384 * 256))      # dominant kernel of the step
         out["roofline"] = {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                            "traffic": tr[0] if tr else None,
                            "traffic_source": ("committed profile " + tr[1]) if tr else None,
-                           "traffic_note": "adam_dense_kernel FETCH_SIZE x2 + WRITE_SIZE per launch" if tr else None}
+                           "traffic_note": "adam_dense_kernel FETCH_SIZE x2 + WRITE_SIZE per launch" if tr else None,
+                           "copy_GBps_same_run": copy_gbs, "frac_of_copy": bytes_step / sec / 1e9 / copy_gbs,
+                           "copy_note": "torch device-to-device copy of one 5.6 GB table (read + write bytes / s), median of 7, "
+                                        "right after the timed steps"}
     return out
 
 

@@ -55,6 +55,10 @@ SIGNATURES = {
     "crh_bpr_fwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "crh_bpr_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _sz, _vp]),
+    "crh_bpr_bwd_owned_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "crh_rows_pack_cap": (_i64, [_i64, _i32]),
+    "crh_rows_pack_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "crh_rows_unpack_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "crh_adam_dense_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64,
                                   _i64, _i32, _vp, _vp]),
     "crh_adam_rows_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i64, _vp, _f64, _f64, _f64,

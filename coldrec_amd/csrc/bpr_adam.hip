@@ -56,6 +56,8 @@ struct BprArgs {
                            // split, where they were all-reduced over the ranks -- or NULL: reduce `partials`
     float* sums_out;       // [4] forward-only entry point: where bpr_sums_kernel leaves the batch sums
     int64_t B_global;      // batch size the means / norms refer to (== B unless data-parallel)
+    int own_mod, own_rem;  // deterministic backward over the plan's row slots w with w % own_mod == own_rem only (1, 0 = all):
+                           // the row-ownership split of the data-parallel touched-rows step (crh_bpr_bwd_owned_f32)
 };
 
 template <int G>
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a, in
             const int e0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
             const int e1 = user_side ? pv.uptr[w + 1] : pv.iptr[w - pv.n_u + 1];
             if (e1 - e0 > BPR_HEAVY) continue;                    // on the heavy list
+            if (a.own_mod > 1 && (int)(w % a.own_mod) != a.own_rem) continue;   // another rank's row
             f32x4 own = {0.f, 0.f, 0.f, 0.f}, acc = {0.f, 0.f, 0.f, 0.f};
             if (on) own = reinterpret_cast<const f32x4*>((user_side ? a.tu : a.tp) + row * a.d)[lig];
             grad_row_entries<G>(a, k, user_side, user_side ? pv.ulist : pv.ilist, e0, e1, lig, on, lig, own, acc);
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_bwd_rows_kernel(BprArgs a, in
     const int heavy_blocks = (int)gridDim.x - light_blocks;
     for (int h = (int)blockIdx.x - light_blocks; h < pv.n_heavy; h += heavy_blocks) {
         const int64_t w = pv.heavy[h];
+        if (a.own_mod > 1 && (int)(w % a.own_mod) != a.own_rem) continue;       // (block-uniform: no barrier is skipped by a part of the block)
         const bool user_side = w < pv.n_u;
         const int64_t row = user_side ? pv.urow[w] : pv.irow[w - pv.n_u];
         const int r0 = user_side ? pv.uptr[w] : pv.iptr[w - pv.n_u];
@@ -1644,7 +1648,7 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
                const int32_t* user_idx, const int32_t* pos_idx, const int32_t* neg_idx, int64_t batch,
                int64_t global_batch, float reg, float* grad_user, float* grad_pos, float* grad_neg,
                float* loss_out, const int32_t* plan, const float* totals, float* sums_out, void* workspace,
-               size_t workspace_bytes, void* stream, const char* who) {
+               size_t workspace_bytes, void* stream, const char* who, int own_mod = 1, int own_rem = 0) {
     CRH_CHECK_ARG(user_table && pos_table && neg_table, "%s: NULL table", who);
     CRH_CHECK_ARG(batch > 0 && global_batch >= batch, "%s: empty batch / global batch smaller than the local one", who);
     CRH_CHECK_ARG(d >= 4 && d % 4 == 0, "%s: d=%d must be a positive multiple of 4", who, d);
@@ -1673,6 +1677,8 @@ int bpr_launch(int phases, const float* user_table, const float* pos_table, cons
     a.totals = totals;
     a.sums_out = sums_out;
     a.B_global = global_batch;
+    a.own_mod = own_mod;
+    a.own_rem = own_rem;
     const int G = pick_group(d);
     const int64_t per_block = BPR_THREADS / G;
     int64_t blocks = (batch + per_block - 1) / per_block;
@@ -1748,6 +1754,102 @@ extern "C" int crh_bpr_bwd_f32(const float* user_table, const float* pos_table, 
     return bpr_launch(2, user_table, pos_table, neg_table, d, user_idx, pos_idx, neg_idx, batch, global_batch, reg,
                       grad_user, grad_pos, grad_neg, loss_out, plan, sums, nullptr, workspace, workspace_bytes,
                       stream, "crh_bpr_bwd_f32");
+}
+
+// Row-ownership split of the deterministic backward (data-parallel touched-rows step): every rank holds the
+// whole batch, its plan, the score differences of a forward over the whole batch (same workspace) and the batch sums; rank r
+// sums and stores only the gradient rows of the plan's row slots w with w % own_mod == own_rem -- each row by ONE rank, in
+// the plan's entry order, i.e. the very bits of the single-GPU launch -- and the ranks then exchange whole rows
+// (crh_rows_pack_f32 -> all-gather -> crh_rows_unpack_f32).
+extern "C" int crh_bpr_bwd_owned_f32(const float* user_table, const float* item_table, int d, const int32_t* user_idx,
+                                     const int32_t* pos_idx, const int32_t* neg_idx, int64_t batch, float reg,
+                                     const float* sums, float* grad_user, float* grad_item, float* loss_out,
+                                     const int32_t* plan, int own_mod, int own_rem, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    CRH_CHECK_ARG(sums && plan, "crh_bpr_bwd_owned_f32: NULL sums / plan");
+    CRH_CHECK_ARG(own_mod >= 1 && own_rem >= 0 && own_rem < own_mod, "crh_bpr_bwd_owned_f32: own_rem=%d outside 0..%d", own_rem,
+                  own_mod - 1);
+    return bpr_launch(2, user_table, item_table, item_table, d, user_idx, pos_idx, neg_idx, batch, batch, reg, grad_user,
+                      grad_item, grad_item, loss_out, plan, sums, nullptr, workspace, workspace_bytes, stream,
+                      "crh_bpr_bwd_owned_f32", own_mod, own_rem);
+}
+
+namespace {
+// slot w of a plan -> table row (users first), or -1 past the plan's rows
+__device__ __forceinline__ int64_t plan_slot_row(const PlanView& pv, int64_t w, int64_t user_rows) {
+    if (w < pv.n_u) return pv.urow[w];
+    if (w < (int64_t)pv.n_u + pv.n_i) return user_rows + pv.irow[w - pv.n_u];
+    return -1;
+}
+
+// out_ids[m], out_rows[m] = the table row of plan slot own_rem + m * own_mod (m < cap; -1 / untouched past the plan's rows)
+template <int G>
+__global__ __launch_bounds__(256) void rows_pack_kernel(const float* __restrict__ table, const int32_t* __restrict__ plan,
+                                                        int64_t user_rows, int own_mod, int own_rem, int64_t cap, int d,
+                                                        int32_t* __restrict__ out_ids, float* __restrict__ out_rows) {
+    const PlanView pv = plan_view(plan);
+    const int lig = threadIdx.x % G;
+    const int64_t m = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (m >= cap) return;
+    const int64_t row = plan_slot_row(pv, own_rem + m * own_mod, user_rows);
+    if (lig == 0) out_ids[m] = (int32_t)row;
+    if (row < 0) return;
+    for (int c = lig; c < (d >> 2); c += G)
+        reinterpret_cast<f32x4*>(out_rows + m * d)[c] = reinterpret_cast<const f32x4*>(table + row * d)[c];
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void rows_unpack_kernel(float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                          const float* __restrict__ rows, int64_t n, int d) {
+    const int lig = threadIdx.x % G;
+    const int64_t m = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (m >= n) return;
+    const int64_t row = ids[m];
+    if (row < 0) return;
+    for (int c = lig; c < (d >> 2); c += G)
+        reinterpret_cast<f32x4*>(table + row * d)[c] = reinterpret_cast<const f32x4*>(rows + m * d)[c];
+}
+}  // namespace
+
+// The exchange format of the row-ownership split: `cap` = crh_rows_pack_cap(batch, own_mod) slots of (row id, d floats), the
+// gradient rows a rank owns, in slot order; ids past the plan's rows are -1.  pack reads `table` (the gradient table) at the
+// owned rows; unpack STORES rows into it (every row has exactly one owner: nothing is added), ids < 0 skipped.
+extern "C" int64_t crh_rows_pack_cap(int64_t batch, int own_mod) {
+    return batch > 0 && own_mod >= 1 ? (3 * batch + own_mod - 1) / own_mod : 0;
+}
+
+extern "C" int crh_rows_pack_f32(const float* table, const int32_t* plan, int64_t batch, int64_t user_rows, int d, int own_mod,
+                                 int own_rem, int32_t* out_ids, float* out_rows, void* stream) {
+    CRH_CHECK_ARG(table && plan && out_ids && out_rows, "crh_rows_pack_f32: NULL pointer");
+    CRH_CHECK_ARG(batch > 0 && d >= 4 && d % 4 == 0 && d <= 256, "crh_rows_pack_f32: batch=%lld d=%d", (long long)batch, d);
+    CRH_CHECK_ARG(own_mod >= 1 && own_rem >= 0 && own_rem < own_mod, "crh_rows_pack_f32: own_rem=%d outside 0..%d", own_rem, own_mod - 1);
+    const int64_t cap = crh_rows_pack_cap(batch, own_mod);
+    const int G = pick_group(d);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dispatch_group(G, [&](auto gc) -> int {
+        constexpr int GG = decltype(gc)::value;
+        const int64_t per_block = 256 / GG;
+        hipLaunchKernelGGL(rows_pack_kernel<GG>, dim3((unsigned)((cap + per_block - 1) / per_block)), dim3(256), 0, st, table, plan,
+                           user_rows, own_mod, own_rem, cap, d, out_ids, out_rows);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    });
+}
+
+extern "C" int crh_rows_unpack_f32(float* table, const int32_t* ids, const float* rows, int64_t n, int d, void* stream) {
+    CRH_CHECK_ARG(table && ids && rows, "crh_rows_unpack_f32: NULL pointer");
+    CRH_CHECK_ARG(n >= 0 && d >= 4 && d % 4 == 0 && d <= 256, "crh_rows_unpack_f32: n=%lld d=%d", (long long)n, d);
+    if (n == 0) return CRH_OK;
+    const int G = pick_group(d);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dispatch_group(G, [&](auto gc) -> int {
+        constexpr int GG = decltype(gc)::value;
+        const int64_t per_block = 256 / GG;
+        hipLaunchKernelGGL(rows_unpack_kernel<GG>, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), 0, st, table, ids, rows,
+                           n, d);
+        CRH_HIP(hipGetLastError());
+        return CRH_OK;
+    });
 }
 
 extern "C" int crh_adam_dense_f32(float* p0, float* g0, float* m0, float* v0, int64_t n0, float* p1, float* g1,

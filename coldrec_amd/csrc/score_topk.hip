@@ -820,6 +820,7 @@ struct RoutePlan {
     bool dense;        // score block + crh_mask_topk_f32
     bool use_wg;       // a workgroup kernel (register-staged ring, or the LDS-DMA form when use_dma)
     bool use_dma;
+    int dma_mode;      // CRH_SCORE_DMA as read for this call
     bool can_pack;     // the workspace holds the fragment-ordered copy of the shard
     int wg_waves_l;    // waves of the workgroup that is launched
     int wg_slots_l;    // workgroups resident per round
@@ -859,7 +860,10 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     // CRH_SCORE_DMA (read per call): 0 never, anything else (default) on
     const int dma_mode = getenv("CRH_SCORE_DMA") ? atoi(getenv("CRH_SCORE_DMA")) : 1;
     const size_t tb_off = lists_bytes(n_users, k) + packed_bytes(n_items, d, esz) + sync_bytes(n_items);   // the tiles' candidate bits
-    const bool dma_shape = dma_mode && (d * esz == 512 || d * esz == 256) && score_dma_lds_bytes(d * esz, k) <= 160 * 1024 &&
+    // (fp16 d=128 was measured on it too, round 6: 0.482 against 0.479 of 2.5 PF for the ring kernel at 10 M items, 0.305
+    // against 0.347 at 1.25 M -- a 1 024-cycle tile is too short for one barrier + one threshold test each: not routed)
+    const bool dma_rows = esz == 2 ? d == 256 : (d == 128 || d == 64);
+    const bool dma_shape = dma_mode && dma_rows && score_dma_ring_slots(esz, d, k, dma_mode) > 0 &&
                            (!has_bitmap || workspace_bytes >= tb_off + tbits_bytes(n_items));
     // fp32 d=64 (the reference's default width) has no register-staged ring kernel: a workgroup kernel only as the DMA form
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : ((d == 128 && wg_waves == 8) || (d == 64 && dma_shape));
@@ -891,6 +895,7 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     r.dense = dense_mode && n_splits == 0 && !seeded && dense_b && has_workspace && workspace_bytes >= dense_b;
     r.use_wg = use_wg;
     r.use_dma = use_dma;
+    r.dma_mode = dma_mode;
     r.can_pack = can_pack;
     r.wg_waves_l = wg_waves_l;
     r.wg_slots_l = wg_slots_l;
@@ -947,7 +952,7 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     // fp16, 512-byte rows (configs[4]): at 16x the fp32 MFMA rate a slow-path event costs as much as a whole tile and, in
     // the workgroup kernels, stalls the whole CU: 9 % of the launch at 10 M items (profiles/r05_f16_*).  A 4 096-item prefix
     // takes k (1 + ln(P / k)) of every user's k (1 + ln(N / k)) events out of the stream: 282 -> 156 per user at 10 M items
-    const bool f16_stream = !cuts && esz == 2 && (d == 256 || d == 128) && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
+    const bool f16_stream = !cuts && esz == 2 && d == 256 && n_users >= 32768 && n_items >= ((int64_t)1 << 20);
     // fp32, 512-byte rows on the workgroup kernels (the headline): the same, worth less at the fp32 rate -- 131 072 x 3 M 0.883 ->
     // 0.895, x 4 M 0.895 -> 0.905, x 10 M 0.9245 -> 0.9285 (16 384-item prefix; 4 096 / 8 192 at 10 M: +0.35 / +0.38 %).  8 192 items
     // keep the prefix's score block (4.3 GB at 131 072 users) inside what the packed copy of such a shard takes anyway
@@ -1174,7 +1179,10 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     int rc;
     // XCD soft lockstep (xcd_window_sync): only when every wave is resident at once (one round) and all waves
     // walk the same tile range (no item-range cuts); counters sit behind the packed copy in the workspace
-    static const int sync_win = CRH_TUNE_ENV("CRH_SCORE_SYNC_WINDOW") ? atoi(CRH_TUNE_ENV("CRH_SCORE_SYNC_WINDOW")) : 128;
+    // (an even count of at least 2: the workgroup kernels count whole loop trips of two tiles, and the counters below are sized
+    // from THIS value -- an odd window made kernel and host disagree about the number of windows)
+    static const int sync_win_raw = CRH_TUNE_ENV("CRH_SCORE_SYNC_WINDOW") ? atoi(CRH_TUNE_ENV("CRH_SCORE_SYNC_WINDOW")) : 128;
+    static const int sync_win = sync_win_raw <= 0 ? 0 : std::max(2, sync_win_raw & ~1);
     a.xcd_sync = nullptr;
     a.sync_window = sync_win;
     a.sync_stride = 0;
@@ -1214,7 +1222,7 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 #endif
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
     if (use_dma) {
-        rc = launch_score_dma(esz, d, a, st);
+        rc = launch_score_dma(esz, d, rp.dma_mode, a, st);
     } else if (esz == 4 && use_wg) {
         rc = launch_score_wg<float, 128, 2, 8>(a, st);
     } else if (use_wg) {

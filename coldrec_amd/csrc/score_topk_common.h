@@ -346,7 +346,9 @@ __device__ __forceinline__ bool xcd_window_sync(unsigned* cnt, int64_t win, int 
 constexpr int WG_RING = 3;   // item-tile slots in LDS (workgroup kernels)
 
 // score_topk_dma.hip (built with -mllvm -amdgpu-mfma-vgpr-form): the LDS-DMA workgroup kernel for 512- and 256-byte rows
-__attribute__((visibility("hidden"))) int launch_score_dma(int esz, int d, const ScoreArgs& a, hipStream_t stream);
-__attribute__((visibility("hidden"))) size_t score_dma_lds_bytes(int row_bytes, int k);
+// (mode = CRH_SCORE_DMA: 1 default, 3 = barrier form for fp32 too)
+__attribute__((visibility("hidden"))) int launch_score_dma(int esz, int d, int mode, const ScoreArgs& a, hipStream_t stream);
+__attribute__((visibility("hidden"))) size_t score_dma_lds_bytes(int row_bytes, int k, int ring_slots, bool flags);
+__attribute__((visibility("hidden"))) int score_dma_ring_slots(int esz, int d, int k, int mode);
 
 }  // namespace crh_score

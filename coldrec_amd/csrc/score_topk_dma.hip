@@ -10,10 +10,10 @@
 namespace crh_score {
 namespace {
 
-constexpr int DMA_RING = 4;         // item-tile slots in LDS
 constexpr int DMA_NW = 4;           // waves per workgroup (one per SIMD)
 constexpr int DMA_UPW = 128;        // users per wave
 constexpr int TBITS_B = 2 * 64 * 4; // two blocks of 64 tiles' candidate bits
+constexpr int FLAGS_B = 64;         // flag form: ready[<= 8] and done[<= 8] counters of the ring slots
 
 // per-wave LDS of the DMA kernel: the lists (scores, ids, fill) and a 192-bit membership filter of each user's rated list.
 // The rated-list bounds are read from memory when a candidate's filter says "maybe rated" (rare).  k = 20: 188 bytes per user,
@@ -23,6 +23,27 @@ __host__ __device__ constexpr size_t dma_wave_lds_bytes(int K) {
     return (size_t)DMA_UPW * K * 8 + (size_t)DMA_UPW * 4 + (size_t)DMA_UPW * DMA_FW * 4;
 }
 __device__ __forceinline__ unsigned rated_hash192(int gi) { return ((((unsigned)gi * 2654435761u) >> 16) * (32u * DMA_FW)) >> 16; }
+
+// The 4 UW MFMAs of one fp32 chunk, as Elem<float>::mma (k pairs in the order x, z, y, w, users interleaved), with
+// hook(integral_constant<BASE + i>) run right behind MFMA i: the flag form hangs its few non-MFMA instructions (polls, bumps,
+// DMA issue) into single MFMA gaps this way -- an fp32 MFMA runs 64 cycles, a gap hides about a dozen scalar / LDS / VMEM
+// instructions, and a block of them in FRONT of a group's MFMAs is paid in full (the first flag form did that: -2 % at
+// d=128, -4 % at d=64 on 10 M-item streams against the barrier form).
+template <int K>
+__device__ __forceinline__ float f4_comp(const f32x4& v) {
+    if constexpr (K == 0) return v.x;
+    else if constexpr (K == 1) return v.z;
+    else if constexpr (K == 2) return v.y;
+    else return v.w;
+}
+template <int UW, int BASE, typename H>
+__device__ __forceinline__ void mma_f32_hooked(f32x16 (&acc)[UW], const f32x4& c, const f32x4 (&b)[UW], H&& hook) {
+    [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+        ((acc[I % UW] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_comp<I / UW>(c), f4_comp<I / UW>(b[I % UW]), acc[I % UW], 0, 0, 0),
+          hook(std::integral_constant<int, BASE + I>{})),
+         ...);
+    }(std::make_integer_sequence<int, 4 * UW>{});
+}
 
 // Slow path of one 32x32 accumulator tile, as tile_slow_path (score_topk_common.h) with every memory round trip of the
 // common case removed: the candidate-bitmap bits of the tile come out of LDS (tb: the tile's 32 bits, fetched by DMA with
@@ -141,9 +162,26 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
 // Users, thresholds and lists are per wave exactly as in the other kernels: results are identical.
 // The loop runs n_steps + 1 bodies: body j multiplies tile j (the last one a clamped duplicate nobody selects) and
 // selects tile j - 1.
-template <typename T, int D>
+//
+// FL = the FLAG form (fp32, round 6).  The barrier form above gives the four waves no slack at all: a slow-path event of one
+// wave (~0.4 us) is paid by the whole workgroup at the next barrier, and events are what separates the kernel from its bare
+// MFMA stream (tools/probes/dma_stream_probe_f32.hip: stream 0.943 / 0.963 of the fp32 peak at d = 64 / 128, kernel 0.884 /
+// 0.925; with the barriers ablated the d=64 kernel gets 2.5 of its 3.5 points of event cost back).  Here the ring is
+// guarded by two monotonic LDS counters per slot instead:
+//   ready[s]  += 1 by every wave when ITS pieces of the tile in slot s have landed (it waits for its own DMA of the body
+//                before, a whole tile ago, just before it issues the next one at the head of a body);
+//   done[s]   += 1 by every wave when its last fragment read of the tile in slot s has returned.
+// A wave reads tile t only once ready = 4 (t / R + 1) and refills the slot of tile t - R only once done = 4 (t / R): all
+// dependencies point at earlier tiles, so there is no cycle; the polls are one ds_read_b32 issued a group ahead (it rides
+// the counted fragment waits) + v_readfirstlane + a scalar compare, and spin only when a partner really is behind.  With
+// R = 4 slots and a prefetch distance of 2 tiles a wave may run (NG - 2) / NG of a tile ahead of the slowest reader and a
+// whole tile ahead of the slowest refiller: several events' worth at fp32 tile times (3.4 / 6.8 us).  fp16 tiles last
+// 0.85 us -- less than a DMA round trip -- so the fp16 kernel keeps the barrier form.
+template <typename T, int D, int R, bool FL>
 __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     constexpr int NW = DMA_NW, UW = 4, UPW = DMA_UPW;
+    constexpr int PF = FL ? R / 2 : 3;                 // body j issues the DMA of tile j + PF
+    static_assert(FL ? (R == 4 || R == 8) && sizeof(T) == 4 : R == 4, "ring shape");
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int NCH = ROWB / 32;
     constexpr int TILE_B = NCH * 1024;
@@ -163,15 +201,21 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     const int K = a.k;
     const int i = lane & 31, h = lane >> 5;
 
-    char* ring = smem;                                  // [DMA_RING][TILE_B]
-    unsigned* tbits = reinterpret_cast<unsigned*>(smem + DMA_RING * TILE_B);   // [2][64]
+    char* ring = smem;                                  // [R][TILE_B]
+    unsigned* tbits = reinterpret_cast<unsigned*>(smem + R * TILE_B);   // [2][64]
+    unsigned* flags = tbits + TBITS_B / 4;             // FL: ready[R] at 0, done[R] at 8; slots of the prologue's tiles start ready
+    if constexpr (FL) {
+        // (published by the prologue's barrier.  Tiles 0 .. PF-2 of the prologue start complete; tile PF-1 is bumped by body 0
+        // like every later tile: the prologue waited for all of them)
+        if (threadIdx.x < 16) flags[threadIdx.x] = threadIdx.x < PF - 1 ? (unsigned)NW : 0u;
+    }
     const int64_t NT = (a.n_items + 31) >> 5;
     const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
     const int64_t split_end = (t1 << 5) < a.n_items ? (t1 << 5) : a.n_items;
     const int64_t slot0w = ug * UPW;
 
     // ---- this wave's lists
-    char* wl = smem + DMA_RING * TILE_B + TBITS_B + (size_t)wave * dma_wave_lds_bytes(K);
+    char* wl = smem + R * TILE_B + TBITS_B + (FL ? FLAGS_B : 0) + (size_t)wave * dma_wave_lds_bytes(K);
     float* ls = reinterpret_cast<float*>(wl);           // [UPW][K]
     int* li = reinterpret_cast<int*>(ls + UPW * K);      // [UPW][K]
     int* cnt = li + UPW * K;                            // [UPW]
@@ -323,9 +367,52 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 #endif
     };
     static_assert(GR == 2, "lds_group / lds_wait are written for two chunks per group");
+    // ---- flag form: counters, polls (see the kernel's comment)
+    const uint32_t flags_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned*)flags;
+    unsigned rflag = 0, dflag = 0;                       // poll results in flight (landed at the next counted fragment wait)
+    auto flag_read = [&](unsigned& dst, int word) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(flags_lds + 4u * (unsigned)word));
+#endif
+    };
+    // (all 64 lanes add to the one counter -- lane 0 a one, the others zeros: one instruction and no exec-mask detour; the
+    // compiler's form of `if (lane == 0) atomicAdd` is a dozen instructions with two branches)
+    const unsigned bump_val = lane == 0 ? 1u : 0u;
+    auto flag_bump = [&](int word) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_add_u32 %0, %1" ::"v"(flags_lds + 4u * (unsigned)word), "v"(bump_val) : "memory");
+#endif
+    };
+    auto flag_land = [&](unsigned& f) __attribute__((always_inline)) {     // everything LDS issued so far has landed (it was long ago)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f));
+#endif
+    };
+    // the counted wait of a group in the flag form: everything but the GR fragment reads issued last has landed -- the
+    // fragments of this group AND of the next one (a group is 2048 cycles of MFMAs: they landed long ago), the polls, the bumps
+    auto lds_wait_fl = [&](f32x4(&x)[GR], unsigned& f0, unsigned& f1) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(f0), "+v"(f1) : "i"(GR));
+#endif
+    };
+    // spin until counter `word` reaches `want` (rare: a partner wave is behind -- in a slow-path event, or waiting for its XCD)
+    auto flag_spin = [&](unsigned have, int word, unsigned want) __attribute__((always_inline)) {
+        unsigned v = __builtin_amdgcn_readfirstlane(have);
+        if (__builtin_expect(v >= want, 1) || (CRH_ABLATE(a.ablate) & 4)) return;
+        unsigned spins = 0;
+        do {
+            __builtin_amdgcn_s_sleep(1);
+            unsigned t;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(flags_lds + 4u * (unsigned)word) : "memory");
+#endif
+            v = __builtin_amdgcn_readfirstlane(t);
+            if (++spins > (1u << 24)) __builtin_trap();      // seconds: a protocol bug must not hang the GPU (nor pass silently)
+        } while (v < want);
+    };
 
     // body j: MFMAs of tile j (ring slot s_cur) into accumulator set P, threshold test of tile j-1 out of set 1-P;
-    // s_nxt = slot of tile j+1, s_fill = slot tile j-1 left = slot of tile j+3
+    // s_nxt = slot of tile j+1, s_fill = slot of tile j + PF (barrier form: the slot tile j-1 left)
     auto body = [&](auto Pc, int j, int s_cur, int s_nxt, int s_fill) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value, Q = 1 - P;
         const uint32_t src = ring_lds + s_cur * TILE_B, srcn = ring_lds + s_nxt * TILE_B;
@@ -334,21 +421,25 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
         auto group = [&](auto Gc) __attribute__((always_inline)) {
             constexpr int g = decltype(Gc)::value;
             // fragments of the group after next (two groups = 16 MFMAs of slack for the LDS round trip); the last two groups
-            // of a tile read the first two of tile j+1, visible since this body's barrier
+            // of a tile read the first two of tile j+1, visible since this body's barrier (flag form: since the poll above)
             if constexpr (g + 2 < NG) lds_group(c[(g + 2) & 3], src, std::integral_constant<int, g + 2>{});
             else lds_group(c[(g + 2) & 3], srcn, std::integral_constant<int, g + 2 - NG>{});
-            if constexpr (g == BG) {
+            if constexpr (!FL && g == BG) {
                 dma_wait_but_newest_tile();             // my pieces of tile j+1 (issued two tiles ago) have landed
                 if (!(CRH_ABLATE(a.ablate) & 4)) __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
-            lds_wait(c[g & 3], std::integral_constant<int, 2 * GR>{});   // this group's fragments (read two groups ago) are in
-            // tile j+3 into the slot tile j-1 left (every wave is past it); the scheduler places the DMA instructions
+            if constexpr (FL) {
+                lds_wait_fl(c[g & 3], rflag, dflag);
+            } else {
+                lds_wait(c[g & 3], std::integral_constant<int, 2 * GR>{});   // this group's fragments (read two groups ago) are in
+            }
+            // barrier form: tile j+3 into the slot tile j-1 left (every wave is past it); the scheduler places the DMA instructions
             // BETWEEN this group's MFMAs (they follow the wait in program order).  With it the candidate bits of the block
             // of 64 tiles that holds tile j + 32: the current block again (same bytes) in its first half, the NEXT block in
             // its second half -- into the buffer of the block before, whose last tile was selected at the head of body
-            // 64 b, before every wave's barrier of that body
-            if constexpr (g == BG) {
+            // 64 b, before every wave's barrier of that body (flag form: 32 tiles behind every wave, which are at most R apart)
+            if constexpr (!FL && g == BG) {
                 dma_tbits((t0 + j + 32) >> 6);
                 dma_tile(j + 3, s_fill);
                 // one DMA instruction and a few of its address instructions per MFMA gap instead of all of them in one gap
@@ -361,17 +452,59 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (the DMA)
                 }
             }
-#pragma unroll
-            for (int jj = 0; jj < GR; ++jj) {
-                if constexpr (g == 0) {
-                    if (jj == 0) {
-#pragma unroll
-                        for (int u = 0; u < UW; ++u)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[P][u][r] = 0.0f;
+            if constexpr (FL) {
+                // The flag protocol, one piece per MFMA gap (n = index of the MFMA just issued, 0 .. 8 UW - 1 in this group):
+                //   group 0      n=0  my pieces of tile j + PF - 1 (issued a whole tile ago) have landed -> publish them
+                //                n=1  may the slot of tile j + PF - R be refilled?  (poll issued in the last group of the body before)
+                //                n=2  the tile bits, n=3 tile j + PF
+                //   group NG-3   n=0  poll: is tile j+1 complete?   n=8: the poll has landed, n=9: spin if it is not
+                //   group NG-2   n=0  every fragment read of tile j has returned (the group's counted wait left only its own reads
+                //                     -- of tile j+1 -- outstanding): the slot may be refilled
+                //   group NG-1   n=0  poll for the next body's refill, n=8: landed
+                auto hook = [&](auto Nc) __attribute__((always_inline)) {
+                    constexpr int n = decltype(Nc)::value;
+                    constexpr bool any = (g == 0 && n <= 3) || (g == NG - 3 && (n == 0 || n == 8 || n == 9)) || (g == NG - 2 && n == 0) ||
+                                         (g == NG - 1 && (n == 0 || n == 8));
+                    if constexpr (any) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (g == 0 && n == 0) {
+                        dma_wait_all();
+                        flag_bump((j + PF - 1) & (R - 1));
                     }
+                    if constexpr (g == 0 && n == 1) flag_spin(dflag, 8 + s_fill, (unsigned)NW * (unsigned)((j + PF) / R));
+                    if constexpr (g == 0 && n == 2) dma_tbits((t0 + j + 32) >> 6);
+                    if constexpr (g == 0 && n == 3) dma_tile(j + PF, s_fill);
+                    if constexpr (g == NG - 3 && n == 0) flag_read(rflag, s_nxt);
+                    if constexpr (g == NG - 3 && n == 8) flag_land(rflag);
+                    if constexpr (g == NG - 3 && n == 9) flag_spin(rflag, s_nxt, (unsigned)NW * (unsigned)((j + 1) / R + 1));
+                    if constexpr (g == NG - 2 && n == 0) flag_bump(8 + s_cur);
+                    if constexpr (g == NG - 1 && n == 0) flag_read(dflag, 8 + ((j + 1 + PF) & (R - 1)));
+                    if constexpr (g == NG - 1 && n == 8) flag_land(dflag);
+                    if constexpr (any) __builtin_amdgcn_sched_barrier(0);
+                };
+                if constexpr (g == 0) {
+#pragma unroll
+                    for (int u = 0; u < UW; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[P][u][r] = 0.0f;
                 }
-                Elem<T>::template mma<UW>(acc[P], c[g & 3][jj], b[g * GR + jj]);
+                if constexpr (sizeof(T) == 4) {
+                    [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
+                        (mma_f32_hooked<UW, JJ * 4 * UW>(acc[P], c[g & 3][JJ], b[g * GR + JJ], hook), ...);
+                    }(std::make_integer_sequence<int, GR>{});
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < GR; ++jj) {
+                    if constexpr (g == 0) {
+                        if (jj == 0) {
+#pragma unroll
+                            for (int u = 0; u < UW; ++u)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[P][u][r] = 0.0f;
+                        }
+                    }
+                    Elem<T>::template mma<UW>(acc[P], c[g & 3][jj], b[g * GR + jj]);
+                }
             }
             if constexpr (g == 1) {
 #pragma unroll
@@ -404,13 +537,13 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     if (n_steps > 0) {
         dma_tbits(t0 >> 6);
         dma_tbits((t0 >> 6) + 1);
-        dma_tile(0, 0);
-        dma_tile(1, 1);
-        dma_tile(2, 2);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) dma_tile(p, p);
         dma_wait_all();
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                     // (also publishes the flag form's initial counters)
         lds_group(c[0], ring_lds, std::integral_constant<int, 0>{});
         lds_group(c[1], ring_lds, std::integral_constant<int, 1>{});
+        if constexpr (FL) flag_read(dflag, 8 + (PF & (R - 1)));      // body 0's refill poll (nothing has been read yet: 0 >= 0)
         int s0 = 0;
         // XCD soft lockstep (see xcd_window_sync): wave 0 reports / waits for the workgroup, the others meet it at the
         // tile's barrier
@@ -452,16 +585,17 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
                             __hip_atomic_fetch_add(sync_cnt + 1 + wdw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            const int s1 = (s0 + 1) & 3, s2 = (s0 + 2) & 3, s3 = (s0 + 3) & 3;
-            body(std::integral_constant<int, 0>{}, j, s0, s1, s3);          // tile j+3 -> slot of tile j-1 = s0 - 1 = s3
+            const int s1 = (s0 + 1) & (R - 1), s2 = (s0 + 2) & (R - 1);
+            // barrier form: tile j+3 -> slot of tile j-1 = s0 + 3, tile j+4 -> slot of tile j; flag form: tile j + PF -> its own slot
+            body(std::integral_constant<int, 0>{}, j, s0, s1, (s0 + PF) & (R - 1));
             if (j + 1 > n_steps) break;
-            body(std::integral_constant<int, 1>{}, j + 1, s1, s2, s0);      // tile j+4 -> slot of tile j
+            body(std::integral_constant<int, 1>{}, j + 1, s1, s2, (s1 + PF) & (R - 1));
             s0 = s2;
         }
         dma_wait_all();   // the prefetches of the last bodies must not outlive the workgroup's LDS ...
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[2][0]), "+v"(c[2][1]),
-                     "+v"(c[3][0]), "+v"(c[3][1]));   // ... nor the last fragment reads their registers
+                     "+v"(c[3][0]), "+v"(c[3][1]), "+v"(rflag), "+v"(dflag));   // ... nor the last fragment reads / polls their registers
 #endif
     }
 
@@ -480,10 +614,10 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     }
 }
 
-template <typename T, int D>
+template <typename T, int D, int R, bool FL>
 int launch_score_dma_t(const ScoreArgs& a, hipStream_t stream) {
-    const size_t lds = score_dma_lds_bytes(D * (int)sizeof(T), a.k);
-    auto kern = score_topk_dma_kernel<T, D>;
+    const size_t lds = score_dma_lds_bytes(D * (int)sizeof(T), a.k, R, FL);
+    auto kern = score_topk_dma_kernel<T, D, R, FL>;
     CRH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const int64_t blocks = ((a.n_ugroups + DMA_NW - 1) / DMA_NW) * a.n_splits;
@@ -494,15 +628,26 @@ int launch_score_dma_t(const ScoreArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-size_t score_dma_lds_bytes(int row_bytes, int k) {
-    return (size_t)DMA_RING * (row_bytes / 32) * 1024 + TBITS_B + DMA_NW * dma_wave_lds_bytes(k);
+size_t score_dma_lds_bytes(int row_bytes, int k, int ring_slots, bool flags) {
+    return (size_t)ring_slots * (row_bytes / 32) * 1024 + TBITS_B + (flags ? FLAGS_B : 0) + DMA_NW * dma_wave_lds_bytes(k);
+}
+
+// Which form a launch takes: fp16 the barrier form (4 slots); fp32 the flag form -- 512-byte rows 4 slots, 256-byte rows
+// 8 slots when the lists leave room for them (k <= 20), else 4.  0 = the lists do not fit beside any ring.
+int score_dma_ring_slots(int esz, int d, int k, int mode) {
+    const bool fl = esz == 4 && mode != 3;                           // CRH_SCORE_DMA=3: the barrier form for fp32 too (A/B)
+    if (fl && d * esz == 256 && score_dma_lds_bytes(256, k, 8, true) <= 160 * 1024) return 8;
+    return score_dma_lds_bytes(d * esz, k, 4, fl) <= 160 * 1024 ? 4 : 0;
 }
 
 // 512-byte rows (fp32 d=128: the headline; fp16 d=256: configs[4]) and 256-byte rows (fp32 d=64: the reference's default
-// width, main.py:97 --emb_size 64 = configs[0]; fp16 d=128): half the ring, half the B registers, the same loop.
-int launch_score_dma(int esz, int d, const ScoreArgs& a, hipStream_t stream) {
-    if (esz == 4) return d == 128 ? launch_score_dma_t<float, 128>(a, stream) : launch_score_dma_t<float, 64>(a, stream);
-    return d == 256 ? launch_score_dma_t<_Float16, 256>(a, stream) : launch_score_dma_t<_Float16, 128>(a, stream);
+// width, main.py:97 --emb_size 64 = configs[0]): half the tile, half the B registers, the same loop.
+int launch_score_dma(int esz, int d, int mode, const ScoreArgs& a, hipStream_t stream) {
+    const int slots = score_dma_ring_slots(esz, d, a.k, mode);
+    if (esz == 2) return launch_score_dma_t<_Float16, 256, 4, false>(a, stream);
+    if (mode == 3) return d == 128 ? launch_score_dma_t<float, 128, 4, false>(a, stream) : launch_score_dma_t<float, 64, 4, false>(a, stream);
+    if (d == 128) return launch_score_dma_t<float, 128, 4, true>(a, stream);
+    return slots == 8 ? launch_score_dma_t<float, 64, 8, true>(a, stream) : launch_score_dma_t<float, 64, 4, true>(a, stream);
 }
 
 }  // namespace crh_score

@@ -287,6 +287,42 @@ def bpr_bwd(user_table, pos_table, neg_table, user_idx, pos_idx, neg_idx, global
     return loss_out
 
 
+def bpr_bwd_owned(user_table, item_table, user_idx, pos_idx, neg_idx, reg: float, sums: torch.Tensor, grad_user, grad_item,
+                  loss_out: Optional[torch.Tensor], workspace: torch.Tensor, plan: torch.Tensor, own_mod: int, own_rem: int):
+    """Deterministic backward over the plan's row slots ``w % own_mod == own_rem`` only (crh_bpr_bwd_owned_f32): the
+    row-ownership split of the data-parallel touched-rows step; ``workspace`` carries a forward over the WHOLE batch."""
+    _need_cuda(user_table, item_table, user_idx, pos_idx, neg_idx, sums, grad_user, grad_item, workspace, plan)
+    d, batch = _bpr_checks(user_table, item_table, item_table, user_idx, pos_idx, neg_idx)
+    rc = _lib.lib().crh_bpr_bwd_owned_f32(_lib.ptr(user_table), _lib.ptr(item_table), d, _lib.ptr(user_idx), _lib.ptr(pos_idx),
+                                          _lib.ptr(neg_idx), batch, float(reg), _lib.ptr(sums), _lib.ptr(grad_user),
+                                          _lib.ptr(grad_item), _lib.ptr(loss_out), _lib.ptr(plan), int(own_mod), int(own_rem),
+                                          _lib.ptr(workspace), workspace.numel(), _lib.current_stream())
+    _lib.check(rc, "crh_bpr_bwd_owned_f32")
+    return loss_out
+
+
+def rows_pack_cap(batch: int, own_mod: int) -> int:
+    return int(_lib.lib().crh_rows_pack_cap(int(batch), int(own_mod)))
+
+
+def rows_pack(table, plan, batch: int, user_rows: int, own_mod: int, own_rem: int, out_ids, out_rows) -> None:
+    """(row id, row) of every plan slot this rank owns, from ``table`` (crh_rows_pack_f32); ids past the plan's rows are -1."""
+    _need_cuda(table, plan, out_ids, out_rows)
+    assert out_ids.dtype == torch.int32 and out_rows.dtype == torch.float32 and out_rows.is_contiguous() and table.is_contiguous()
+    assert out_ids.numel() >= rows_pack_cap(batch, own_mod) and out_rows.shape[0] >= out_ids.numel()
+    _lib.check(_lib.lib().crh_rows_pack_f32(_lib.ptr(table), _lib.ptr(plan), int(batch), int(user_rows), table.shape[1],
+                                            int(own_mod), int(own_rem), _lib.ptr(out_ids), _lib.ptr(out_rows),
+                                            _lib.current_stream()), "crh_rows_pack_f32")
+
+
+def rows_unpack(table, ids, rows) -> None:
+    """table[ids[e]] = rows[e] for ids[e] >= 0 (crh_rows_unpack_f32)."""
+    _need_cuda(table, ids, rows)
+    assert ids.dtype == torch.int32 and rows.dtype == torch.float32 and rows.is_contiguous() and ids.is_contiguous()
+    _lib.check(_lib.lib().crh_rows_unpack_f32(_lib.ptr(table), _lib.ptr(ids), _lib.ptr(rows), ids.numel(), table.shape[1],
+                                              _lib.current_stream()), "crh_rows_unpack_f32")
+
+
 def bpr_workspace(batch: int, device) -> torch.Tensor:
     """A private scratch buffer for a bpr_fwd / bpr_bwd pair (the shared grow-only workspace may be
     reused by other ops between the two calls)."""

@@ -89,6 +89,8 @@ class _TableState:
         self.dp = dp
         self.sums = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._dp_ws, self._dp_cap = None, 0
+        self._xc = None                      # exchange buffers of the touched-rows step (_lazy_step_dp)
+        self.exchange_bytes_per_step = 0
 
     def _ws(self, batch: int) -> torch.Tensor:
         """This engine's OWN BPR scratch (grown only outside graph capture): a captured epoch keeps its raw pointer."""
@@ -192,7 +194,7 @@ class MFEngine(_TableState):
     lazy = False
 
     def enable_lazy_adam(self) -> None:
-        assert self.dp is None, "the touched-rows optimiser is single-GPU"
+        """Single GPU, or data-parallel (``enable_data_parallel`` first or afterwards): see ``_lazy_step_dp``."""
         if self.optimizer != 'adam':       # SGD never moves an untouched row: sgd_rows already is the touched-rows form
             return
         self.lazy = True
@@ -252,26 +254,64 @@ class MFEngine(_TableState):
         if self._table is None or upto > self._table_steps:
             n = max(1024, 2 * upto)
             sc = np.zeros((n + 1, 2), np.float32)
-            sc[1:] = ops.adam_step_scalars(1, n, self.lr)
+            sc[1:] = self.k.adam_step_scalars(1, n, self.lr)
             self._table, self._table_steps = torch.from_numpy(sc).to(self.device), n
         return self._table
 
     def sync_tables(self) -> None:
         """Bring every row up to the current step (no-op for the dense optimiser)."""
         if self.lazy and self._dirty:
-            ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, None, 0, self.user_num, self.step_count,
-                          self._scalar_table(self.step_count), mode=2)
+            self.k.adam_rows(self.E, self.G, self.M, self.V, self.last_step, None, 0, self.user_num, self.step_count,
+                             self._scalar_table(self.step_count), mode=2)
             self._dirty = False
 
     def _lazy_step(self, user_idx, pos_idx, neg_idx, plan, loss) -> None:
         U, B, t = self.user_num, user_idx.shape[0], self.step_count + 1
         if plan is None:
-            plan = ops.build_plans_device(user_idx, pos_idx, neg_idx, B)[0]
+            plan = self.k.build_plans_device(user_idx, pos_idx, neg_idx, B)[0]
         tab = self._scalar_table(t)
-        ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=0)
+        self.k.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=0)
         self.k.bpr_fwd_bwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.reg,
                            self.G[:U], self.G[U:], self.G[U:], loss, plan=plan, workspace=self._ws(B))
-        ops.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=1)
+        self.k.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=1)
+        self.step_count, self._dirty = t, True
+
+    def _lazy_step_dp(self, user_idx, pos_idx, neg_idx, plan, loss) -> None:
+        """The touched-rows step over G replicas (SURVEY.md 8(e) at S-TRAIN-XL: the dense split would all-reduce a 5.6 GB
+        gradient table per step).  Split by ROW OWNERSHIP, not by batch slice: every rank holds the whole batch and builds
+        the same plan, catches the batch's rows up and runs the (cheap) forward over the whole batch -- identical sums on
+        every replica; the backward, the part that gathers 2-3 rows per entry, is cut: rank r sums the gradient rows of the
+        plan's row slots w with w % G == r, each row in the plan's entry order, i.e. with the bits of the single-GPU launch.
+        ONE all-gather of (row id, d floats) for at most ceil(3 B / G) rows per rank (100 MB per step at B = 65 536, d = 128,
+        G = 8), every replica stores the rows into its gradient table and applies crh_adam_rows_f32 over the whole plan:
+        replicas stay bit-identical and equal the single-GPU touched-rows run bit for bit."""
+        U, B, t = self.user_num, user_idx.shape[0], self.step_count + 1
+        G, r = self.dp.world, self.dp.rank
+        if plan is None:
+            plan = self.k.build_plans_device(user_idx, pos_idx, neg_idx, B)[0]
+        tab = self._scalar_table(t)
+        k = self.k
+        k.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=0)
+        ws = self._ws(B)
+        k.bpr_fwd(self.E[:U], self.E[U:], self.E[U:], user_idx, pos_idx, neg_idx, self.sums, ws)
+        k.bpr_bwd_owned(self.E[:U], self.E[U:], user_idx, pos_idx, neg_idx, self.reg, self.sums, self.G[:U], self.G[U:], loss,
+                        ws, plan, G, r)
+        cap = k.rows_pack_cap(B, G)
+        if self._xc is None or self._xc[0].shape[0] < G * cap:
+            dev = self.device
+            # ids and rows travel in ONE buffer of 32-bit words: slot = [row id, 3 pad words | d floats as bit patterns]
+            self._xc = (torch.empty((G * cap, self.d + 4), dtype=torch.int32, device=dev),
+                        torch.zeros((cap, self.d + 4), dtype=torch.int32, device=dev),
+                        torch.empty(cap, dtype=torch.int32, device=dev), torch.empty((cap, self.d), dtype=torch.float32, device=dev))
+        full, part, ids, rows = self._xc
+        full, part, ids, rows = full[: G * cap], part[:cap], ids[:cap], rows[:cap]
+        k.rows_pack(self.G, plan, B, U, G, r, ids, rows)
+        part[:, 0] = ids
+        part[:, 4:] = rows.view(torch.int32)
+        self.dp.all_gather_rows(full, part)
+        self.exchange_bytes_per_step = int(full.numel() * 4)
+        k.rows_unpack(self.G, full[:, 0].contiguous(), full[:, 4:].contiguous().view(torch.float32))
+        k.adam_rows(self.E, self.G, self.M, self.V, self.last_step, plan, B, U, t, tab, mode=1)
         self.step_count, self._dirty = t, True
 
     def step(self, user_idx: torch.Tensor, pos_idx: torch.Tensor, neg_idx: torch.Tensor,
@@ -280,6 +320,8 @@ class MFEngine(_TableState):
         without atomics; without it gradients are accumulated with fp32 atomics."""
         U = self.user_num
         loss = self.loss if loss_out is None else loss_out
+        if self.lazy and self.dp is not None:
+            return self._lazy_step_dp(user_idx, pos_idx, neg_idx, plan, loss)
         if self.lazy:
             return self._lazy_step(user_idx, pos_idx, neg_idx, plan, loss)
         if self.dp is not None:

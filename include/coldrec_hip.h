@@ -206,6 +206,26 @@ int crh_bpr_bwd_f32(const float* user_table, const float* pos_table, const float
                     size_t workspace_bytes, void* stream);
 
 /*
+ * Row-ownership split of the same backward, for the data-parallel TOUCHED-ROWS step (SURVEY.md 8(e), S-TRAIN-XL: the
+ * dense gradient all-reduce of the split above is 5.6 GB per step there).  Every rank holds the whole batch, its plan,
+ * the forward of the whole batch (crh_bpr_fwd_f32 over `workspace`) and its `sums`; rank r computes only the gradient rows
+ * of the plan's row slots w with w % own_mod == own_rem -- each row summed by ONE rank in the plan's entry order, i.e. the
+ * bits of the single-GPU launch of model/MF.py:22-26's backward.  The ranks then exchange whole rows: crh_rows_pack_f32
+ * gathers the owned rows of the gradient table into crh_rows_pack_cap(batch, own_mod) slots of (row id, d floats) (ids past
+ * the plan's rows: -1), one all-gather moves them, crh_rows_unpack_f32 STORES every rank's rows into the gradient table
+ * (each row has exactly one owner: nothing is added), and crh_adam_rows_f32 runs over the whole plan on every replica.
+ * item_table is the shared positive / negative table (a plan requires it); d <= 256.
+ */
+int crh_bpr_bwd_owned_f32(const float* user_table, const float* item_table, int d, const int32_t* user_idx,
+                          const int32_t* pos_idx, const int32_t* neg_idx, int64_t batch, float reg, const float* sums,
+                          float* grad_user, float* grad_item, float* loss_out, const int32_t* plan, int own_mod,
+                          int own_rem, void* workspace, size_t workspace_bytes, void* stream);
+int64_t crh_rows_pack_cap(int64_t batch, int own_mod);
+int crh_rows_pack_f32(const float* table, const int32_t* plan, int64_t batch, int64_t user_rows, int d, int own_mod,
+                      int own_rem, int32_t* out_ids, float* out_rows, void* stream);
+int crh_rows_unpack_f32(float* table, const int32_t* ids, const float* rows, int64_t n, int d, void* stream);
+
+/*
  * torch.optim.Adam(lr) defaults, dense, for up to two tensors in one launch (model/MF.py:14,27:
  * user table then item table, equal step counters).  Mirrors torch/optim/adam.py
  * _single_tensor_adam op for op; scalar factors are evaluated in double.  step starts at 1.

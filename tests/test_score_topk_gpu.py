@@ -463,13 +463,14 @@ def test_f16_workgroup_kernel_is_exact(d, n_splits):
 @pytest.mark.parametrize("dtype,n_items,n_splits,k,d", [("f16", 200_003, 1, 20, 256), ("f16", 200_003, 0, 20, 256), ("f16", 70_001, 2, 50, 256),
                                                        ("f32", 200_003, 1, 20, 128), ("f32", 70_001, 3, 20, 128),
                                                        ("f32", 200_003, 1, 20, 64), ("f32", 200_003, 0, 20, 64), ("f32", 70_001, 3, 28, 64),
-                                                       ("f16", 200_003, 1, 20, 128), ("f16", 70_001, 2, 10, 128)])
+                                                       ("f32", 200_003, 1, 5, 64), ("f32", 40_000, 1, 20, 128)])
 def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits, k, d, monkeypatch):
     """The LDS-DMA workgroup kernel (512-byte rows: fp16 d=256, fp32 d=128; 256-byte rows: fp32 d=64 = the reference's default
-    width, fp16 d=128) against the kernel the library runs without it (CRH_SCORE_DMA=0: the register-staged ring kernel; fp32
+    width) against the kernel the library runs without it (CRH_SCORE_DMA=0: the register-staged ring kernel; fp32
     d=64 has none and takes the per-wave kernel) on thousands of tiles with continuous embeddings: every list of every
     user bit-identical (a tile read before its DMA landed, or overwritten while a slower wave still reads it, shows up
-    here), plus sampled users against the oracle."""
+    here), plus sampled users against the oracle.  fp32 runs the FLAG form of the kernel (ring slots guarded by LDS counters,
+    the four waves up to a tile apart; 8 slots at d=64 while k <= 20, 4 beyond) and, CRH_SCORE_DMA=3, its barrier form."""
     from coldrec_amd import ops
     rng = np.random.default_rng(n_items + n_splits)
     n_users = 32768 + 77
@@ -490,6 +491,10 @@ def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits
     if k <= 20 or d * U.itemsize == 256:
         assert ops.score_topk_route(n_users, n_items, d, k, half=dtype == "f16", n_splits=max(n_splits, 1))["route"] == "fused-dma"
     s1, i1 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
+    if dtype == "f32":
+        monkeypatch.setenv("CRH_SCORE_DMA", "3")                            # the barrier form of the same kernel
+        s3, i3 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)
+        assert torch.equal(i1, i3) and torch.equal(s1.view(torch.int32), s3.view(torch.int32))
     monkeypatch.setenv("CRH_SCORE_DMA", "0")
     assert ops.score_topk_route(n_users, n_items, d, k, half=dtype == "f16", n_splits=max(n_splits, 1))["route"] != "fused-dma"
     s0, i0 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=n_splits)

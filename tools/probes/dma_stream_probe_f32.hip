@@ -133,6 +133,13 @@ __global__ __launch_bounds__(256, 1) void k(const char* __restrict__ tiles, int 
             if constexpr (g == 1 && (FEAT & 2) && !(FEAT & 64)) {
 #pragma unroll
                 for (int u = 0; u < UW; ++u) m[u] = (FEAT & 32) ? max16_chain(acc[Q][u]) : max16(acc[Q][u]);
+                if constexpr ((FEAT & 128) != 0) {      // spread: SPREAD VALU per MFMA gap over the group's 32 MFMAs
+#pragma unroll
+                    for (int q = 0; q < 32; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, (FEAT & 1024) ? 1 : 2, 0);
+                    }
+                }
             }
             if constexpr (g >= 1 && g <= 4 && NG > 4 && (FEAT & 2) && (FEAT & 64)) {      // one user tile per group
                 m[g - 1] = (FEAT & 32) ? max16_chain(acc[Q][g - 1]) : max16(acc[Q][g - 1]);
@@ -228,7 +235,10 @@ int main(int argc, char** argv) {
         run<8 | 4 | 2 | 1, N>(dt, ntb, bits, dout, dclk, n_tiles, "+ DMA stream, barrier, threshold test");              \
         run<8 | 4 | 2 | 1 | 16, N>(dt, ntb, bits, dout, dclk, n_tiles, "+ tile-bits piece (the kernel's stream)");       \
         run<8 | 4 | 1 | 256, N>(dt, ntb, bits, dout, dclk, n_tiles, "DMA stream WITHOUT the barrier (no test)");         \
-        run<8 | 4 | 512, N>(dt, ntb, bits, dout, dclk, n_tiles, "static tile + barrier per tile (no DMA, no test)");
+        run<8 | 4 | 512, N>(dt, ntb, bits, dout, dclk, n_tiles, "static tile + barrier per tile (no DMA, no test)");          \
+        run<8 | 4 | 2 | 128, N>(dt, ntb, bits, dout, dclk, n_tiles, "threshold test VALU spread 2 per MFMA gap (static tile)");     \
+        run<8 | 4 | 2 | 128 | 1024, N>(dt, ntb, bits, dout, dclk, n_tiles, "threshold test VALU spread 1 per MFMA gap (static tile)"); \
+        run<8 | 4 | 2 | 32, N>(dt, ntb, bits, dout, dclk, n_tiles, "threshold test as two-operand max chain (static tile)");
         LADDER(8)
         LADDER(16)
     }
