@@ -395,10 +395,10 @@ def main():
         result["predicted_scaling_8gpu"] = {
             "value": 8.0 * shard_leg["items_per_s"] / value,
             "shard_items_per_s": shard_leg["items_per_s"], "whole_items_per_s": value,
-            "note": "8 x rate(one rank's %d-item shard) / rate(the whole %d-item table) on one GPU; the shard runs the per-wave "
-                    "kernel (%.3f of the fp32 MFMA peak), the whole table the workgroup kernel (%.3f): no measured 8-GPU "
-                    "number exists, the driver's SCALE run is the only one" % (
-                        I // 8, I, shard_leg["frac_of_fp32_mfma_peak"], result["roofline"]["frac"])}
+            "note": "8 x rate(one rank's %d-item shard) / rate(the whole %d-item table) on one GPU; the shard's route is %s (%.3f "
+                    "of the fp32 MFMA peak), the whole table's %s (%.3f): no measured 8-GPU number exists, the driver's SCALE "
+                    "run is the only one" % (I // 8, I, shard_leg["route"]["route"], shard_leg["frac_of_fp32_mfma_peak"],
+                                             result["roofline"]["route"]["route"], result["roofline"]["frac"])}
     if rank == 0:
         wall["total"] = round(time.perf_counter() - t_main, 1)
         result["wall_s"] = wall

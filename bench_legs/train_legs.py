@@ -184,11 +184,21 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         for _ in range(3):                                            # warm: speculation running, worker core at speed
             runner.run(*pref.get())
         torch.cuda.synchronize()
+        pref.timing, t_run = [], []
         t0 = time.perf_counter()
         for _ in range(n_e2e):
-            runner.run(*pref.get())
+            tri_e = pref.get()
+            t_r = time.perf_counter()
+            runner.run(*tri_e)
+            t_run.append(time.perf_counter() - t_r)
         torch.cuda.synchronize()
         sec_e2e = (time.perf_counter() - t0) / n_e2e
+        tm = np.array(pref.timing) if pref.timing else np.zeros((1, 4))
+        e2e_host = {"wait_for_sampler_ms": float(np.median(tm[:, 0])) * 1e3, "publish_state_and_upload_ms": float(np.median(tm[:, 1])) * 1e3,
+                    "start_next_epoch_ms": float(np.median(tm[:, 2])) * 1e3, "runner_launch_ms": float(np.median(t_run)) * 1e3,
+                    "note": "medians per epoch on the calling thread: get() = wait + publish/upload + start of the next epoch's "
+                            "sampling; run() = copies, plans, per-step factors, graph replay (all asynchronous launches)"}
+        pref.timing = None
         pref.close()
         N, nnz = n_u + n_i, (len(val) if layers else 0)
         opt_bytes = 8 if optim == "sgd" else 32                        # dense Adam moves 32 B per element;
@@ -209,7 +219,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
                                                           shape, n_u, n_i, n, d, B,
                                                           "plain SGD (torch.optim.SGD defaults)" if optim == "sgd" else "dense Adam")},
                "sampler": "host (csrc/sampler.hip, persistent worker thread, pinned async upload)",
-               "host_sampler_s_per_epoch": t_sample, "device_plan_s_per_epoch": t_plans,
+               "host_sampler_s_per_epoch": t_sample, "device_plan_s_per_epoch": t_plans, "end_to_end_host_ms": e2e_host,
                "roofline": {"bound": "hbm", "achieved": bytes_step / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": bytes_step / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_step": bytes_step,
                             "traffic": None, "note": "whole step (all kernels of one optimiser step)"}}

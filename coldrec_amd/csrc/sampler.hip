@@ -15,6 +15,8 @@
 // additionally from NumPy's stream for the positives; next_batch_cgrc (:303-336) draws from NumPy only and
 // returns list(set(...)), whose order is CPython's set-table slot order (restated in IntSet).
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -345,6 +347,17 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     // it is, so the data-dependent branch of the rejection loop -- mispredicted on a quarter of the draws -- is gone.
     // The draws of one key block are consumed through a local window (no generator state in the loop).
     MT19937& g = s->rng;
+#ifdef CRH_PROFILE
+    static const bool timing = getenv("CRH_SAMPLER_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    double t_gather = 0, t_draw = 0, t_reject = 0;
+#endif
+    // The gather of the shuffled records rides in the shuffle's shadow: position ii is final once its (accepted) swap is done
+    // -- Fisher-Yates from the top never touches it again -- so user / positive item of slot ii are fetched and stored right
+    // there (a rejected draw writes the not-yet-final record: the accepted one overwrites it).  The loop is bound by its
+    // chain through ii and the swapped words; the extra load is independent of that chain and costs next to nothing, where
+    // the separate pass over all n slots was a third of an epoch (random 8-byte reads from a 5 MB table).
+    const int64_t* __restrict__ recs = s->rec_ui.data();
     {
         int32_t* __restrict__ ord = s->order.data();
         int64_t i = n - 1;
@@ -363,13 +376,22 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
                     const int32_t a = ord[ii], b = ord[j];
                     ord[ii] = b;
                     ord[j] = a;
+                    const int64_t ui = recs[b];
+                    user_out_host[ii] = (int32_t)(uint32_t)ui;
+                    pos_out_host[ii] = (int32_t)(ui >> 32);
                     ii -= ok;
                 }
                 g.pos += used;
                 i = ii;
             }
         }
+        const int64_t u0 = recs[ord[0]];                      // slot 0 is never the top of a swap
+        user_out_host[0] = (int32_t)(uint32_t)u0;
+        pos_out_host[0] = (int32_t)(u0 >> 32);
     }
+#ifdef CRH_PROFILE
+    const auto tp1 = std::chrono::steady_clock::now();
+#endif
     const uint32_t imax = (uint32_t)(s->n_items - 1);
     const uint32_t imask = imax ? 0xffffffffu >> __builtin_clz(imax) : 0u;
     // masked-rejection draws of `cnt` item ids, again walked per raw draw: write, then advance only if accepted
@@ -394,8 +416,6 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     s->check.resize((size_t)std::min(batch_size, n) + 1);
     s->next_check.resize(s->check.size());
     s->redraw.resize(s->check.size());
-    const int64_t* __restrict__ rec = s->rec_ui.data();
-    const int32_t* __restrict__ ordc = s->order.data();
     const bool use_bits = s->words_per_user != 0;
     const uint64_t* __restrict__ bits = s->bits.data();
     const int64_t wpu = s->words_per_user;
@@ -405,13 +425,19 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     };
     for (int64_t lo = 0; lo < n; lo += batch_size) {
         const int64_t hi = std::min(lo + batch_size, n);
-        for (int64_t t = lo; t < hi; ++t) {
-            const int64_t ui = rec[ordc[t]];
-            user_out_host[t] = (int32_t)(uint32_t)ui;
-            pos_out_host[t] = (int32_t)(ui >> 32);
-        }
+#ifdef CRH_PROFILE
+        const auto tb0 = std::chrono::steady_clock::now();
+#endif
+#ifdef CRH_PROFILE
+        const auto tb1 = std::chrono::steady_clock::now();
+#endif
         // first round over the whole batch without materialising the slot list (utils.py:141-153)
         draw_items(neg_out_host + lo, hi - lo);
+#ifdef CRH_PROFILE
+        const auto tb2 = std::chrono::steady_clock::now();
+        t_gather += std::chrono::duration<double>(tb1 - tb0).count();
+        t_draw += std::chrono::duration<double>(tb2 - tb1).count();
+#endif
         int32_t* chk = s->check.data();
         int64_t nc = 0;
         for (int64_t t = lo; t < hi; ++t) {                  // compaction without a branch on the outcome
@@ -432,7 +458,15 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
             chk = s->check.data();
             nc = nn;
         }
+#ifdef CRH_PROFILE
+        t_reject += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb2).count();
+#endif
     }
+#ifdef CRH_PROFILE
+    if (timing)
+        fprintf(stderr, "[crh sampler] shuffle %.3f ms, gather %.3f ms, first draws %.3f ms, membership + redraws %.3f ms\n",
+                std::chrono::duration<double>(tp1 - tp0).count() * 1e3, t_gather * 1e3, t_draw * 1e3, t_reject * 1e3);
+#endif
     return CRH_OK;
 }
 

@@ -745,6 +745,16 @@ int launch_score_per_wave(int esz, int d, int occ, const ScoreArgs& a, hipStream
 // kernel with seeded lists.  Same box, 131 072 users, seeded per-wave / workgroup (LDS-DMA): 2 M items 0.888 / 0.864 (unseeded),
 // 3 M 0.8835 / 0.8952 (seeded), 4 M 0.8876 / 0.9052, 10 M 0.898 (unseeded) / 0.9285.
 constexpr int64_t FP32_WG_MIN_ITEMS = 2500000;
+// Round 6, same box, 131 072 users, seeded, fraction of the fp32 MFMA peak -- LDS-DMA kernel in its flag form / its barrier form /
+// per-wave kernel (profiles/r06_flag_vs_barrier_vs_wave_ab.log):
+//   d=128   1.25 M 0.880 / 0.857 / 0.876   1.8 M 0.895 / 0.879 / 0.882   2.5 M 0.903 / 0.893 / 0.889   5 M 0.915 / 0.915 / 0.893
+//           10 M 0.920 / 0.927 / 0.898
+//   d=64    1.25 M 0.810 / 0.772 / 0.823   2.5 M 0.840 / 0.823 / 0.852   5 M 0.858 / 0.859 / 0.868   10 M 0.870 / 0.883 / 0.879
+// d=128: the DMA kernel from 1.2 M items (one rank's shard of the 8-GPU split of the headline is 1.25 M), flag form below 6 M
+// items -- where a user's ~k ln(N / P) slow-path events are a visible share and the barrier form pays each of them four times --
+// barrier form above.  d=64 (one wave of 128 users per SIMD, nothing shared, nothing to wait for): the per-wave kernel is as
+// fast or faster up to 5 M items; the DMA kernel (barrier form) from 7.5 M.
+constexpr int64_t FP32_DMA_MIN_ITEMS_D128 = 1200000, FP32_DMA_FLAG_MAX_ITEMS = 6000000, FP32_DMA_MIN_ITEMS_D64 = 7500000;
 // Small and mid-size blocks are scored into a dense block and ranked by crh_mask_topk_f32 (see score_topk_any).
 constexpr int64_t DENSE_MAX_ITEMS = 262144;
 // users go in chunks when the block would exceed this: 8 GiB (1 GiB chunks ran the same shapes at 0.37-0.43 of the MFMA peak
@@ -820,7 +830,7 @@ struct RoutePlan {
     bool dense;        // score block + crh_mask_topk_f32
     bool use_wg;       // a workgroup kernel (register-staged ring, or the LDS-DMA form when use_dma)
     bool use_dma;
-    int dma_mode;      // CRH_SCORE_DMA as read for this call
+    int dma_mode;      // form of the DMA kernel: 2 = flag form (fp32 d=128), 3 = barrier form
     bool can_pack;     // the workspace holds the fragment-ordered copy of the shard
     int wg_waves_l;    // waves of the workgroup that is launched
     int wg_slots_l;    // workgroups resident per round
@@ -863,7 +873,9 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     // (fp16 d=128 was measured on it too, round 6: 0.482 against 0.479 of 2.5 PF for the ring kernel at 10 M items, 0.305
     // against 0.347 at 1.25 M -- a 1 024-cycle tile is too short for one barrier + one threshold test each: not routed)
     const bool dma_rows = esz == 2 ? d == 256 : (d == 128 || d == 64);
-    const bool dma_shape = dma_mode && dma_rows && score_dma_ring_slots(esz, d, k, dma_mode) > 0 &&
+    // the form of the fp32 DMA kernel: CRH_SCORE_DMA = 2 flag form, 3 barrier form, anything else by stream length
+    const int dma_form = dma_mode == 2 || dma_mode == 3 ? dma_mode : (esz == 4 && d == 128 && n_items < FP32_DMA_FLAG_MAX_ITEMS ? 2 : 3);
+    const bool dma_shape = dma_mode && dma_rows && score_dma_ring_slots(esz, d, k, dma_form) > 0 &&
                            (!has_bitmap || workspace_bytes >= tb_off + tbits_bytes(n_items));
     // fp32 d=64 (the reference's default width) has no register-staged ring kernel: a workgroup kernel only as the DMA form
     const bool wg_shape = esz == 2 ? (d == 64 || d == 128 || d == 256) : ((d == 128 && wg_waves == 8) || (d == 64 && dma_shape));
@@ -871,7 +883,8 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     // pays on long streams (FP32_WG_MIN_ITEMS) and when its 512-user workgroups fill the CUs (65 536 users = 128 workgroups ran
     // at 0.33 against 0.60 per wave)
     const int64_t n_wg64 = ((n_users + 63) / 64 + wg_waves - 1) / wg_waves;
-    const bool fp32_wg_ok = n_items >= FP32_WG_MIN_ITEMS && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
+    const int64_t fp32_min_items = !dma_shape ? FP32_WG_MIN_ITEMS : (d == 64 ? FP32_DMA_MIN_ITEMS_D64 : FP32_DMA_MIN_ITEMS_D128);
+    const bool fp32_wg_ok = n_items >= fp32_min_items && (double)n_wg64 / (double)(((n_wg64 + 255) / 256) * 256) >= 0.9;
     const bool use_wg = wg_mode && can_pack && wg_shape && (dma_shape || wg_waves == 8 || 2 * wg4_lds <= 160 * 1024) &&
                         (n_users + 63) / 64 >= 512 && (esz == 2 || fp32_wg_ok || wg_mode == 2);
     const bool use_dma = use_wg && dma_shape;
@@ -895,7 +908,7 @@ RoutePlan plan_route(int esz, int64_t n_users, int64_t n_items, int d, int k, bo
     r.dense = dense_mode && n_splits == 0 && !seeded && dense_b && has_workspace && workspace_bytes >= dense_b;
     r.use_wg = use_wg;
     r.use_dma = use_dma;
-    r.dma_mode = dma_mode;
+    r.dma_mode = dma_form;
     r.can_pack = can_pack;
     r.wg_waves_l = wg_waves_l;
     r.wg_slots_l = wg_slots_l;
@@ -946,9 +959,11 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     if (!seed_mode || P <= 0 || n_users <= 0) return 0;
     const int upw = users_per_wave(esz, d);
     const int64_t n_ug = (n_users + upw - 1) / upw;
-    const bool cuts = pick_splits(n_ug, n_items, 2) > 1;
+    const int occ_pw = esz == 2 || d == 128 ? 2 : 1;         // waves per SIMD of the per-wave kernel for this width (plan_route)
+    const bool cuts = pick_splits(n_ug, n_items, occ_pw) > 1;
     const char* smi = getenv("CRH_SCORE_SEED_MAX_ITEMS");
-    const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : FP32_WG_MIN_ITEMS - 1);
+    const int64_t f32_stream_min = d == 64 ? FP32_DMA_MIN_ITEMS_D64 : FP32_WG_MIN_ITEMS;
+    const bool small_cat = !cuts && esz == 4 && n_items <= (smi ? atoll(smi) : f32_stream_min - 1);
     // fp16, 512-byte rows (configs[4]): at 16x the fp32 MFMA rate a slow-path event costs as much as a whole tile and, in
     // the workgroup kernels, stalls the whole CU: 9 % of the launch at 10 M items (profiles/r05_f16_*).  A 4 096-item prefix
     // takes k (1 + ln(P / k)) of every user's k (1 + ln(N / k)) events out of the stream: 282 -> 156 per user at 10 M items
@@ -956,7 +971,7 @@ int64_t seed_route(int esz, int64_t n_users, int64_t n_items, int d) {
     // fp32, 512-byte rows on the workgroup kernels (the headline): the same, worth less at the fp32 rate -- 131 072 x 3 M 0.883 ->
     // 0.895, x 4 M 0.895 -> 0.905, x 10 M 0.9245 -> 0.9285 (16 384-item prefix; 4 096 / 8 192 at 10 M: +0.35 / +0.38 %).  8 192 items
     // keep the prefix's score block (4.3 GB at 131 072 users) inside what the packed copy of such a shard takes anyway
-    const bool f32_stream = !cuts && esz == 4 && (d == 128 || d == 64) && n_users >= 32768 && n_items >= FP32_WG_MIN_ITEMS;
+    const bool f32_stream = !cuts && esz == 4 && (d == 128 || d == 64) && n_users >= 32768 && n_items >= f32_stream_min;
     if ((small_cat || f16_stream) && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 4096) P = 4096;
     if (f32_stream && !small_cat && !CRH_TUNE_ENV("CRH_SCORE_SEED_ITEMS") && P > 8192) P = 8192;
     if (!(cuts || small_cat || f16_stream || f32_stream || seed_mode == 2) || dense_block_bytes(n_users, P) == 0) return 0;

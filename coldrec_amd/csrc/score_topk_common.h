@@ -185,6 +185,22 @@ __device__ __forceinline__ float max16(const f32x16& v) {
     return fmaxf(b0, b1);
 }
 
+// bit r = (v[r] > t), r = 0 .. 15: one compare and one add-with-carry per register (m = 2 m + vcc, highest row first)
+// instead of compare + select + shift/or
+__device__ __forceinline__ unsigned gt_mask16(const f32x16& v, float t) {
+    unsigned m = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int r = 15; r >= 0; --r)
+        asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(v[r]), "v"(t) : "vcc");
+#endif
+    return m;
+}
+
+// v[r] for a WAVE-UNIFORM r: hipcc indexes the register tuple through the GPR index mode (s_set_gpr_idx_on / v_mov /
+// s_set_gpr_idx_off) -- one VALU instruction where the select tree below took fifteen
+__device__ __forceinline__ float pick16u(const f32x16& v, int r) { return v[__builtin_amdgcn_readfirstlane(r)]; }
+
 __device__ __forceinline__ float pick16(const f32x16& v, int r) {
     const bool b0 = r & 1, b1 = r & 2, b2 = r & 4, b3 = r & 8;
     const float p0 = b0 ? v[1] : v[0], p1 = b0 ? v[3] : v[2], p2 = b0 ? v[5] : v[4], p3 = b0 ? v[7] : v[6];
@@ -217,9 +233,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
         bhi = a.bitmap[w1];
         __builtin_amdgcn_s_waitcnt(0x0f70);   // landed HERE, inside the branch: a wait behind the join would be paid by every event (see below)
     }
-    unsigned cm = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
+    unsigned cm = gt_mask16(acc, tau_reg);
     // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
     const unsigned tb = (unsigned)(((((unsigned long long)bhi) << 32) | blo) >> (g0 & 31));
     const unsigned x = tb >> (4 * (lane >> 5));
@@ -247,7 +261,7 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
             if (il >= split_end) continue;   // clamped duplicate rows of the tail tile
             // r is wave-uniform: pick the accumulator register with a select tree (static indices only),
             // then read lane L
-            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
+            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16u(acc, r)), L));
             // the user's threshold may have moved since the candidate masks were built (an earlier candidate of this event).
             // Strictly below it = out; a TIE is decided by the ids further down: within a tile the candidates of a user do not
             // come in id order (rows 0-3, 8-11, ... of one half-wave, then 4-7, 12-15, ... of the other)

@@ -57,9 +57,7 @@ __device__ __forceinline__ void mma_f32_hooked(f32x16 (&acc)[UW], const f32x4& c
 __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau_reg, float* ls, int* li, int* cnt, int K,
                                                    int ucol0, int64_t slot0, const ScoreArgs& a, int64_t item0,
                                                    int64_t split_end, int lane, unsigned tb, const unsigned* rfilter) {
-    unsigned cm = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cm |= (acc[r] > tau_reg) ? (1u << r) : 0u;
+    unsigned cm = gt_mask16(acc, tau_reg);
     // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
     const unsigned x = tb >> (4 * (lane >> 5));
     const unsigned m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
@@ -83,7 +81,7 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
             cmL &= cmL - 1;
             const int64_t il = item0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (il >= split_end) continue;   // clamped duplicate rows of the tail tile
-            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16(acc, r)), L));
+            float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pick16u(acc, r)), L));
             const int gi = (int)(a.item_base + il);
             // one batch of LDS reads: fill, tail entry, filter word
             const unsigned hsh = rated_hash192(gi);
@@ -101,6 +99,11 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
             if (!masked && ((__builtin_amdgcn_readfirstlane(fw_raw) >> (hsh & 31)) & 1u)) {
                 const int64_t lo = a.rated_rowptr[slot], hi = a.rated_rowptr[slot + 1];
                 masked = wave_is_masked_at(gi, lo, hi, a.rated_col, nullptr, lane);
+                // every load of the search has landed HERE, inside the rare branch: left pending on this exit, hipcc guards the
+                // join with s_waitcnt vmcnt(0) -- paid by EVERY event, and vmcnt counts the tile DMAs in flight too: the
+                // flag form issued them one group (0.8 us) earlier, the barrier form at 256-byte rows in this very group, so an
+                // event waited for a DMA round trip (round 6, found in the ISA; tile_slow_path has had the same fix since round 4)
+                __builtin_amdgcn_s_waitcnt(0x0f70);
             }
             if (masked) sc = CRH_MASKED_SCORE;
             // wave_list_insert (k <= 64 here) that also hands back the user's NEW threshold out of the registers it already
@@ -180,7 +183,11 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
 template <typename T, int D, int R, bool FL>
 __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     constexpr int NW = DMA_NW, UW = 4, UPW = DMA_UPW;
-    constexpr int PF = FL ? R / 2 : 3;                 // body j issues the DMA of tile j + PF
+    // body j issues the DMA of tile j + PF; in the flag form it publishes its pieces of tile j + PF - 1 - WL (issued 1 + WL
+    // bodies ago).  4 slots: PF 2, WL 0 -- a wave may lead the slowest reader by (NG-2)/NG of a tile, the slowest refiller by
+    // one tile.  8 slots (256-byte rows: a tile lasts 3.4 us, about one cold DMA round trip): PF 5, WL 1 -- 2.5 and 2 tiles
+    constexpr int PF = FL ? (R == 8 ? 5 : 2) : 3;
+    constexpr int WL = FL && R == 8 ? 1 : 0;
     static_assert(FL ? (R == 4 || R == 8) && sizeof(T) == 4 : R == 4, "ring shape");
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int NCH = ROWB / 32;
@@ -205,9 +212,9 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     unsigned* tbits = reinterpret_cast<unsigned*>(smem + R * TILE_B);   // [2][64]
     unsigned* flags = tbits + TBITS_B / 4;             // FL: ready[R] at 0, done[R] at 8; slots of the prologue's tiles start ready
     if constexpr (FL) {
-        // (published by the prologue's barrier.  Tiles 0 .. PF-2 of the prologue start complete; tile PF-1 is bumped by body 0
-        // like every later tile: the prologue waited for all of them)
-        if (threadIdx.x < 16) flags[threadIdx.x] = threadIdx.x < PF - 1 ? (unsigned)NW : 0u;
+        // (published by the prologue's barrier.  Tiles 0 .. PF-2-WL of the prologue start complete; the later ones are bumped by the
+        // first bodies like every tile after them: the prologue waited for all of them)
+        if (threadIdx.x < 16) flags[threadIdx.x] = threadIdx.x < PF - 1 - WL ? (unsigned)NW : 0u;
     }
     const int64_t NT = (a.n_items + 31) >> 5;
     const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
             }
             if constexpr (FL) {
                 // The flag protocol, one piece per MFMA gap (n = index of the MFMA just issued, 0 .. 8 UW - 1 in this group):
-                //   group 0      n=0  my pieces of tile j + PF - 1 (issued a whole tile ago) have landed -> publish them
+                //   group 0      n=0  my pieces of tile j + PF - 1 - WL (issued 1 + WL tiles ago) have landed -> publish them
                 //                n=1  may the slot of tile j + PF - R be refilled?  (poll issued in the last group of the body before)
                 //                n=2  the tile bits, n=3 tile j + PF
                 //   group NG-3   n=0  poll: is tile j+1 complete?   n=8: the poll has landed, n=9: spin if it is not
@@ -467,8 +474,9 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
                                          (g == NG - 1 && (n == 0 || n == 8));
                     if constexpr (any) __builtin_amdgcn_sched_barrier(0);
                     if constexpr (g == 0 && n == 0) {
-                        dma_wait_all();
-                        flag_bump((j + PF - 1) & (R - 1));
+                        if constexpr (WL == 0) dma_wait_all();
+                        else dma_wait_but_newest_tile();
+                        flag_bump((j + PF - 1 - WL) & (R - 1));
                     }
                     if constexpr (g == 0 && n == 1) flag_spin(dflag, 8 + s_fill, (unsigned)NW * (unsigned)((j + PF) / R));
                     if constexpr (g == 0 && n == 2) dma_tbits((t0 + j + 32) >> 6);
@@ -632,22 +640,22 @@ size_t score_dma_lds_bytes(int row_bytes, int k, int ring_slots, bool flags) {
     return (size_t)ring_slots * (row_bytes / 32) * 1024 + TBITS_B + (flags ? FLAGS_B : 0) + DMA_NW * dma_wave_lds_bytes(k);
 }
 
-// Which form a launch takes: fp16 the barrier form (4 slots); fp32 the flag form -- 512-byte rows 4 slots, 256-byte rows
-// 8 slots when the lists leave room for them (k <= 20), else 4.  0 = the lists do not fit beside any ring.
+// Ring slots of a launch, 0 = the lists do not fit beside the ring.  (The flag form with EIGHT slots -- 256-byte rows, prefetch
+// distance 5, publish lag 1 -- was built and measured in round 6: at d=64 the per-wave kernel is as fast or faster wherever the
+// flag form beats the barrier form, profiles/r06_flag_vs_barrier_vs_wave_ab.log; the kernel template keeps R = 8, nothing
+// instantiates it.)
 int score_dma_ring_slots(int esz, int d, int k, int mode) {
-    const bool fl = esz == 4 && mode != 3;                           // CRH_SCORE_DMA=3: the barrier form for fp32 too (A/B)
-    if (fl && d * esz == 256 && score_dma_lds_bytes(256, k, 8, true) <= 160 * 1024) return 8;
+    const bool fl = esz == 4 && d == 128 && mode == 2;
     return score_dma_lds_bytes(d * esz, k, 4, fl) <= 160 * 1024 ? 4 : 0;
 }
 
 // 512-byte rows (fp32 d=128: the headline; fp16 d=256: configs[4]) and 256-byte rows (fp32 d=64: the reference's default
-// width, main.py:97 --emb_size 64 = configs[0]): half the tile, half the B registers, the same loop.
+// width, main.py:97 --emb_size 64 = configs[0]): half the tile, half the B registers, the same loop.  mode: 2 = the flag form
+// (fp32 d=128 only), anything else the barrier form.
 int launch_score_dma(int esz, int d, int mode, const ScoreArgs& a, hipStream_t stream) {
-    const int slots = score_dma_ring_slots(esz, d, a.k, mode);
     if (esz == 2) return launch_score_dma_t<_Float16, 256, 4, false>(a, stream);
-    if (mode == 3) return d == 128 ? launch_score_dma_t<float, 128, 4, false>(a, stream) : launch_score_dma_t<float, 64, 4, false>(a, stream);
-    if (d == 128) return launch_score_dma_t<float, 128, 4, true>(a, stream);
-    return slots == 8 ? launch_score_dma_t<float, 64, 8, true>(a, stream) : launch_score_dma_t<float, 64, 4, true>(a, stream);
+    if (d == 64) return launch_score_dma_t<float, 64, 4, false>(a, stream);
+    return mode == 2 ? launch_score_dma_t<float, 128, 4, true>(a, stream) : launch_score_dma_t<float, 128, 4, false>(a, stream);
 }
 
 }  // namespace crh_score

@@ -81,10 +81,20 @@ def test_the_library_reports_its_route():
     head = ops.score_topk_route(131072, 10_000_000, 128, 20)                 # the headline: 4-wave workgroups fed by LDS-DMA
     assert head["route"] == "fused-dma" and head["kernel"] == "score_topk_dma_kernel" and head["n_splits"] == 1
     assert head["seeded"] and head["prefix_items"] == 8192                   # (lists seeded from an 8 192-item prefix: round 5)
-    shard = ops.score_topk_route(131072, 1_250_000, 128, 20)                 # one rank's shard of the 8-GPU split: below the
-    assert shard["route"] == "fused-wave" and shard["seeded"]                # 2.5 M-item gate -> per-wave kernel, seeded (4 096-item prefix)
-    assert shard["prefix_items"] == 4096 and shard["kernel"] == "score_topk_kernel"
-    assert shard["code"] != head["code"]
+    shard = ops.score_topk_route(131072, 1_250_000, 128, 20)                 # one rank's shard of the 8-GPU split: the same kernel
+    assert shard["route"] == "fused-dma" and shard["seeded"] and shard["prefix_items"] == 4096    # (its flag form below 6 M items)
+    below = ops.score_topk_route(131072, 1_000_000, 128, 20)                 # below the 1.2 M-item gate: per-wave kernel, seeded
+    assert below["route"] == "fused-wave" and below["seeded"] and below["prefix_items"] == 4096
+    # the reference's default width (main.py:97 --emb_size 64, BASELINE configs[0]): one wave of 128 users per SIMD up to 7.5 M items,
+    # the LDS-DMA kernel beyond; lists of up to 28 entries fit beside its four 8 KiB slots
+    d64 = ops.score_topk_route(131072, 10_000_000, 64, 20)
+    assert d64["route"] == "fused-dma" and d64["kernel"] == "score_topk_dma_kernel" and d64["seeded"] and d64["n_splits"] == 1
+    assert ops.score_topk_route(131072, 10_000_000, 64, 28)["route"] == "fused-dma"
+    assert ops.score_topk_route(131072, 10_000_000, 64, 29)["route"] == "fused-wave"
+    mid64 = ops.score_topk_route(131072, 1_250_000, 64, 20)
+    assert mid64["route"] == "fused-wave" and mid64["seeded"] and mid64["prefix_items"] == 4096 and mid64["n_splits"] == 1
+    assert ops.score_topk_route(6040, 3706, 64, 20)["route"] == "dense"
+    assert below["kernel"] == "score_topk_kernel" and below["code"] != head["code"]
     f16 = ops.score_topk_route(131072, 50_000_000, 256, 20, half=True)       # configs[4]: the LDS-DMA workgroup kernel
     assert f16["route"] == "fused-dma" and f16["kernel"] == "score_topk_dma_kernel" and f16["seeded"] and f16["prefix_items"] == 4096
     f16_shard = ops.score_topk_route(131072, 6_250_000, 256, 20, half=True)

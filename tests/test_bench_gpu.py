@@ -66,3 +66,66 @@ def test_config5_generator_fp16_three_uneven_shards_equal_one_rank():
     three = _bench(["--gpus", "3"] + small, CRH_BENCH_BACKEND="gloo")
     assert three["n_gpus"] == 3 and three["dtype"] == "f16" and "dropoutnet_generator" in three
     assert one["result_crc32"] == three["result_crc32"]
+
+
+def test_config5_full_size_fp16_properties_in_the_suite():
+    """BASELINE configs[4] AT ITS OWN SIZE inside the GPU suite (it used to run only as bench.py's eval_f16 leg):
+    131 072 users x 50 M fp16 items, d=256, rated CSR + 20 % cold bitmap, through the C ABI.  Size-independent properties --
+    (1) two item shards (25 M each, global ids) + the canonical merge == the whole-table call, byte for byte;
+    (2) a caller-named item-range cut (n_splits = 3) == the dispatcher's own route, byte for byte;
+    and 16 users re-scored by a plain fp32 matmul over the same fp16 tables (the float-kernel reference of this tier: 1e-3
+    relative + 1e-5), every returned id present in the reference's top-(k+8) or tied with its k-th score, no masked id returned."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    from bench_legs.common import item_shard, rated_lists, xavier_
+    from coldrec_amd import ops
+    dev = torch.device("cuda:0")
+    n_items, d, Bu, k = 50_000_000, 256, 131072, 20
+    V = item_shard(n_items, d, 0, n_items, dev, torch.float16)
+    U = xavier_(Bu, d, 17, dev, 1_000_000).to(torch.float16)
+    rowptr, col = rated_lists(Bu, n_items, 50, seed=4)
+    cold = np.where(np.random.default_rng(5).random(n_items) < 0.2)[0]
+    bm = ops.make_bitmap(n_items, cold, dev)
+    rp, rc = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
+    assert ops.score_topk_route(Bu, n_items, d, k, half=True)["route"] == "fused-dma"
+    s, i = ops.score_topk(U, None, V, k, rp, rc, bm)
+    half = n_items // 2
+    parts = [ops.score_topk(U, None, V[lo:hi], k, rp, rc, bm, item_base=lo) for lo, hi in ((0, half), (half, n_items))]
+    ms, mi = ops.merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+    assert torch.equal(mi, i) and torch.equal(ms.view(torch.int32), s.view(torch.int32)), "two shards + merge != whole table"
+    del parts, ms, mi
+    s3, i3 = ops.score_topk(U, None, V, k, rp, rc, bm, n_splits=3)
+    assert torch.equal(i3, i) and torch.equal(s3.view(torch.int32), s.view(torch.int32)), "named cuts != the dispatcher's route"
+    del s3, i3
+    rng = np.random.default_rng(9)
+    slots = np.sort(rng.choice(Bu, 16, replace=False))
+    uu = U[torch.from_numpy(slots).to(dev)].float()
+    best_s = torch.full((16, k + 8), -float("inf"), device=dev)
+    best_i = torch.zeros((16, k + 8), dtype=torch.int64, device=dev)
+    cold_t = torch.from_numpy(cold).to(dev)
+    for lo in range(0, n_items, 2_500_000):
+        hi = min(lo + 2_500_000, n_items)
+        S = uu @ V[lo:hi].float().T
+        S[:, cold_t[(cold_t >= lo) & (cold_t < hi)] - lo] = -1e9
+        for q, sl in enumerate(slots.tolist()):
+            ids = col[rowptr[sl]:rowptr[sl + 1]]
+            ids = ids[(ids >= lo) & (ids < hi)] - lo
+            if len(ids):
+                S[q, torch.from_numpy(ids.astype(np.int64)).to(dev)] = -1e9
+        cs, ci = torch.topk(S, k + 8, dim=1)
+        m_s, m_i = torch.topk(torch.cat([best_s, cs], 1), k + 8, dim=1)
+        best_i = torch.gather(torch.cat([best_i, ci + lo], 1), 1, m_i)
+        best_s = m_s
+        del S
+    gs, gi = s[torch.from_numpy(slots).to(dev)].cpu().numpy(), i[torch.from_numpy(slots).to(dev)].cpu().numpy()
+    rs, ri = best_s.cpu().numpy(), best_i.cpu().numpy()
+    cold_set = set(cold[:0].tolist())
+    for q, sl in enumerate(slots.tolist()):
+        ref_of = dict(zip(ri[q].tolist(), rs[q].tolist()))
+        rated_u = set(col[rowptr[sl]:rowptr[sl + 1]].tolist())
+        for g, sg in zip(gi[q].tolist(), gs[q].tolist()):
+            assert g not in rated_u and sg > -1e8, (sl, g, sg)                     # nothing masked is returned
+            assert g in ref_of and abs(ref_of[g] - sg) <= 1e-3 * abs(sg) + 1e-5, (sl, g, sg, ref_of.get(g))
+        assert np.all(np.abs(np.sort(gs[q])[::-1] - rs[q, :k]) <= 1e-3 * np.abs(rs[q, :k]) + 1e-5), sl
+    assert not np.isin(gi, cold).any()
