@@ -207,6 +207,11 @@ def route_of(n_users, n_items, d, k, dtype="f32", masks=True, n_splits=0):
     r["label"] = "%s<%s,%d>%s" % (r["kernel"], dtype, d, " + mask_topk_kernel" if r["route"] == "dense" else "")
     ctype, mangled = ("float", "If") if dtype == "f32" else ("_Float16", "IDF16_")
     r["profile_patterns"] = ("%s<%s, %d" % (r["kernel"], ctype, d), "%s%sLi%dE" % (r["kernel"], mangled, d))
+    if r["route"] == "fused-dma":     # <T, D, ring slots, flag form>: the two forms of the fp32 kernel are separate profile rows
+        fl = r.get("dma_form") == "flags"
+        r["label"] = "%s<%s,%d,%s>" % (r["kernel"], dtype, d, "flags" if fl else "barrier")
+        r["profile_patterns"] = ("%s<%s, %d, 4, %s>" % (r["kernel"], ctype, d, "true" if fl else "false"),
+                                 "%s%sLi%dELi4ELb%dE" % (r["kernel"], mangled, d, 1 if fl else 0))
     return r
 
 

@@ -1336,6 +1336,7 @@ extern "C" int crh_score_topk_route(int elem_bytes, int64_t n_users, int64_t n_i
     const RoutePlan r = plan_route(elem_bytes, n_users, n_main, d, k, has_ws, ws, has_bitmap != 0, n_splits, P > 0);
     int route = r.dense ? CRH_ROUTE_DENSE : (r.use_dma ? CRH_ROUTE_FUSED_DMA : (r.use_wg ? CRH_ROUTE_FUSED_WG : CRH_ROUTE_FUSED_WAVE));
     if (P > 0) route |= CRH_ROUTE_SEEDED;
+    if (r.use_dma && !r.dense && r.dma_mode == 2) route |= CRH_ROUTE_DMA_FLAGS;
     if (prefix_items) *prefix_items = P;
     if (picked_splits) *picked_splits = r.dense ? 1 : plan_splits(r, elem_bytes, n_users, n_main, k, n_splits, P > 0);
     return route;

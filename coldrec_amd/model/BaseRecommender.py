@@ -385,7 +385,8 @@ class BaseColdStartTrainer(ABC):
             half = getattr(self.args, 'score_dtype', 'fp32') == 'fp16'
             r = ops.score_topk_route(min(len(c['users']), self.EVAL_USER_BLOCK), int(ie.shape[0]), int(ie.shape[1]), self.max_N,
                                      half=half, has_bitmap=c['bitmap'] is not None)
-            print(f"Evaluation route: fused HIP scoring + masks + top-{self.max_N} ({r['kernel']}, {r['route']}"
+            form = f", {r['dma_form']} form" if r.get('dma_form') else ''
+            print(f"Evaluation route: fused HIP scoring + masks + top-{self.max_N} ({r['kernel']}, {r['route']}{form}"
                   f"{', seeded from a %d-item prefix' % r['prefix_items'] if r['seeded'] else ''}); no score block is written")
             return
         block = int(self.batch_size) * n_items * 4

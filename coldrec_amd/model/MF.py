@@ -55,14 +55,14 @@ class MF(BaseColdStartTrainer):
             if hasattr(eng, 'enable_row_sharding') and (getattr(self.args, 'shard_graph', False) or
                                                         os.environ.get('CRH_LGCN_ROW_SHARD', '0') == '1'):
                 eng.enable_row_sharding(dp)
-        else:
-            # catalogue-scale tables: replay dense Adam on the touched rows only (bit-identical, see
-            # crh_adam_rows_f32); 'auto' = when a batch touches under ~5 % of the rows
-            mode = getattr(self.args, 'lazy_adam', 'auto')
-            rows = self.data.user_num + self.data.item_num
-            if hasattr(eng, 'enable_lazy_adam') and type(eng).__name__ == 'MFEngine' and \
-                    (mode == 'on' or (mode == 'auto' and rows > 64 * self.batch_size)):
-                eng.enable_lazy_adam()
+        # catalogue-scale tables: replay dense Adam on the touched rows only (bit-identical, see crh_adam_rows_f32); 'auto' =
+        # when a batch touches under ~5 % of the rows.  Under data parallelism the step is then split by row ownership with
+        # ONE all-gather of gradient rows instead of the dense gradient all-reduce (train.MFEngine._lazy_step_dp)
+        mode = getattr(self.args, 'lazy_adam', 'auto')
+        rows = self.data.user_num + self.data.item_num
+        if hasattr(eng, 'enable_lazy_adam') and type(eng).__name__ == 'MFEngine' and \
+                (mode == 'on' or (mode == 'auto' and rows > 64 * self.batch_size)):
+            eng.enable_lazy_adam()
         # collectives are kept out of graph capture: the data-parallel epoch is launched eagerly
         runner = EpochRunner(eng, len(self.data.train_u), self.batch_size, use_graph=dp is None)
         # epoch e+1 is sampled (same NumPy stream) while the GPU trains and ranks epoch e: by the C++ sampler on its

@@ -130,7 +130,7 @@ def score_topk_route(n_users: int, n_items: int, d: int, k: int, half: bool = Fa
                      n_splits: int = 0, pack: bool = True) -> dict:
     """Which kernels ``score_topk`` runs for a block of this shape: the library's own answer (crh_score_topk_route evaluates
     the dispatcher's predicates under the current environment switches; no GPU needed), with the workspace ``score_topk``
-    would pass.  ``{"route", "seeded", "prefix_items", "n_splits", "kernel", "code"}``; ``kernel`` is the scoring kernel's
+    would pass.  ``{"route", "seeded", "dma_form", "prefix_items", "n_splits", "kernel", "code"}``; ``kernel`` is the scoring kernel's
     name as rocprofv3 prints it."""
     import ctypes
     L = _lib.lib()
@@ -142,7 +142,8 @@ def score_topk_route(n_users: int, n_items: int, d: int, k: int, half: bool = Fa
     code = L.crh_score_topk_route(2 if half else 4, n_users, n_items, d, k, ws_bytes, 1 if has_bitmap else 0, n_splits,
                                   ctypes.byref(prefix), ctypes.byref(splits))
     _lib.check(code if code < 0 else 0, "crh_score_topk_route")
-    return {"route": ROUTE_NAMES[code & 15], "seeded": bool(code & 16), "prefix_items": int(prefix.value),
+    return {"route": ROUTE_NAMES[code & 15], "seeded": bool(code & 16), "dma_form": ("flags" if code & 32 else "barrier") if (code & 15) == 4 else None,
+            "prefix_items": int(prefix.value),
             "n_splits": int(splits.value), "kernel": L.crh_score_topk_route_kernel(code).decode(), "code": int(code)}
 
 
@@ -639,10 +640,14 @@ class SpmmSchedule:
         col = self._col.cpu().numpy() if torch.is_tensor(self._col) else np.asarray(self._col)
         val = self._val.cpu().numpy() if torch.is_tensor(self._val) else np.asarray(self._val)
         # what exactly is being baked in: version counters of the source tensors and two checksums of the host copies taken
-        # NOW (a later in-place ``val.mul_(c)`` must not pass for "the same edges" because the pointer is the same)
-        self._baked = (self._col._version if torch.is_tensor(self._col) else None,
-                       self._val._version if torch.is_tensor(self._val) else None, len(col), int(col.astype(np.int64).sum()),
-                       int(np.ascontiguousarray(val, np.float32).view(np.int32).astype(np.int64).sum()))
+        # NOW (a later in-place ``val.mul_(c)`` must not pass for "the same edges" because the pointer is the same).
+        # Position-weighted (sum of (i + 1) x_i in int64, wrapping on both sides): a permutation of the edges does not pass either
+        wts = np.arange(1, len(col) + 1, dtype=np.int64)
+        with np.errstate(over="ignore"):
+            self._baked = (self._col._version if torch.is_tensor(self._col) else None,
+                           self._val._version if torch.is_tensor(self._val) else None, len(col),
+                           int((col.astype(np.int64) * wts).sum()),
+                           int((np.ascontiguousarray(val, np.float32).view(np.int32).astype(np.int64) * wts).sum()))
         stream = np.zeros((n_pairs, 2), np.uint32)
         stream[start[:-1], 0] = rows.astype(np.uint32)
         stream[start[:-1], 1] = deg.astype(np.uint32)

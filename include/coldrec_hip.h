@@ -75,7 +75,8 @@ size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k);
  * Returns the route of the stage that walks the catalogue -- CRH_ROUTE_DENSE (score block + crh_mask_topk_f32),
  * CRH_ROUTE_FUSED_WAVE (one wave per user group), CRH_ROUTE_FUSED_WG (8-wave workgroups, register-staged LDS ring),
  * CRH_ROUTE_FUSED_DMA (4-wave workgroups fed by LDS-DMA) -- OR-ed with CRH_ROUTE_SEEDED when a catalogue prefix is ranked
- * first and seeds the lists; < 0 on bad arguments.  prefix_items / picked_splits (either may be NULL) receive the prefix
+ * first and seeds the lists, and with CRH_ROUTE_DMA_FLAGS when the DMA kernel runs in its flag form (ring slots guarded by
+ * LDS counters instead of a barrier per tile: fp32 d=128 below 6 M items); < 0 on bad arguments.  prefix_items / picked_splits (either may be NULL) receive the prefix
  * length (0: not seeded) and the item-range cut count of the main stage.
  * There is no counterpart in the reference (model/BaseRecommender.py:172-183 is one matmul + topk whatever the shape). */
 #define CRH_ROUTE_DENSE 1
@@ -83,6 +84,7 @@ size_t crh_score_topk_min_workspace_bytes(int64_t n_users, int k);
 #define CRH_ROUTE_FUSED_WG 3
 #define CRH_ROUTE_FUSED_DMA 4
 #define CRH_ROUTE_SEEDED 16
+#define CRH_ROUTE_DMA_FLAGS 32
 int crh_score_topk_route(int elem_bytes, int64_t n_users, int64_t n_items, int d, int k, size_t workspace_bytes,
                          int has_bitmap, int n_splits, int64_t* prefix_items, int* picked_splits);
 /* kernel-name prefix of a route's scoring kernel as rocprofv3 prints it ("score_topk_dma_kernel", ...) */

@@ -83,6 +83,7 @@ def test_the_library_reports_its_route():
     assert head["seeded"] and head["prefix_items"] == 8192                   # (lists seeded from an 8 192-item prefix: round 5)
     shard = ops.score_topk_route(131072, 1_250_000, 128, 20)                 # one rank's shard of the 8-GPU split: the same kernel
     assert shard["route"] == "fused-dma" and shard["seeded"] and shard["prefix_items"] == 4096    # (its flag form below 6 M items)
+    assert shard["dma_form"] == "flags" and head["dma_form"] == "barrier" and shard["code"] == head["code"] | 32
     below = ops.score_topk_route(131072, 1_000_000, 128, 20)                 # below the 1.2 M-item gate: per-wave kernel, seeded
     assert below["route"] == "fused-wave" and below["seeded"] and below["prefix_items"] == 4096
     # the reference's default width (main.py:97 --emb_size 64, BASELINE configs[0]): one wave of 128 users per SIMD up to 7.5 M items,

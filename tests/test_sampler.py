@@ -95,6 +95,32 @@ def test_matches_numpy_oracle_other_seeds(seed, bs):
             assert np.array_equal(a, b)
 
 
+def test_large_record_set_matches_numpy_oracle():
+    """Round 6: the gather of the shuffled records rides in the shuffle loop (csrc/sampler.hip: a slot is final once its swap is
+    done; slot 0 is fetched after the loop).  Two epochs of 230 000 records against the NumPy oracle, triple for triple, and the
+    generator state after them."""
+    rng = np.random.default_rng(3)
+    n_u, n_i = 1500, 2500
+    key = np.unique(rng.integers(0, n_u * n_i, 245_000))[:230_000]
+    rng.shuffle(key)
+    ru, ri = (key // n_i).astype(np.int32), (key % n_i).astype(np.int32)
+    s = PairwiseSampler(ru, ri, n_u, n_i)
+    o = orc.PairwiseSampler(ru, ri, n_i, n_u)
+    np.random.seed(77)
+    s.pull_numpy_state()
+    for _ in range(2):
+        want = [np.concatenate(x) for x in zip(*o.epoch(4096))]
+        got = s.epoch(4096)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+    key_np, pos_np = np.random.get_state()[1], np.random.get_state()[2]
+    import ctypes
+    k = np.empty(624, np.uint32)
+    pos = ctypes.c_int(0)
+    s._L.crh_sampler_get_state(s._h, k.ctypes.data, ctypes.addressof(pos))
+    assert np.array_equal(k, key_np) and int(pos.value) == int(pos_np)
+
+
 def test_negatives_never_rated_and_speed():
     rng = np.random.default_rng(0)
     n_u, n_i, n = 2000, 3000, 300_000
