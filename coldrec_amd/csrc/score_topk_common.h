@@ -177,12 +177,28 @@ __device__ __forceinline__ void wave_lds_init(const WaveLds<UPW>& w, const Score
 
 // maximum of the 16 accumulator registers as a depth-3 tree of 3-input maxima (v_max3_f32): the wave waits
 // for this chain between two tiles, and a sequential chain of 15 is ~4x longer
+// Written as the eight instructions it is (7 v_max3_f32 + 1 v_max_f32): from fmaxf hipcc first canonicalises accumulator
+// registers it cannot prove quiet (v_max_f32 x, x: two more instructions per call), and beside v_mfma_f32_32x32x2_f32 every VALU
+// instruction costs its full issue time.  NaNs are ignored by both forms alike.
 __device__ __forceinline__ float max16(const f32x16& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float a0, a1, a2, a3, a4, b0, b1, r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(v[3]), "v"(v[4]), "v"(v[5]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a2) : "v"(v[6]), "v"(v[7]), "v"(v[8]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a3) : "v"(v[9]), "v"(v[10]), "v"(v[11]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a4) : "v"(v[12]), "v"(v[13]), "v"(v[14]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(a0), "v"(a1), "v"(a2));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(a3), "v"(a4), "v"(v[15]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(b0), "v"(b1));
+    return r;
+#else
     const float a0 = fmaxf(fmaxf(v[0], v[1]), v[2]), a1 = fmaxf(fmaxf(v[3], v[4]), v[5]);
     const float a2 = fmaxf(fmaxf(v[6], v[7]), v[8]), a3 = fmaxf(fmaxf(v[9], v[10]), v[11]);
     const float a4 = fmaxf(fmaxf(v[12], v[13]), v[14]);
     const float b0 = fmaxf(fmaxf(a0, a1), a2), b1 = fmaxf(fmaxf(a3, a4), v[15]);
     return fmaxf(b0, b1);
+#endif
 }
 
 // bit r = (v[r] > t), r = 0 .. 15: one compare and one add-with-carry per register (m = 2 m + vcc, highest row first)

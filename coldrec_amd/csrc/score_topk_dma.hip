@@ -520,10 +520,12 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (g == 1) {
-                bool hit = false;
+                // four compares straight into scalar masks (OR-ed per lane first, the ballot of the result was a select and a second
+                // compare: two VALU instructions per tile beside MFMAs that hide none)
+                unsigned long long hitm = 0ull;
 #pragma unroll
-                for (int u = 0; u < UW; ++u) hit = hit || (m[u] > tau[u]);
-                if (__ballot(hit) != 0ull && live && j > 0 && !(CRH_ABLATE(a.ablate) & 1)) {
+                for (int u = 0; u < UW; ++u) hitm |= __ballot(m[u] > tau[u]);
+                if (hitm != 0ull && live && j > 0 && !(CRH_ABLATE(a.ablate) & 1)) {
                     const int64_t ts = t0 + j - 1;                                      // the tile being selected
                     const unsigned tb = has_bits ? tbits[((ts >> 6) & 1) * 64 + (ts & 63)] : 0u;
 #pragma unroll

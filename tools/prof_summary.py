@@ -36,7 +36,7 @@ def _db_stats(stats_dir, tag):
         with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as o:
             w = csv.writer(o)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-            w.writerows(rows[:25])
+            w.writerows(rows[:40])
 
 
 def _long_cluster(v):
