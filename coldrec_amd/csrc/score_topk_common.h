@@ -250,12 +250,16 @@ __device__ __forceinline__ void tile_slow_path(const f32x16& acc, float& tau_reg
         __builtin_amdgcn_s_waitcnt(0x0f70);   // landed HERE, inside the branch: a wait behind the join would be paid by every event (see below)
     }
     unsigned cm = gt_mask16(acc, tau_reg);
-    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
-    const unsigned tb = (unsigned)(((((unsigned long long)bhi) << 32) | blo) >> (g0 & 31));
-    const unsigned x = tb >> (4 * (lane >> 5));
-    const unsigned m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
-    // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
-    if (tau_reg > CRH_NEG_INF) cm &= ~m16;
+    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r.  (No bitmap word was fetched = no masked row can be a
+    // candidate here: the bit shuffling is skipped with it -- a dozen VALU instructions per event.)
+    unsigned m16 = 0u;
+    if ((blo | bhi) != 0u) {          // wave-uniform
+        const unsigned tb = (unsigned)(((((unsigned long long)bhi) << 32) | blo) >> (g0 & 31));
+        const unsigned x = tb >> (4 * (lane >> 5));
+        m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
+        // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
+        if (tau_reg > CRH_NEG_INF) cm &= ~m16;
+    }
     const unsigned bm = cm & m16;
     unsigned long long lanes = __ballot(cm != 0u);
     const bool wide = K > 64;                         // lane t holds entries t and t + 64 of a list (k <= 128)

@@ -58,11 +58,15 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
                                                    int ucol0, int64_t slot0, const ScoreArgs& a, int64_t item0,
                                                    int64_t split_end, int lane, unsigned tb, const unsigned* rfilter) {
     unsigned cm = gt_mask16(acc, tau_reg);
-    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r
-    const unsigned x = tb >> (4 * (lane >> 5));
-    const unsigned m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
-    // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
-    if (tau_reg > CRH_NEG_INF) cm &= ~m16;
+    // bits of this lane's 16 rows: rows (r&3) + 8*(r>>2) + 4*hh <-> bit r.  Masked rows are packed as zeros: with no negative
+    // threshold in the group none of them is a candidate, and the bit shuffling (a dozen VALU instructions) is skipped
+    unsigned m16 = 0u;
+    if (tb != 0u && __ballot(tau_reg < 0.0f) != 0ull) {          // wave-uniform
+        const unsigned x = tb >> (4 * (lane >> 5));
+        m16 = (x & 0xFu) | ((x >> 4) & 0xF0u) | ((x >> 8) & 0xF00u) | ((x >> 12) & 0xF000u);
+        // a masked candidate scores -1e9: it can only enter a list that is not full (tau = -inf)
+        if (tau_reg > CRH_NEG_INF) cm &= ~m16;
+    }
     const unsigned bm = cm & m16;
     unsigned long long lanes = __ballot(cm != 0u);
     while (lanes) {
