@@ -109,7 +109,8 @@ def midsize_eval_leg(dev):
                                    (4096, 10_000_000, 128, 20),        # the reference's own user block (--bs 4096) on the S-EVAL catalogue
                                    (131072, 1_250_000, 128, 20),       # one rank's item shard of the 8-GPU run
                                    (8192, 262144, 64, 20), (131072, 1_250_000, 64, 20),   # main.py:97 --emb_size 64
-                                   (65536, 1048576, 128, 50)):         # main.py:95 --topN is free-form
+                                   (65536, 1048576, 128, 50),          # main.py:95 --topN is free-form
+                                   (65536, 524288, 256, 20)):          # fp32 d=256: 32 users per wave, one wave per SIMD (never timed before)
         U = xavier_(n_users, d, 31, dev, n_items)
         V = item_shard(n_items, d, 0, n_items, dev)
         rowptr, col = rated_lists(n_users, n_items, 50, seed=4)

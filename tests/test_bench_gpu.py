@@ -54,6 +54,11 @@ def test_gpus_8_full_headline_size_self_launched_equals_gpus_1():
     assert one["verified_users"] == 64 and eight["verified_users"] == 64
     assert one["result_crc32"] == eight["result_crc32"]
     assert eight["train_mf_dp"]["replicas_identical"] is True
+    # round 6: the touched-rows step over the ranks at S-TRAIN-XL (an eighth of it when eight ranks share one GPU): replicas bit-equal,
+    # one all-gather of ceil(3 B / 8) (row id, row) slots per rank and step instead of the dense gradient all-reduce
+    xl = eight["train_xl_dp"]
+    assert xl["replicas_identical"] is True and xl["exchange_bytes_per_step"] == 8 * (-(-3 * 65536 // 8)) * (128 + 4) * 4
+    assert xl["exchange_bytes_per_step"] * 5 < xl["dense_gradient_allreduce_bytes_it_replaces"]
 
 
 def test_config5_generator_fp16_three_uneven_shards_equal_one_rank():

@@ -23,7 +23,7 @@ has() { [[ " $PARTS " == *" $1 "* ]]; }
 
 if has eval; then
 $T rocprofv3 --kernel-trace --stats -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_stats.json" 2> "$OUT/stats.err"
-EV="--no-cpu-baseline --no-verify --legs none --steps 2 --warmup 1"
+EV="--no-cpu-baseline --no-verify --legs eval_d64 --steps 2 --warmup 1"      # the headline's launches + the d=64 leg's (its own kernel rows)
 $T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_sq.err"
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_fetch.err"
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -- python3 bench.py $EV > /dev/null 2> "$OUT/pmc_write.err"
