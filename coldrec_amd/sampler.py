@@ -263,6 +263,10 @@ class EpochPrefetcher:
         st = np.random.get_state()
         np.random.set_state((st[0], key, pos, st[3], st[4]))
         self._base = self._slot = None
+        _t2 = time.perf_counter()
+        if self.enabled:
+            self._start()                      # speculate on the following epoch FIRST (its buffers are the other slot's): the
+        _t3 = time.perf_counter()              # worker samples while this thread queues the upload and the epoch's launches
         out = self._host[k]
         if self.device is not None:
             torch = self._torch
@@ -272,11 +276,8 @@ class EpochPrefetcher:
             ev.record(torch.cuda.current_stream(self.device))
             self._uploaded[k] = ev
             out = self._dev[k]
-        _t2 = time.perf_counter()
-        if self.enabled:
-            self._start()                      # speculate on the following epoch
         if self.timing is not None:
-            self.timing.append((_t1 - _t0, _t2 - _t1, time.perf_counter() - _t2, self._t_sync))
+            self.timing.append((_t1 - _t0, (_t2 - _t1) + (time.perf_counter() - _t3), _t3 - _t2, self._t_sync))
         return out
 
     def close(self) -> None:

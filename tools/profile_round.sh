@@ -93,5 +93,9 @@ echo "train-xl passes done after $SECONDS s"
 fi
 
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/ 2>/dev/null
+# (the line above also carries the snapshot's OLD copies of this tag's bench lines: this run's own go on top again)
+[ -f "$OUT/bench_under_stats.json" ] && cp "$OUT/bench_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_eval_bench_under_rocprof.json
+[ -f "$OUT/train_under_stats.json" ] && cp "$OUT/train_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_train_bench_under_rocprof.json
+[ -f "$OUT/xl_under_stats.json" ] && cp "$OUT/xl_under_stats.json" gpurun_out/profiles_$TAG/${TAG}_xl_lightgcn_bench_under_rocprof.json
 cp "$OUT"/f16_*.json "$OUT"/f16_*.log "$OUT"/f16_ceiling.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 for f in "$OUT"/*.err; do echo "== $f"; grep -v -E "simple_timer|generateRocpd|tool.cpp|amdgpu.ids" "$f" | tail -n 3; done; du -sh gpurun_out; ls -la gpurun_out/profiles_$TAG
