@@ -91,6 +91,7 @@ SIGNATURES = {
     "crh_comm_rank": (_i32, [_vp]),
     "crh_comm_world": (_i32, [_vp]),
     "crh_comm_allreduce_f32": (_i32, [_vp, _vp, _i64, _vp]),
+    "crh_comm_allgather_rows": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "crh_comm_allgather_topk_workspace_bytes": (_sz, [_i32, _i64, _i32]),
     "crh_comm_allgather_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "crh_sampler_create": (_vp, [_vp, _vp, _i64, _i32, _i32]),

@@ -161,6 +161,19 @@ __global__ void unpack_topk_kernel(const int32_t* __restrict__ gathered, int64_t
 
 }  // namespace
 
+// Exchange step of the data-parallel touched-rows training step (crh_bpr_bwd_owned_f32 -> crh_rows_pack_f32 -> HERE ->
+// crh_rows_unpack_f32): every rank contributes its `cap` slots of (row id, d floats); gathered_* are laid out [rank][slot],
+// exactly what crh_rows_unpack_f32 takes with n = world * cap.  Two collectives on the caller's stream (ids: 4 bytes per
+// slot, rows: 4 d bytes per slot; no packing pass over the 13 MB of rows).
+extern "C" int crh_comm_allgather_rows(crh_comm* c, const int32_t* ids, const float* rows, int64_t cap, int d,
+                                       int32_t* gathered_ids, float* gathered_rows, void* stream) {
+    CRH_CHECK_ARG(c && ids && rows && gathered_ids && gathered_rows && cap > 0 && d > 0, "crh_comm_allgather_rows: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CRH_NCCL(g_rccl.AllGather(ids, gathered_ids, (size_t)cap, ncclInt32, c->comm, st), "crh_comm_allgather_rows (ids)");
+    CRH_NCCL(g_rccl.AllGather(rows, gathered_rows, (size_t)cap * (size_t)d, ncclFloat32, c->comm, st), "crh_comm_allgather_rows (rows)");
+    return CRH_OK;
+}
+
 extern "C" size_t crh_comm_allgather_topk_workspace_bytes(int world, int64_t n_users, int k) {
     if (world < 1 || n_users < 0 || k < 1) return 0;
     return (size_t)(world + 1) * (size_t)n_users * 2 * (size_t)k * sizeof(int32_t);

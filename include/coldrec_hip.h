@@ -428,6 +428,8 @@ int crh_l2_reg_bwd_f32(const float* x, int64_t n, int64_t rows, float reg, const
  *                            coldrec_amd/eval.py sends through torch.distributed) through the caller's device
  *                            `workspace` of crh_comm_allgather_topk_workspace_bytes(world, n_users, k) bytes
  *   crh_comm_allreduce_f32   in-place sum of n floats: the 4 batch sums of crh_bpr_fwd_f32, the dense gradient table
+ *   crh_comm_allgather_rows  every rank's crh_rows_pack_cap slots of (row id, d floats) -> gathered_* laid out [rank][slot],
+ *                            crh_rows_unpack_f32's input with n = world * cap (the touched-rows step over the ranks)
  * librccl.so is dlopen'ed on first use (an already loaded copy is reused); single-GPU callers never load it.
  * coldrec_amd's Python host layer issues the same collectives through torch.distributed ("nccl" = RCCL).
  */
@@ -438,6 +440,8 @@ int crh_comm_destroy(crh_comm* c);
 int crh_comm_rank(const crh_comm* c);
 int crh_comm_world(const crh_comm* c);
 int crh_comm_allreduce_f32(crh_comm* c, float* buf, int64_t n, void* stream);
+int crh_comm_allgather_rows(crh_comm* c, const int32_t* ids, const float* rows, int64_t cap, int d, int32_t* gathered_ids,
+                            float* gathered_rows, void* stream);
 size_t crh_comm_allgather_topk_workspace_bytes(int world, int64_t n_users, int k);
 int crh_comm_allgather_topk(crh_comm* c, const float* score, const int32_t* idx, int64_t n_users, int k,
                             float* gathered_score, int32_t* gathered_idx, void* workspace, size_t workspace_bytes,

@@ -249,6 +249,30 @@ def test_crh_comm_single_rank_roundtrip():
         torch.cuda.synchronize()
         assert torch.equal(x, want) and torch.equal(gs[0], s) and torch.equal(gi[0], i)
         assert torch.equal(mi, i) and torch.equal(ms, s)
+        # the touched-rows step's exchange through the C ABI alone (round 6): backward over the owned rows -> pack -> crh_comm_allgather_rows
+        # -> unpack into a zeroed gradient table == the plain deterministic backward, bit for bit (world = 1: every row is owned here)
+        n_u, n_i, d, B = 300, 500, 64, 700
+        U0 = t((rng.standard_normal((n_u, d)) * 0.1).astype(np.float32))
+        V0 = t((rng.standard_normal((n_i, d)) * 0.1).astype(np.float32))
+        tri = [t(rng.integers(0, n, B).astype(np.int32)) for n in (n_u, n_i, n_i)]
+        plan = ops.build_plans_device(*tri, B)[0]
+        E = torch.cat([U0, V0]).contiguous()
+        G_want, G_own, G_got = torch.zeros_like(E), torch.zeros_like(E), torch.zeros_like(E)
+        loss = torch.zeros(2, device=DEV)
+        ops.bpr_fwd_bwd(E[:n_u], E[n_u:], E[n_u:], *tri, 1e-3, G_want[:n_u], G_want[n_u:], G_want[n_u:], loss, plan=plan)
+        wsb, sums, loss2 = ops.bpr_workspace(B, DEV), torch.zeros(4, device=DEV), torch.zeros(2, device=DEV)
+        ops.bpr_fwd(E[:n_u], E[n_u:], E[n_u:], *tri, sums, wsb)
+        ops.bpr_bwd_owned(E[:n_u], E[n_u:], *tri, 1e-3, sums, G_own[:n_u], G_own[n_u:], loss2, wsb, plan, 1, 0)
+        cap = ops.rows_pack_cap(B, 1)
+        ids, rows = torch.empty(cap, dtype=torch.int32, device=DEV), torch.zeros((cap, d), device=DEV)
+        ops.rows_pack(G_own, plan, B, n_u, 1, 0, ids, rows)
+        gids, grows = torch.empty_like(ids), torch.empty_like(rows)
+        _lib.check(L.crh_comm_allgather_rows(comm, ids.data_ptr(), rows.data_ptr(), cap, d, gids.data_ptr(), grows.data_ptr(), st),
+                   "crh_comm_allgather_rows")
+        ops.rows_unpack(G_got, gids, grows)
+        torch.cuda.synchronize()
+        assert torch.equal(loss, loss2) and torch.equal(G_own.view(torch.int32), G_want.view(torch.int32))
+        assert torch.equal(G_got.view(torch.int32), G_want.view(torch.int32)) and int((gids >= 0).sum()) == int(plan[0] + plan[1])
     finally:
         _lib.check(L.crh_comm_destroy(comm), "crh_comm_destroy")
 
@@ -448,6 +472,15 @@ ms, mi = ops.merge_topk(gs, gi, k)
 ws, wi = ops.score_topk(U, None, V, k)
 x = torch.full((1000,), float(rank + 1), device=dev)
 _lib.check(L.crh_comm_allreduce_f32(comm, x.data_ptr(), x.numel(), st), "crh_comm_allreduce_f32")
+cap, dd = 37, 16
+rid = torch.arange(cap, dtype=torch.int32, device=dev) * world + rank
+rrow = torch.full((cap, dd), float(rank), device=dev)
+gid, grow = torch.empty(world * cap, dtype=torch.int32, device=dev), torch.empty((world * cap, dd), device=dev)
+_lib.check(L.crh_comm_allgather_rows(comm, rid.data_ptr(), rrow.data_ptr(), cap, dd, gid.data_ptr(), grow.data_ptr(), st),
+           "crh_comm_allgather_rows")
+torch.cuda.synchronize()
+assert all(torch.equal(gid[r * cap:(r + 1) * cap], torch.arange(cap, dtype=torch.int32, device=dev) * world + r) and
+           float(grow[r * cap:(r + 1) * cap].min()) == float(r) == float(grow[r * cap:(r + 1) * cap].max()) for r in range(world))
 torch.cuda.synchronize()
 assert torch.equal(mi, wi) and torch.equal(ms.view(torch.int32), ws.view(torch.int32)), "shards + C-ABI all-gather + merge != one rank"
 assert float(x[0]) == world * (world + 1) / 2 and float(x.min()) == float(x.max())
