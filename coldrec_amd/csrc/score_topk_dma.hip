@@ -187,12 +187,10 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
 template <typename T, int D, int R, bool FL>
 __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     constexpr int NW = DMA_NW, UW = 4, UPW = DMA_UPW;
-    // body j issues the DMA of tile j + PF; in the flag form it publishes its pieces of tile j + PF - 1 - WL (issued 1 + WL
-    // bodies ago).  4 slots: PF 2, WL 0 -- a wave may lead the slowest reader by (NG-2)/NG of a tile, the slowest refiller by
-    // one tile.  8 slots (256-byte rows: a tile lasts 3.4 us, about one cold DMA round trip): PF 5, WL 1 -- 2.5 and 2 tiles
-    constexpr int PF = FL ? (R == 8 ? 5 : 2) : 3;
-    constexpr int WL = FL && R == 8 ? 1 : 0;
-    static_assert(FL ? (R == 4 || R == 8) && sizeof(T) == 4 : R == 4, "ring shape");
+    // body j issues the DMA of tile j + PF; in the flag form it publishes its pieces of tile j + PF - 1 (issued one body ago) first:
+    // a wave may lead the slowest reader by (NG - 2) / NG of a tile and the slowest refiller by one tile
+    constexpr int PF = FL ? 2 : 3;
+    static_assert(R == 4 && (!FL || sizeof(T) == 4), "ring shape");
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int NCH = ROWB / 32;
     constexpr int TILE_B = NCH * 1024;
@@ -216,9 +214,9 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
     unsigned* tbits = reinterpret_cast<unsigned*>(smem + R * TILE_B);   // [2][64]
     unsigned* flags = tbits + TBITS_B / 4;             // FL: ready[R] at 0, done[R] at 8; slots of the prologue's tiles start ready
     if constexpr (FL) {
-        // (published by the prologue's barrier.  Tiles 0 .. PF-2-WL of the prologue start complete; the later ones are bumped by the
-        // first bodies like every tile after them: the prologue waited for all of them)
-        if (threadIdx.x < 16) flags[threadIdx.x] = threadIdx.x < PF - 1 - WL ? (unsigned)NW : 0u;
+        // (published by the prologue's barrier.  Tiles 0 .. PF-2 of the prologue start complete; tile PF-1 is bumped by body 0 like
+        // every tile after it: the prologue waited for all of them)
+        if (threadIdx.x < 16) flags[threadIdx.x] = threadIdx.x < PF - 1 ? (unsigned)NW : 0u;
     }
     const int64_t NT = (a.n_items + 31) >> 5;
     const int64_t t0 = NT * split / S, t1 = NT * (split + 1) / S;
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
             }
             if constexpr (FL) {
                 // The flag protocol, one piece per MFMA gap (n = index of the MFMA just issued, 0 .. 8 UW - 1 in this group):
-                //   group 0      n=0  my pieces of tile j + PF - 1 - WL (issued 1 + WL tiles ago) have landed -> publish them
+                //   group 0      n=0  my pieces of tile j + PF - 1 (issued a whole tile ago) have landed -> publish them
                 //                n=1  may the slot of tile j + PF - R be refilled?  (poll issued in the last group of the body before)
                 //                n=2  the tile bits, n=3 tile j + PF
                 //   group NG-3   n=0  poll: is tile j+1 complete?   n=8: the poll has landed, n=9: spin if it is not
@@ -478,9 +476,8 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
                                          (g == NG - 1 && (n == 0 || n == 8));
                     if constexpr (any) __builtin_amdgcn_sched_barrier(0);
                     if constexpr (g == 0 && n == 0) {
-                        if constexpr (WL == 0) dma_wait_all();
-                        else dma_wait_but_newest_tile();
-                        flag_bump((j + PF - 1 - WL) & (R - 1));
+                        dma_wait_all();
+                        flag_bump((j + PF - 1) & (R - 1));
                     }
                     if constexpr (g == 0 && n == 1) flag_spin(dflag, 8 + s_fill, (unsigned)NW * (unsigned)((j + PF) / R));
                     if constexpr (g == 0 && n == 2) dma_tbits((t0 + j + 32) >> 6);
@@ -646,10 +643,9 @@ size_t score_dma_lds_bytes(int row_bytes, int k, int ring_slots, bool flags) {
     return (size_t)ring_slots * (row_bytes / 32) * 1024 + TBITS_B + (flags ? FLAGS_B : 0) + DMA_NW * dma_wave_lds_bytes(k);
 }
 
-// Ring slots of a launch, 0 = the lists do not fit beside the ring.  (The flag form with EIGHT slots -- 256-byte rows, prefetch
-// distance 5, publish lag 1 -- was built and measured in round 6: at d=64 the per-wave kernel is as fast or faster wherever the
-// flag form beats the barrier form, profiles/r06_flag_vs_barrier_vs_wave_ab.log; the kernel template keeps R = 8, nothing
-// instantiates it.)
+// Ring slots of a launch, 0 = the lists do not fit beside the ring.  (A flag form with EIGHT slots for 256-byte rows -- prefetch
+// distance 5, publish lag 1 -- was built and measured in round 6: at d=64 the per-wave kernel is as fast or faster wherever that
+// form beat the barrier form; HISTORY.md, profiles/r06_flag_vs_barrier_vs_wave_ab.log.)
 int score_dma_ring_slots(int esz, int d, int k, int mode) {
     const bool fl = esz == 4 && d == 128 && mode == 2;
     return score_dma_lds_bytes(d * esz, k, 4, fl) <= 160 * 1024 ? 4 : 0;
