@@ -261,6 +261,41 @@ class Two:
     assert not _is_stock_batch_predict(len) and not _is_stock_batch_predict(functools.partial(print))
 
 
+def test_trainer_says_which_route_its_evaluation_takes(capsys):
+    """at its first evaluation a trainer prints the route -- the fused kernel the LIBRARY names for the shape, or the
+    size of the dense block a non-stock batch_predict materialises per batch -- and warns when that block passes 4 GiB."""
+    import warnings
+    from coldrec_amd.model.BaseRecommender import BaseColdStartTrainer
+    _, d = builder()
+    args = argparse.Namespace(dataset="toy", model="MF", epochs=2, layers=2, topN="10,20", bs=512, emb_size=16,
+                              lr=1e-3, reg=1e-4, early_stop=2, eval_every=1, cold_object="item", save_emb=False)
+    cfg = types.SimpleNamespace(args=args, data=d, device=torch.device("cpu"))
+
+    class Stub(BaseColdStartTrainer):
+        def train(self): ...
+        def predict(self, u): ...
+        def save(self): ...
+        def batch_predict(self, users): ...
+
+    tr = Stub(cfg)
+    c = {"users": list(range(300)), "bitmap": None}
+    tr._tell_route(False, False, c)
+    out = capsys.readouterr().out
+    assert "Evaluation route: batch_predict -> (512 x %d) fp32 score block" % d.item_num in out and "crh_mask_topk_f32" in out
+    assert "not the stock" in out
+    tr.batch_size = 4_000_000                                    # (batch x items x 4 B) far beyond 4 GiB
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tr._tell_route(False, True, c)
+    assert any("GiB score block" in str(x.message) for x in w)
+    assert "not 2-D device tensors" in capsys.readouterr().out
+    tr.item_emb = torch.zeros((10_000_000, 128))                 # the fused route's line names the library's kernel for the shape
+    tr.max_N, c["users"] = 20, list(range(131072))
+    tr._tell_route(True, True, c)
+    out = capsys.readouterr().out
+    assert "fused HIP scoring + masks + top-20 (score_topk_dma_kernel, fused-dma, barrier form, seeded from a 8192-item prefix)" in out
+
+
 def test_trainers_refuse_cpu_and_early_stopping_rules():
     from coldrec_amd.model import AVAILABLE_MODELS
     from coldrec_amd.model.BaseRecommender import BaseColdStartTrainer, _is_stock_batch_predict
