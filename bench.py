@@ -325,18 +325,13 @@ def main():
             rp_last.cpu().numpy() if args.masks != "none" else np.zeros(Bu + 1, np.int64), rc_last.cpu().numpy(),
             None if args.masks == "none" else cold, k, n_check=64)
         result["verified_against"] = "oracle/topk_oracle.c (canonical fp32 fma chain, score desc / index asc), bit-exact"
-    if want_cpu:
-        nu = min(args.cpu_sample_users, n_user_rows)
-        rate, done, secs = cpu_baseline(torch.from_numpy(U_cpu[:nu]), torch.from_numpy(V_cpu), rowptr[:nu + 1], col, cold, k,
-                                        block=256, budget_s=args.cpu_budget_s)
-        result["cpu_baseline"] = {
-            "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d users (of %d sampled; blocks of 256, stopped at the %.0f s budget) x the WHOLE %d-item table, same "
-                      "masks, torch %s matmul+mask+topk on %d threads, %.1f s of CPU work"
-                      % (done, nu, args.cpu_budget_s, V_cpu.shape[0], torch.__version__, os.cpu_count(), secs)}
-    del U_cpu, V_cpu
+    if not want_cpu:
+        del U_cpu, V_cpu
+    # (the CPU baseline itself runs AFTER the legs, below: half a minute of every host core at full tilt leaves worker threads
+    # spinning and clocks ramped, and the legs that time host-side work beside the GPU -- the trainers' end-to-end epochs --
+    # must not run in its wake)
     legs = [] if args.legs == "none" else [x.strip() for x in args.legs.split(",") if x.strip()]
-    wall = {"headline_incl_setup_checks_cpu_baseline": round(time.perf_counter() - t_main, 1)}   # where the run's minutes go
+    wall = {"headline_incl_setup_and_checks": round(time.perf_counter() - t_main, 1)}   # where the run's minutes go
     if world > 1 and not args.no_train and args.dtype == "f32":
         # Secondary leg.  The headline line must survive it: an exception is caught below, and if a rank gets stuck
         # in a collective (the others would wait for ever) a watchdog on every rank prints what it has (rank 0) and
@@ -387,6 +382,18 @@ def main():
                 result.update(leg_fns[leg_name]())
                 torch.cuda.empty_cache()
                 wall[leg_name] = round(time.perf_counter() - t_leg, 1)
+    if want_cpu:
+        t_cpu = time.perf_counter()
+        nu = min(args.cpu_sample_users, n_user_rows)
+        rate, done, secs = cpu_baseline(torch.from_numpy(U_cpu[:nu]), torch.from_numpy(V_cpu), rowptr[:nu + 1], col, cold, k,
+                                        block=256, budget_s=args.cpu_budget_s)
+        result["cpu_baseline"] = {
+            "value": rate, "unit": "items/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d users (of %d sampled; blocks of 256, stopped at the %.0f s budget) x the WHOLE %d-item table, same "
+                      "masks, torch %s matmul+mask+topk on %d threads, %.1f s of CPU work, after every GPU leg of the run"
+                      % (done, nu, args.cpu_budget_s, V_cpu.shape[0], torch.__version__, os.cpu_count(), secs)}
+        del U_cpu, V_cpu
+        wall["cpu_baseline"] = round(time.perf_counter() - t_cpu, 1)
     shard_leg = result.get("eval_midsize", {}).get("%dx%d" % (Bu, I // 8)) if rank == 0 and world == 1 else None
     if shard_leg:
         # what the 8-GPU run is expected to give -- every rank ranks the same user block against its

@@ -123,6 +123,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
     out = {}
     B = 4096
     data_cache = {}
+    cpu_jobs = []
     # the last two: the REFERENCE'S DEFAULT width and depth (main.py:97 --emb_size 64, :94 --layers 2; config/model_param.py),
     # VERDICT r5 #1 -- kernel-side and end-to-end rates only (no second CPU baseline, half the epochs)
     for name, shape, layers, optim, d, cpu_ok, n_timed, n_e2e in (
@@ -184,18 +185,22 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         for _ in range(3):                                            # warm: speculation running, worker core at speed
             runner.run(*pref.get())
         torch.cuda.synchronize()
-        pref.timing, t_run = [], []
+        pref.timing, t_run, t_mark = [], [], []
         t0 = time.perf_counter()
         for _ in range(n_e2e):
             tri_e = pref.get()
             t_r = time.perf_counter()
             runner.run(*tri_e)
-            t_run.append(time.perf_counter() - t_r)
+            t_mark.append(time.perf_counter())
+            t_run.append(t_mark[-1] - t_r)
         torch.cuda.synchronize()
         sec_e2e = (time.perf_counter() - t0) / n_e2e
+        gaps = np.diff(np.array([t0] + t_mark))                       # host-side epoch intervals (the host is at most two epochs ahead)
         tm = np.array(pref.timing) if pref.timing else np.zeros((1, 4))
         e2e_host = {"wait_for_sampler_ms": float(np.median(tm[:, 0])) * 1e3, "publish_state_and_upload_ms": float(np.median(tm[:, 1])) * 1e3,
                     "start_next_epoch_ms": float(np.median(tm[:, 2])) * 1e3, "runner_launch_ms": float(np.median(t_run)) * 1e3,
+                    "epoch_interval_ms": {"median": float(np.median(gaps)) * 1e3, "max": float(gaps.max()) * 1e3,
+                                          "mean": float(gaps.mean()) * 1e3},
                     "note": "medians per epoch on the calling thread: get() = wait + publish/upload + start of the next epoch's "
                             "sampling; run() = copies, plans, per-step factors, graph replay (all asynchronous launches)"}
         pref.timing = None
@@ -235,43 +240,52 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         if tr:
             leg["roofline"].update({"traffic": tr[0], "traffic_source": "committed profile " + tr[1], "traffic_note": what})
         if with_cpu and cpu_ok:
-            from oracle import ref_port
-
-            def make_port():
-                if layers:
-                    return ref_port.LGCNPort(U0.numpy(), V0.numpy(), ref_port.coo_adj(rowptr, col, val), layers, 1e-3, 1e-4,
-                                             optimizer=optim)
-                return ref_port.MFPort(U0.numpy(), V0.numpy(), 1e-3, 1e-4, optimizer=optim)
-
-            def cpu_steps(port, count):
-                t0 = time.perf_counter()
-                for s in range(count):
-                    lo, hi = steps[s % len(steps)]
-                    port.step(u[lo:hi], i[lo:hi], j[lo:hi])
-                return (time.perf_counter() - t0) / count
-
-            # tiny ATen ops do not scale to every core: take the best of a few thread counts, bounded time
-            best = None
-            for th in sorted({os.cpu_count(), min(32, os.cpu_count()), min(8, os.cpu_count())}):
-                torch.set_num_threads(th)
-                port = make_port()
-                cpu_steps(port, 1)
-                dt = cpu_steps(port, 2)
-                if best is None or dt < best[0]:
-                    best = (dt, th)
-            torch.set_num_threads(best[1])
-            port = make_port()
-            cpu_steps(port, 1)
-            n_cpu = int(max(2, min(60, 6.0 / best[0])))
-            dt = cpu_steps(port, n_cpu)
-            torch.set_num_threads(os.cpu_count())
-            leg["cpu_baseline"] = {"value": B / dt, "unit": "triples/s", "cores": best[1], "kind": "port",
-                                   "sample": "%d optimiser steps of the same epoch (torch autograd + torch.optim.%s%s) on %d "
-                                             "threads (best of 8/32/all), sampler excluded"
-                                             % (n_cpu, "SGD" if optim == "sgd" else "Adam",
-                                                ", torch.sparse.mm COO" if layers else "", best[1])}
+            # the CPU port of this leg runs AFTER every GPU leg of this function (below): its hundreds of ATen worker threads keep
+            # spinning for a while after a parallel region, and the NEXT leg's end-to-end epochs -- a host thread sampling beside
+            # the GPU -- then showed 20-70 ms hiccups (train_mf_sgd 0.46 of its kernel-side rate behind train_mf's CPU baseline,
+            # 0.82-0.84 without one before it)
+            cpu_jobs.append((name, leg, U0, V0, (rowptr, col, val) if layers else None, layers, optim, steps, (u, i, j)))
         out[name] = leg
         del eng, runner
+    if cpu_jobs:
+        from oracle import ref_port
+    for name, leg, U0, V0, graph, layers, optim, steps, (u, i, j) in cpu_jobs:
+        if graph is not None:
+            rowptr, col, val = graph
+
+        def make_port():
+            if layers:
+                return ref_port.LGCNPort(U0.numpy(), V0.numpy(), ref_port.coo_adj(rowptr, col, val), layers, 1e-3, 1e-4,
+                                         optimizer=optim)
+            return ref_port.MFPort(U0.numpy(), V0.numpy(), 1e-3, 1e-4, optimizer=optim)
+
+        def cpu_steps(port, count):
+            t0 = time.perf_counter()
+            for s in range(count):
+                lo, hi = steps[s % len(steps)]
+                port.step(u[lo:hi], i[lo:hi], j[lo:hi])
+            return (time.perf_counter() - t0) / count
+
+        # tiny ATen ops do not scale to every core: take the best of a few thread counts, bounded time
+        best = None
+        for th in sorted({os.cpu_count(), min(32, os.cpu_count()), min(8, os.cpu_count())}):
+            torch.set_num_threads(th)
+            port = make_port()
+            cpu_steps(port, 1)
+            dt = cpu_steps(port, 2)
+            if best is None or dt < best[0]:
+                best = (dt, th)
+        torch.set_num_threads(best[1])
+        port = make_port()
+        cpu_steps(port, 1)
+        n_cpu = int(max(2, min(60, 6.0 / best[0])))
+        dt = cpu_steps(port, n_cpu)
+        torch.set_num_threads(os.cpu_count())
+        leg["cpu_baseline"] = {"value": B / dt, "unit": "triples/s", "cores": best[1], "kind": "port",
+                               "sample": "%d optimiser steps of the same epoch (torch autograd + torch.optim.%s%s) on %d "
+                                         "threads (best of 8/32/all), sampler excluded"
+                                         % (n_cpu, "SGD" if optim == "sgd" else "Adam",
+                                            ", torch.sparse.mm COO" if layers else "", best[1])}
     return out
 
 
