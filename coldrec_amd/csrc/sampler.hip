@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -167,6 +168,17 @@ struct crh_sampler {
     std::vector<int32_t> rec_u, rec_i;    // training records, internal ids, file order
     std::vector<int64_t> rec_ui;          // the same, packed (user | item << 32): one cache line per gathered record
     std::vector<int32_t> order;           // cumulative permutation of the records
+    // next_batch_pairwise on record sets whose ids fit 16 bits (MovieLens, CiteULike): the permutation carries each record WITH it
+    // -- index | (user << 16 | item) << 32 -- so that the shuffle needs no third random access for the gather (ord64_live: this
+    // array is the authoritative permutation and `order` is stale until sync_order)
+    std::vector<int64_t> ord64, snap_ord64;
+    bool ord64_live = false, snap_live = false;
+    bool pack16_ok() const { return n_users <= 65536 && n_items <= 65536; }
+    void sync_order() {
+        if (!ord64_live) return;
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)(uint32_t)ord64[i];
+        ord64_live = false;
+    }
     std::vector<int64_t> rowptr;          // per user: sorted training items (rejection test)
     std::vector<int32_t> items;
     int32_t n_users, n_items;
@@ -323,15 +335,19 @@ extern "C" int crh_sampler_snapshot(crh_sampler* s) {
     CRH_CHECK_ARG(s, "crh_sampler_snapshot: NULL sampler");
     s->snap_rng = s->rng;
     s->snap_pyrng = s->pyrng;
-    s->snap_order = s->order;
+    s->snap_live = s->ord64_live;
+    if (s->ord64_live) s->snap_ord64 = s->ord64;             // (one of the two: whichever holds the permutation)
+    else s->snap_order = s->order;
     return CRH_OK;
 }
 
 extern "C" int crh_sampler_restore(crh_sampler* s) {
-    CRH_CHECK_ARG(s && s->snap_order.size() == s->order.size(), "crh_sampler_restore: no snapshot");
+    CRH_CHECK_ARG(s && (s->snap_live ? s->snap_ord64.size() : s->snap_order.size()) == s->order.size(), "crh_sampler_restore: no snapshot");
     s->rng = s->snap_rng;
     s->pyrng = s->snap_pyrng;
-    s->order = s->snap_order;
+    s->ord64_live = s->snap_live;
+    if (s->snap_live) s->ord64 = s->snap_ord64;
+    else s->order = s->snap_order;
     return CRH_OK;
 }
 
@@ -357,9 +373,35 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     // there (a rejected draw writes the not-yet-final record: the accepted one overwrites it).  The loop is bound by its
     // chain through ii and the swapped words; the extra load is independent of that chain and costs next to nothing, where
     // the separate pass over all n slots was a third of an epoch (random 8-byte reads from a 5 MB table).
+    // When user and item ids fit 16 bits the permutation's elements carry the record itself (ord64): two random accesses per draw
+    // instead of three.
     const int64_t* __restrict__ recs = s->rec_ui.data();
-    {
-        int32_t* __restrict__ ord = s->order.data();
+    const bool wide = s->pack16_ok();
+    if (wide && !s->ord64_live) {
+        s->ord64.resize((size_t)n);
+        for (int64_t t = 0; t < n; ++t) {
+            const int64_t ui = recs[s->order[t]];
+            s->ord64[t] = (int64_t)(uint32_t)s->order[t] | ((int64_t)(((uint32_t)ui << 16) | (uint32_t)(ui >> 32)) << 32);
+        }
+        s->ord64_live = true;
+    }
+    auto shuffle = [&](auto WideC) {
+        constexpr bool WIDE = decltype(WideC)::value;
+        using E = std::conditional_t<WIDE, int64_t, int32_t>;
+        E* __restrict__ ord;
+        if constexpr (WIDE) ord = s->ord64.data();
+        else ord = s->order.data();
+        auto emit = [&](int64_t slot, E e) {
+            if constexpr (WIDE) {
+                const uint32_t pk = (uint32_t)((uint64_t)e >> 32);
+                user_out_host[slot] = (int32_t)(pk >> 16);
+                pos_out_host[slot] = (int32_t)(pk & 0xffffu);
+            } else {
+                const int64_t ui = recs[e];
+                user_out_host[slot] = (int32_t)(uint32_t)ui;
+                pos_out_host[slot] = (int32_t)(ui >> 32);
+            }
+        };
         int64_t i = n - 1;
         while (i >= 1) {
             const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);
@@ -373,22 +415,20 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
                     const uint32_t v = w[used++] & mask;
                     const bool ok = v <= (uint32_t)ii;
                     const int64_t j = ok ? (int64_t)v : ii;
-                    const int32_t a = ord[ii], b = ord[j];
+                    const E a = ord[ii], b = ord[j];
                     ord[ii] = b;
                     ord[j] = a;
-                    const int64_t ui = recs[b];
-                    user_out_host[ii] = (int32_t)(uint32_t)ui;
-                    pos_out_host[ii] = (int32_t)(ui >> 32);
+                    emit(ii, b);
                     ii -= ok;
                 }
                 g.pos += used;
                 i = ii;
             }
         }
-        const int64_t u0 = recs[ord[0]];                      // slot 0 is never the top of a swap
-        user_out_host[0] = (int32_t)(uint32_t)u0;
-        pos_out_host[0] = (int32_t)(u0 >> 32);
-    }
+        emit(0, ord[0]);                                          // slot 0 is never the top of a swap
+    };
+    if (wide) shuffle(std::true_type{});
+    else shuffle(std::false_type{});
 #ifdef CRH_PROFILE
     const auto tp1 = std::chrono::steady_clock::now();
 #endif
@@ -643,6 +683,7 @@ inline int32_t draw_neg_user(crh_sampler* s, int32_t item) {
 // util/utils.py:160-188.  neg_* hold n_records * n_negs entries (the reference appends n_negs per record).
 extern "C" int crh_sampler_epoch_lara(crh_sampler* s, int32_t n_negs, int32_t* user_out_host, int32_t* item_out_host,
                                       int32_t* neg_user_out_host, int32_t* neg_item_out_host) {
+    if (s) s->sync_order();           // (the pairwise sampler may hold the permutation in its wide form)
     CRH_CHECK_ARG(s && s->catalogue, "crh_sampler_epoch_lara: call crh_sampler_set_catalogue first");
     CRH_CHECK_ARG(user_out_host && item_out_host && neg_user_out_host && neg_item_out_host && n_negs >= 0,
                   "crh_sampler_epoch_lara: bad arguments");
@@ -670,6 +711,7 @@ extern "C" int crh_sampler_epoch_lara(crh_sampler* s, int32_t n_negs, int32_t* u
 // own math so that the pool / selected-set switch of random.sample falls where CPython puts it.
 extern "C" int crh_sampler_epoch_clcrec(crh_sampler* s, int32_t n_negs, int64_t sample_setsize, int32_t* user_out_host,
                                         int32_t* item_out_host) {
+    if (s) s->sync_order();           // (the pairwise sampler may hold the permutation in its wide form)
     CRH_CHECK_ARG(s && s->catalogue, "crh_sampler_epoch_clcrec: call crh_sampler_set_catalogue first");
     CRH_CHECK_ARG(user_out_host && item_out_host && n_negs >= 0 && sample_setsize >= 21,
                   "crh_sampler_epoch_clcrec: bad arguments");
@@ -713,6 +755,7 @@ extern "C" int crh_sampler_epoch_ccfcrec(crh_sampler* s, int32_t positive_number
                                          int32_t self_neg_number, int32_t* user_out_host, int32_t* item_out_host,
                                          int32_t* neg_user_out_host, int32_t* pos_items_out_host,
                                          int32_t* neg_items_out_host, int32_t* self_neg_out_host) {
+    if (s) s->sync_order();           // (the pairwise sampler may hold the permutation in its wide form)
     CRH_CHECK_ARG(s && s->catalogue, "crh_sampler_epoch_ccfcrec: call crh_sampler_set_catalogue first");
     CRH_CHECK_ARG(user_out_host && item_out_host && neg_user_out_host && pos_items_out_host && neg_items_out_host &&
                   self_neg_out_host && positive_number >= 0 && negative_number >= 0 && self_neg_number >= 0,
@@ -753,6 +796,7 @@ extern "C" int crh_sampler_epoch_ccfcrec(crh_sampler* s, int32_t positive_number
 extern "C" int crh_sampler_epoch_cgrc(crh_sampler* s, int64_t batch_size, int32_t ranking_neg_per_user,
                                       int32_t* user_out_host, int32_t* item_out_host, int64_t* bset_ptr_out_host,
                                       int32_t* bset_out_host, int64_t capacity) {
+    if (s) s->sync_order();           // (the pairwise sampler may hold the permutation in its wide form)
     CRH_CHECK_ARG(s && user_out_host && item_out_host && bset_ptr_out_host && bset_out_host && batch_size > 0 &&
                   ranking_neg_per_user >= 0, "crh_sampler_epoch_cgrc: bad arguments");
     const int64_t n = (int64_t)s->order.size();
