@@ -200,7 +200,11 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         e2e_host = {"wait_for_sampler_ms": float(np.median(tm[:, 0])) * 1e3, "publish_state_and_upload_ms": float(np.median(tm[:, 1])) * 1e3,
                     "start_next_epoch_ms": float(np.median(tm[:, 2])) * 1e3, "runner_launch_ms": float(np.median(t_run)) * 1e3,
                     "epoch_interval_ms": {"median": float(np.median(gaps)) * 1e3, "max": float(gaps.max()) * 1e3,
-                                          "mean": float(gaps.mean()) * 1e3},
+                                          "mean": float(gaps.mean()) * 1e3,
+                                          "longest": [{"epoch": int(q), "ms": round(float(gaps[q]) * 1e3, 3),
+                                                       "wait_publish_start_sync_run_ms": [round(float(x) * 1e3, 3) for x in
+                                                                                         list(tm[q]) + [t_run[q]]]}
+                                                      for q in np.argsort(-gaps)[:3]] if len(tm) == len(gaps) else None},
                     "note": "medians per epoch on the calling thread: get() = wait + publish/upload + start of the next epoch's "
                             "sampling; run() = copies, plans, per-step factors, graph replay (all asynchronous launches)"}
         pref.timing = None
@@ -212,6 +216,7 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
             bytes_step += 2 * layers * (nnz * 8 + (N + 1) * 8 + 2 * N * d * 4) + 2 * (layers + 2) * N * d * 4
         leg = {"metric": "BPR triples/sec (train)", "value": B / sec * (n / (len(steps) * B)), "unit": "triples/s",
                "value_end_to_end": n / sec_e2e, "ms_per_epoch_end_to_end": sec_e2e * 1e3, "end_to_end_epochs": n_e2e,
+               "end_to_end_over_kernel_side": (n / sec_e2e) / (B / sec * (n / (len(steps) * B))),
                "ms_per_step": sec * 1e3, "steps_per_epoch": len(steps), "timed_epochs": n_ep,
                "ms_per_step_spread": {"median": float(np.median(ep_ms)) / len(steps), "min": float(ep_ms.min()) / len(steps),
                                       "max": float(ep_ms.max()) / len(steps), "mean": float(ep_ms.mean()) / len(steps),

@@ -205,8 +205,34 @@ struct crh_sampler {
     bool pack16_ok() const { return n_users <= 65536 && n_items <= 65536; }
     void sync_order() {
         if (!ord64_live) return;
+        keep_snapshot_copy();                                   // (an undo log speaks of the array it was written against)
         for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)(uint32_t)ord64[i];
         ord64_live = false;
+    }
+    // crh_sampler_snapshot / _restore.  A snapshot copies nothing: the pairwise epoch that follows it logs the targets of its
+    // swaps (one uint32 per record, written in stream order by the loop that computes them anyway), and restoring replays them
+    // backwards -- a copy of the permutation per epoch (5 MB read + 5 MB written on the worker's core, and the same again
+    // evicted from its cache) cost a sixth of the epoch for a roll-back that happens once per training run.  Whatever else
+    // touches the permutation under a snapshot (a second epoch, the other samplers' shuffles) first turns the snapshot into a
+    // plain copy.
+    bool snap_armed = false, snap_logged = false, snap_copied = false;
+    HugeVec<uint32_t> swap_log;                                 // swap_log[t] = target of the swap of slot n - 1 - t
+    template <typename E> static void undo_swaps(E* ord, const uint32_t* log, int64_t n) {
+        for (int64_t pi = 1; pi < n; ++pi) std::swap(ord[pi], ord[log[n - 1 - pi]]);
+    }
+    void keep_snapshot_copy() {
+        if (!snap_armed || snap_copied) return;
+        const int64_t n = (int64_t)order.size();
+        snap_live = ord64_live;
+        if (ord64_live) {
+            snap_ord64 = ord64;
+            if (snap_logged) undo_swaps(snap_ord64.data(), swap_log.data(), n);
+        } else {
+            snap_order = order;
+            if (snap_logged) undo_swaps(snap_order.data(), swap_log.data(), n);
+        }
+        snap_copied = true;
+        snap_logged = false;
     }
     std::vector<int64_t> rowptr;          // per user: sorted training items (rejection test)
     std::vector<int32_t> items;
@@ -364,19 +390,25 @@ extern "C" int crh_sampler_snapshot(crh_sampler* s) {
     CRH_CHECK_ARG(s, "crh_sampler_snapshot: NULL sampler");
     s->snap_rng = s->rng;
     s->snap_pyrng = s->pyrng;
-    s->snap_live = s->ord64_live;
-    if (s->ord64_live) s->snap_ord64 = s->ord64;             // (one of the two: whichever holds the permutation)
-    else s->snap_order = s->order;
+    s->snap_armed = true;
+    s->snap_logged = s->snap_copied = false;
     return CRH_OK;
 }
 
 extern "C" int crh_sampler_restore(crh_sampler* s) {
-    CRH_CHECK_ARG(s && (s->snap_live ? s->snap_ord64.size() : s->snap_order.size()) == s->order.size(), "crh_sampler_restore: no snapshot");
+    CRH_CHECK_ARG(s && s->snap_armed, "crh_sampler_restore: no snapshot");
     s->rng = s->snap_rng;
     s->pyrng = s->snap_pyrng;
-    s->ord64_live = s->snap_live;
-    if (s->snap_live) s->ord64 = s->snap_ord64;
-    else s->order = s->snap_order;
+    if (s->snap_copied) {
+        s->ord64_live = s->snap_live;
+        if (s->snap_live) s->ord64 = s->snap_ord64;
+        else s->order = s->snap_order;
+    } else if (s->snap_logged) {
+        const int64_t n = (int64_t)s->order.size();
+        if (s->ord64_live) crh_sampler::undo_swaps(s->ord64.data(), s->swap_log.data(), n);
+        else crh_sampler::undo_swaps(s->order.data(), s->swap_log.data(), n);
+        s->snap_logged = false;                                 // (the permutation IS the snapshot again)
+    }
     return CRH_OK;
 }
 
@@ -404,6 +436,10 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     // instead of three.
     const int64_t* __restrict__ recs = s->rec_ui.data();
     const bool wide = s->pack16_ok();
+    if (s->snap_armed && (s->snap_logged || wide != s->ord64_live)) s->keep_snapshot_copy();   // second epoch under one snapshot / form changes
+    const bool logging = s->snap_armed && !s->snap_copied;
+    if (logging) s->swap_log.resize((size_t)n);
+    uint32_t* __restrict__ slog = logging ? s->swap_log.data() : nullptr;
     if (wide && !s->ord64_live) {
         s->ord64.resize((size_t)n);
         for (int64_t t = 0; t < n; ++t) {
@@ -474,6 +510,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
                     ii -= ok;
                 }
                 g.pos += used;
+                if (slog) memcpy(slog + (n - 1 - i), jl, (size_t)m * sizeof(uint32_t));
                 for (int64_t t = 0; t < m; ++t) {
                     if (t + PF < m) __builtin_prefetch(&ord[jl[t + PF]], 1, 3);
                     const int64_t pi = i - t, j = (int64_t)jl[t];
@@ -489,6 +526,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     };
     if (wide) shuffle(std::true_type{});
     else shuffle(std::false_type{});
+    if (logging) s->snap_logged = true;
 #ifdef CRH_PROFILE
     const auto tp1 = std::chrono::steady_clock::now();
 #endif
@@ -729,6 +767,7 @@ extern "C" int64_t crh_sampler_min_candidates(const crh_sampler* s) {
 namespace {
 // random.shuffle(training_data): for i = n-1 .. 1: j = _randbelow(i + 1); swap
 void py_shuffle(crh_sampler* s) {
+    s->keep_snapshot_copy();
     for (int64_t i = (int64_t)s->order.size() - 1; i >= 1; --i)
         std::swap(s->order[i], s->order[s->pyrng.py_randbelow((uint32_t)(i + 1))]);
 }
@@ -860,6 +899,7 @@ extern "C" int crh_sampler_epoch_cgrc(crh_sampler* s, int64_t batch_size, int32_
     CRH_CHECK_ARG(s && user_out_host && item_out_host && bset_ptr_out_host && bset_out_host && batch_size > 0 &&
                   ranking_neg_per_user >= 0, "crh_sampler_epoch_cgrc: bad arguments");
     const int64_t n = (int64_t)s->order.size();
+    s->keep_snapshot_copy();
     for (int64_t i = n - 1; i >= 1; --i) std::swap(s->order[i], s->order[s->rng.bounded((uint32_t)i)]);   // np.random.shuffle
     const uint32_t imax = (uint32_t)(s->n_items - 1);
     const int64_t max_tries = (int64_t)ranking_neg_per_user * 50;

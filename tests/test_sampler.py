@@ -398,6 +398,55 @@ def test_epoch_prefetcher_keeps_the_stream_and_takes_back_unused_epochs():
         assert np.array_equal(np.random.randint(0, 1 << 30, 4), tail)
 
 
+def test_snapshot_restore_through_every_path():
+    """crh_sampler_snapshot copies nothing: the pairwise epoch after it logs its swaps and _restore replays them backwards;
+    a second epoch or another sampler's shuffle under the same snapshot turns it into a copy first.  Whatever ran in
+    between, the epochs after _restore are the epochs a sampler that never speculated draws."""
+    from coldrec_amd import _lib
+    g, ru, ri = _toy()
+    n_u, n_i, B = int(g["user_num"]), len(g["item_keys"]), 512
+
+    def fresh(wide=True):
+        # (ids beyond 16 bits: the permutation stays in its narrow form)
+        s = PairwiseSampler(ru, ri, n_u if wide else 70000, n_i)
+        s.set_catalogue(len(g["user_keys"]), g["mapped_cold_item_idx"])
+        s.seed(11)
+        import random
+        random.seed(11)
+        s.pull_python_state()
+        return s
+
+    def snap(s):
+        _lib.check(s._L.crh_sampler_snapshot(s._h), "snapshot")
+
+    def back(s):
+        _lib.check(s._L.crh_sampler_restore(s._h), "restore")
+
+    for wide in (True, False):
+        ref = fresh(wide)
+        e1 = ref.epoch(B)
+        want = [ref.epoch(B), ref.epoch(B)]
+        want_lara = ref.epoch_lara(1)
+        for between in ("nothing", "one epoch", "two epochs", "epoch + lara", "lara", "restore twice"):
+            s = fresh(wide)
+            assert all(np.array_equal(a, b) for a, b in zip(s.epoch(B), e1))
+            snap(s)
+            if between in ("one epoch", "two epochs", "epoch + lara", "restore twice"):
+                s.epoch(B)
+            if between == "two epochs":
+                s.epoch(B)
+            if between in ("epoch + lara", "lara"):
+                s.epoch_lara(1)
+            back(s)
+            if between == "restore twice":
+                assert all(np.array_equal(a, b) for a, b in zip(s.epoch(B), want[0]))
+                back(s)
+            got = [s.epoch(B), s.epoch(B)]
+            for a, b in zip(got, want):
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (wide, between)
+            assert all(np.array_equal(x, y) for x, y in zip(s.epoch_lara(1), want_lara)), (wide, between)
+
+
 def test_cgrc_try_limit_and_lara_guard():
     """next_batch_cgrc stops drawing for a user after 50 x ranking_neg tries (a user that rated everything consumes
     exactly that many draws, util/utils.py:321-334); next_batch_pairwise_LARA would loop for ever on such a user in
