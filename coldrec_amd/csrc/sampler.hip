@@ -31,6 +31,9 @@
 #include <vector>
 
 #include <sys/mman.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 #include "crh_common.h"
 
@@ -69,6 +72,53 @@ struct HugeAlloc {
     template <typename U> bool operator!=(const HugeAlloc<U>&) const { return false; }
 };
 template <typename T> using HugeVec = std::vector<T, HugeAlloc<T>>;
+
+// The two stream compactions of an epoch -- which raw draws of the shuffle are accepted, which masked words are item ids --
+// 16 draws per step on hosts with AVX-512 (mask, two compares, vpcompressd in its register form, one store): the scalar forms
+// cost 2.5 and 1.5 cycles per raw draw, these a quarter of a cycle (tools/probes/sampler_host_probe.cpp).  Both return the
+// number of raw draws they consumed and stop where the scalar walk has to take over (a group with a draw in (ii - 16, ii], the
+// end of the window, the end of the mask's range).
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define CRH_HAVE_AVX512_PATH 1
+__attribute__((target("avx512f"))) int shuffle_accept_avx512(const uint32_t* __restrict__ w, int avail, uint32_t mask, int64_t stop,
+                                                             int64_t& ii, uint32_t* __restrict__ jl, int64_t& m) {
+    int used = 0;
+    const __m512i vmask = _mm512_set1_epi32((int)mask);
+    while (used + 16 <= avail && ii - stop >= 16) {
+        const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(w + used)), vmask);
+        const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(ii - 16)));
+        const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)ii));
+        if (__builtin_expect((__mmask16)(acc | rej) != (__mmask16)0xffff, 0)) break;
+        _mm512_storeu_si512((void*)(jl + m), _mm512_maskz_compress_epi32(acc, v));   // (16 lanes stored: m + 16 <= used + 16 <= 624)
+        const int c = __builtin_popcount((unsigned)acc);
+        m += c;
+        ii -= c;
+        used += 16;
+    }
+    return used;
+}
+__attribute__((target("avx512f"))) int draw_items_avx512(const uint32_t* __restrict__ w, int avail, uint32_t imask, uint32_t imax,
+                                                         int32_t* __restrict__ dst, int64_t cnt, int64_t& w_) {
+    int used = 0;
+    const __m512i vm = _mm512_set1_epi32((int)imask), vx = _mm512_set1_epi32((int)imax);
+    while (used + 16 <= avail && w_ + 16 <= cnt) {           // (a store of 16 lanes stays inside dst[0, cnt))
+        const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(w + used)), vm);
+        const __mmask16 acc = _mm512_cmple_epu32_mask(v, vx);
+        _mm512_storeu_si512((void*)(dst + w_), _mm512_maskz_compress_epi32(acc, v));
+        w_ += __builtin_popcount((unsigned)acc);
+        used += 16;
+    }
+    return used;
+}
+bool host_has_avx512() {
+    static const bool have = __builtin_cpu_supports("avx512f") && getenv("CRH_SAMPLER_NO_AVX512") == nullptr;
+    return have;
+}
+#else
+int shuffle_accept_avx512(const uint32_t*, int, uint32_t, int64_t, int64_t&, uint32_t*, int64_t&) { return 0; }
+int draw_items_avx512(const uint32_t*, int, uint32_t, uint32_t, int32_t*, int64_t, int64_t&) { return 0; }
+bool host_has_avx512() { return false; }
+#endif
 
 struct MT19937 {
     uint32_t key[624];
@@ -412,6 +462,37 @@ extern "C" int crh_sampler_restore(crh_sampler* s) {
     return CRH_OK;
 }
 
+namespace {
+// The membership test of a batch's negatives against the users x items bitmap, as loops of their own: inside the epoch function
+// (a dozen live pointers, the generic `rated` fallback inlined beside it) the same loop reloaded four spilled pointers per test and
+// ran at 1.4 ns per test where this one runs at 0.95 (tools/probes/sampler_host_probe.cpp).  Branch-free compaction: the slot is
+// written, the count advances by the bit.  One random 64-byte line per test; the line of the test 32 slots ahead is prefetched.
+__attribute__((noinline)) int64_t rated_slots_bits(const uint64_t* __restrict__ bits, int64_t wpu, const int32_t* __restrict__ u,
+                                                   const int32_t* __restrict__ neg, int64_t lo, int64_t hi, int32_t* __restrict__ chk) {
+    constexpr int64_t PF = 32;
+    int64_t nc = 0;
+    for (int64_t t = lo; t < hi; ++t) {
+        if (t + PF < hi) __builtin_prefetch(&bits[(size_t)u[t + PF] * wpu + (neg[t + PF] >> 6)], 0, 3);
+        chk[nc] = (int32_t)t;
+        nc += (bits[(size_t)u[t] * wpu + (neg[t] >> 6)] >> (neg[t] & 63)) & 1u;
+    }
+    return nc;
+}
+// one redraw round: the slots of `chk` take the new draws; those that are rated again are compacted into `nxt`
+__attribute__((noinline)) int64_t redraw_round_bits(const uint64_t* __restrict__ bits, int64_t wpu, const int32_t* __restrict__ u,
+                                                    int32_t* __restrict__ neg, const int32_t* __restrict__ chk, int64_t nc,
+                                                    const int32_t* __restrict__ drawn, int32_t* __restrict__ nxt) {
+    int64_t nn = 0;
+    for (int64_t q = 0; q < nc; ++q) {
+        const int32_t t = chk[q], it = drawn[q];
+        neg[t] = it;
+        nxt[nn] = t;
+        nn += (bits[(size_t)u[t] * wpu + (it >> 6)] >> (it & 63)) & 1u;
+    }
+    return nn;
+}
+}  // namespace
+
 // One epoch: all batches concatenated (the last one is short).  Output arrays hold n_records int32.
 extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host,
                                  int32_t* pos_out_host, int32_t* neg_out_host) {
@@ -425,7 +506,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
 #ifdef CRH_PROFILE
     static const bool timing = getenv("CRH_SAMPLER_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    double t_gather = 0, t_draw = 0, t_reject = 0;
+    double t_gather = 0, t_draw = 0, t_reject = 0, t_first = 0;
 #endif
     // The gather of the shuffled records rides in the shuffle's shadow: position ii is final once its (accepted) swap is done
     // -- Fisher-Yates from the top never touches it again -- so user / positive item of slot ii are fetched and stored right
@@ -448,6 +529,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
         }
         s->ord64_live = true;
     }
+    const bool avx512 = host_has_avx512();
     auto shuffle = [&](auto WideC) {
         constexpr bool WIDE = decltype(WideC)::value;
         using E = std::conditional_t<WIDE, int64_t, int32_t>;
@@ -472,7 +554,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
         // by the next iteration, and the targets are known early enough to be prefetched.
         // (tools/probes/sampler_host_probe.cpp: 1.20 -> 0.83 ms per MovieLens epoch against the one-pass walk per raw draw.)
         uint32_t jl[624 + 8];
-        constexpr int PF = 8;
+        constexpr int PF = 16;
         int64_t i = n - 1;
         while (i >= 1) {
             const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);
@@ -483,7 +565,10 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
                 int used = 0;
                 int64_t ii = i, m = 0;
                 while (used < avail && ii > stop) {
-                    if (used + 8 <= avail && ii - stop >= 8) {
+                    if (avx512) {
+                        used += shuffle_accept_avx512(w + used, avail - used, mask, stop, ii, jl, m);
+                        if (!(used < avail && ii > stop)) break;
+                    } else if (used + 8 <= avail && ii - stop >= 8) {
                         const uint32_t lo = (uint32_t)(ii - 8), hi = (uint32_t)ii;
                         uint32_t v[8];
                         uint32_t amb = 0;
@@ -542,7 +627,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
         while (w_ < cnt) {
             int avail;
             const uint32_t* __restrict__ w = g.window(avail);
-            int used = 0;
+            int used = avx512 ? draw_items_avx512(w, avail, imask, imax, dst, cnt, w_) : 0;
             while (used < avail && w_ < cnt) {
                 const uint32_t v = w[used++] & imask;
                 dst[w_] = (int32_t)v;
@@ -557,10 +642,7 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     const bool use_bits = s->words_per_user != 0;
     const uint64_t* __restrict__ bits = s->bits.data();
     const int64_t wpu = s->words_per_user;
-    auto is_rated = [&](int32_t u, int32_t it) -> bool {
-        if (use_bits) return (bits[(size_t)u * wpu + (it >> 6)] >> (it & 63)) & 1u;
-        return s->rated(u, it);
-    };
+    auto is_rated = [&](int32_t u, int32_t it) -> bool { return s->rated(u, it); };     // (record sets too large for a bitmap)
     for (int64_t lo = 0; lo < n; lo += batch_size) {
         const int64_t hi = std::min(lo + batch_size, n);
 #ifdef CRH_PROFILE
@@ -578,20 +660,28 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
 #endif
         int32_t* chk = s->check.data();
         int64_t nc = 0;
-        for (int64_t t = lo; t < hi; ++t) {                  // compaction without a branch on the outcome
-            chk[nc] = (int32_t)t;
-            nc += is_rated(user_out_host[t], neg_out_host[t]);
-        }
+        if (use_bits) nc = rated_slots_bits(bits, wpu, user_out_host, neg_out_host, lo, hi, chk);
+        else
+            for (int64_t t = lo; t < hi; ++t) {              // compaction without a branch on the outcome
+                chk[nc] = (int32_t)t;
+                nc += is_rated(user_out_host[t], neg_out_host[t]);
+            }
+#ifdef CRH_PROFILE
+        const auto tb3 = std::chrono::steady_clock::now();
+        t_first += std::chrono::duration<double>(tb3 - tb2).count();
+#endif
         while (nc > 0) {                                     // redraw only the rejected slots, in slot order
             draw_items(s->redraw.data(), nc);
             int32_t* nxt = s->next_check.data();
             int64_t nn = 0;
-            for (int64_t q = 0; q < nc; ++q) {
-                const int32_t t = chk[q];
-                neg_out_host[t] = s->redraw[q];
-                nxt[nn] = t;
-                nn += is_rated(user_out_host[t], neg_out_host[t]);
-            }
+            if (use_bits) nn = redraw_round_bits(bits, wpu, user_out_host, neg_out_host, chk, nc, s->redraw.data(), nxt);
+            else
+                for (int64_t q = 0; q < nc; ++q) {
+                    const int32_t t = chk[q];
+                    neg_out_host[t] = s->redraw[q];
+                    nxt[nn] = t;
+                    nn += is_rated(user_out_host[t], neg_out_host[t]);
+                }
             s->check.swap(s->next_check);
             chk = s->check.data();
             nc = nn;
@@ -602,8 +692,8 @@ extern "C" int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* us
     }
 #ifdef CRH_PROFILE
     if (timing)
-        fprintf(stderr, "[crh sampler] shuffle %.3f ms, gather %.3f ms, first draws %.3f ms, membership + redraws %.3f ms\n",
-                std::chrono::duration<double>(tp1 - tp0).count() * 1e3, t_gather * 1e3, t_draw * 1e3, t_reject * 1e3);
+        fprintf(stderr, "[crh sampler] shuffle %.3f ms, gather %.3f ms, first draws %.3f ms, membership + redraws %.3f ms (first pass %.3f)\n",
+                std::chrono::duration<double>(tp1 - tp0).count() * 1e3, t_gather * 1e3, t_draw * 1e3, t_reject * 1e3, t_first * 1e3);
 #endif
     return CRH_OK;
 }

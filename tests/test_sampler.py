@@ -447,6 +447,21 @@ def test_snapshot_restore_through_every_path():
             assert all(np.array_equal(x, y) for x, y in zip(s.epoch_lara(1), want_lara)), (wide, between)
 
 
+def test_scalar_compactions_when_avx512_is_switched_off():
+    """On hosts with AVX-512 (the build container and the GPU boxes both) the two stream compactions of an epoch run 16 draws
+    per step; the scalar forms are what every other host runs.  The switch is read once per process, so the golden-stream
+    tests are repeated in a child with CRH_SAMPLER_NO_AVX512=1."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CRH_SAMPLER_NO_AVX512="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "golden_g1 or large_record_set or snapshot_restore or prefetcher"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "deselected" in r.stdout
+
+
 def test_cgrc_try_limit_and_lara_guard():
     """next_batch_cgrc stops drawing for a user after 50 x ranking_neg tries (a user that rated everything consumes
     exactly that many draws, util/utils.py:321-334); next_batch_pairwise_LARA would loop for ever on such a user in

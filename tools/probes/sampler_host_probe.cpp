@@ -136,6 +136,136 @@ static int64_t shuffle_s2(int64_t* __restrict__ ord, int64_t n, const uint32_t* 
     return used;
 }
 
+// S3: S2 with phase A in AVX-512: 16 draws masked, compared and compacted (vpcompressd, register form) per step
+#include <immintrin.h>
+template <int WIN, int PF>
+__attribute__((target("avx512f"))) static int64_t shuffle_s3(int64_t* __restrict__ ord, int64_t n, const uint32_t* __restrict__ w, Out o) {
+    int64_t used = 0, i = n - 1;
+    uint32_t jl[WIN + 64];
+    while (i >= 1) {
+        const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);
+        const int64_t stop = (int64_t)(mask >> 1);
+        const __m512i vmask = _mm512_set1_epi32((int)mask);
+        while (i > stop) {
+            int64_t ii = i;
+            int64_t m = 0;
+            int q = 0;
+            const uint32_t* ww = w + used;
+            while (q < WIN && ii > stop) {
+                if (q + 16 <= WIN && ii - stop >= 16) {
+                    const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(ww + q)), vmask);
+                    const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(ii - 16)));
+                    const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)ii));
+                    if (__builtin_expect((__mmask16)(acc | rej) == (__mmask16)0xffff, 1)) {
+                        _mm512_storeu_si512((void*)(jl + m), _mm512_maskz_compress_epi32(acc, v));
+                        const int c = __builtin_popcount((unsigned)acc);
+                        m += c;
+                        ii -= c;
+                        q += 16;
+                        continue;
+                    }
+                }
+                const uint32_t v = ww[q++] & mask;
+                jl[m] = v;
+                const bool ok = v <= (uint32_t)ii;
+                m += ok;
+                ii -= ok;
+            }
+            used += q;
+            for (int64_t t = 0; t < m; ++t) {
+                if (PF > 0 && t + PF < m) __builtin_prefetch(&ord[jl[t + PF]], 1, 3);
+                const int64_t pi = i - t, j = jl[t];
+                const int64_t a = ord[pi], b = ord[j];
+                ord[pi] = b;
+                ord[j] = a;
+                emit(o, pi, b);
+            }
+            i = ii;
+        }
+    }
+    emit(o, 0, ord[0]);
+    return used;
+}
+
+// S4: S3 on 32-bit elements that ARE the record (user << 16 | item), no index beside it: half the table
+template <int WIN, int PF>
+__attribute__((target("avx512f"))) static int64_t shuffle_s4(uint32_t* __restrict__ ord, int64_t n, const uint32_t* __restrict__ w, Out o) {
+    int64_t used = 0, i = n - 1;
+    uint32_t jl[WIN + 64];
+    while (i >= 1) {
+        const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);
+        const int64_t stop = (int64_t)(mask >> 1);
+        const __m512i vmask = _mm512_set1_epi32((int)mask);
+        while (i > stop) {
+            int64_t ii = i;
+            int64_t m = 0;
+            int q = 0;
+            const uint32_t* ww = w + used;
+            while (q < WIN && ii > stop) {
+                if (q + 16 <= WIN && ii - stop >= 16) {
+                    const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(ww + q)), vmask);
+                    const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(ii - 16)));
+                    const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)ii));
+                    if (__builtin_expect((__mmask16)(acc | rej) == (__mmask16)0xffff, 1)) {
+                        _mm512_storeu_si512((void*)(jl + m), _mm512_maskz_compress_epi32(acc, v));
+                        const int c = __builtin_popcount((unsigned)acc);
+                        m += c;
+                        ii -= c;
+                        q += 16;
+                        continue;
+                    }
+                }
+                const uint32_t v = ww[q++] & mask;
+                jl[m] = v;
+                const bool ok = v <= (uint32_t)ii;
+                m += ok;
+                ii -= ok;
+            }
+            used += q;
+            for (int64_t t = 0; t < m; ++t) {
+                if (PF > 0 && t + PF < m) __builtin_prefetch(&ord[jl[t + PF]], 1, 3);
+                const int64_t pi = i - t, j = jl[t];
+                const uint32_t a = ord[pi], b = ord[j];
+                ord[pi] = b;
+                ord[j] = a;
+                o.u[pi] = (int32_t)(b >> 16); o.p[pi] = (int32_t)(b & 0xffffu);
+            }
+            i = ii;
+        }
+    }
+    o.u[0] = (int32_t)(ord[0] >> 16); o.p[0] = (int32_t)(ord[0] & 0xffffu);
+    return used;
+}
+
+// the masked-rejection draws of item ids: D0 shipped (write, advance if accepted), D1 AVX-512 compaction
+static int64_t draws_d0(const uint32_t* __restrict__ w, uint32_t imask, uint32_t imax, int32_t* __restrict__ dst, int64_t cnt) {
+    int64_t w_ = 0, used = 0;
+    while (w_ < cnt) {
+        const uint32_t v = w[used++] & imask;
+        dst[w_] = (int32_t)v;
+        w_ += v <= imax;
+    }
+    return used;
+}
+__attribute__((target("avx512f"))) static int64_t draws_d1(const uint32_t* __restrict__ w, uint32_t imask, uint32_t imax,
+                                                           int32_t* __restrict__ dst, int64_t cnt) {
+    int64_t w_ = 0, used = 0;
+    const __m512i vm = _mm512_set1_epi32((int)imask), vx = _mm512_set1_epi32((int)imax);
+    while (w_ + 16 <= cnt) {                              // (a full store of 16 stays inside dst)
+        const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(w + used)), vm);
+        const __mmask16 acc = _mm512_cmple_epu32_mask(v, vx);
+        _mm512_storeu_si512((void*)(dst + w_), _mm512_maskz_compress_epi32(acc, v));
+        w_ += __builtin_popcount((unsigned)acc);
+        used += 16;
+    }
+    while (w_ < cnt) {
+        const uint32_t v = w[used++] & imask;
+        dst[w_] = (int32_t)v;
+        w_ += v <= imax;
+    }
+    return used;
+}
+
 // M2: 64 tests into one mask word (no store per test), then the set bits are appended
 static int64_t member_m2(const uint64_t* __restrict__ bits, int64_t wpu, const int32_t* __restrict__ u,
                          const int32_t* __restrict__ neg, int64_t n, int64_t batch, int32_t* __restrict__ chk) {
@@ -220,6 +350,47 @@ int main(int argc, char** argv) {
     run("shuffle S2 win 624 pf 8", shuffle_s2<624, 8>);
     run("shuffle S2 win 624 pf 24", shuffle_s2<624, 24>);
     run("shuffle S2 win 2496 pf 24", shuffle_s2<2496, 24>);
+    const bool avx512 = __builtin_cpu_supports("avx512f");
+    if (avx512) {
+        run("shuffle S3 avx512 win 624 pf 8", shuffle_s3<624, 8>);
+        run("shuffle S3 avx512 win 624 pf 16", shuffle_s3<624, 16>);
+        std::vector<uint32_t> o32((size_t)n);
+        for (int64_t t = 0; t < n; ++t) o32[t] = (uint32_t)((uint64_t)base[t] >> 32);
+        for (int pf : {16, 32}) {
+            double best = 1e9;
+            int64_t used = 0;
+            for (int r = 0; r < reps; ++r) {
+                const double t0 = now();
+                used = pf == 16 ? shuffle_s4<624, 16>(o32.data(), n, raw.data(), o) : shuffle_s4<624, 32>(o32.data(), n, raw.data(), o);
+                const double dt = now() - t0;
+                if (dt < best) best = dt;
+            }
+            printf("shuffle S4 32-bit records pf %d  %.3f ms  %.2f ns/raw draw\n", pf, best * 1e3, best * 1e9 / used);
+        }
+    }
+    {
+        std::vector<int32_t> d0((size_t)n + 16), d1((size_t)n + 16);
+        const uint32_t imax = (uint32_t)(ni - 1), imask = 0xffffffffu >> __builtin_clz(imax);
+        auto rund = [&](const char* name, auto fn, std::vector<int32_t>& dst) {
+            double best = 1e9;
+            int64_t used = 0;
+            for (int r = 0; r < reps; ++r) {
+                const double t0 = now();
+                // batch by batch, as the library draws them (the compaction restarts per batch)
+                used = 0;
+                for (int64_t lo = 0; lo < n; lo += 4096) used += fn(raw.data() + used, imask, imax, dst.data() + lo, (lo + 4096 < n ? lo + 4096 : n) - lo);
+                const double dt = now() - t0;
+                if (dt < best) best = dt;
+            }
+            printf("%-28s %.3f ms  %.2f ns/raw draw  (%lld raw)\n", name, best * 1e3, best * 1e9 / used, (long long)used);
+        };
+        rund("draws D0 shipped", draws_d0, d0);
+        if (avx512) {
+            rund("draws D1 avx512", draws_d1, d1);
+            d0.resize((size_t)n); d1.resize((size_t)n);
+            printf("draws identical: %s\n", d0 == d1 ? "yes" : "NO");
+        }
+    }
 
     const int64_t wpu = (ni + 63) / 64;
     std::vector<uint64_t> bits((size_t)(nu * wpu));
