@@ -182,8 +182,10 @@ def train_legs(dev, with_cpu, e2e_epochs=30, timed_epochs=60):
         # ---- end to end: sampler + prefetch + upload + plans + steps, as model/MF.py's epoch loop runs them
         np.random.seed(2024)
         pref = EpochPrefetcher(smp, B, device=dev)
-        for _ in range(3):                                            # warm: speculation running, worker core at speed
-            runner.run(*pref.get())
+        for _ in range(12):                                           # warm: speculation running, worker core at speed -- the
+            runner.run(*pref.get())                                   # hosts' cores idle at a quarter of their clock and take
+        # ~5 epochs of the worker's sampling (25 ms) to ramp: with 3 warm epochs the first timed ones ran 4-9 ms and cost a
+        # 15-epoch leg a quarter of its mean (`epoch_interval_ms.longest` used to name epochs 2-6; profiles/r06_e2e_gaps.log)
         torch.cuda.synchronize()
         pref.timing, t_run, t_mark = [], [], []
         t0 = time.perf_counter()
