@@ -54,6 +54,16 @@ __device__ __forceinline__ void mma_f32_hooked(f32x16 (&acc)[UW], const f32x4& c
 // (Measured and not kept, round 5: one LDS round trip per candidate -- the whole list, its fill and the filter word
 // requested together, the insert and the user's new threshold computed from those registers -- ran 2.7 % SLOWER on the
 // same box, 0.5316 vs 0.5457 of 2.5 PF: most events end at the "cannot enter" test after three scalar reads.)
+// ONE_TRIP (fp32): the candidate's list rides the first batch of LDS reads (fill, list, filter word: one wait) and the insert works
+// out of those registers -- at fp32 a candidate above its user's threshold does enter (no rounding ties), so the second round trip
+// of the two-step form (fill and list read again by the insert) is paid by nearly every event; at fp16 most events end at the
+// "cannot enter" test and the lean first batch wins (the round-5 measurement above).
+#ifdef CRH_DMA_TWO_TRIP                      // (variant build: the two-step form for fp32 too, tools/ab_lib.sh)
+constexpr bool DMA_ONE_TRIP_F32 = false;
+#else
+constexpr bool DMA_ONE_TRIP_F32 = true;
+#endif
+template <bool ONE_TRIP>
 __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau_reg, float* ls, int* li, int* cnt, int K,
                                                    int ucol0, int64_t slot0, const ScoreArgs& a, int64_t item0,
                                                    int64_t split_end, int lane, unsigned tb, const unsigned* rfilter) {
@@ -90,13 +100,15 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
             // one batch of LDS reads: fill, tail entry, filter word
             const unsigned hsh = rated_hash192(gi);
             const int n_raw = cnt[ul];
-            const float ks_raw = lsu[K - 1];
-            const int ki_raw = liu[K - 1];
+            const int le = ONE_TRIP ? (lane < K ? lane : K - 1) : K - 1;   // (ONE_TRIP: lane l reads entry l; the others the tail entry)
+            const float ks_raw = lsu[le];
+            const int ki_raw = liu[le];
             const unsigned fw_raw = a.rated_rowptr ? rfilter[ul * DMA_FW + (hsh >> 5)] : 0u;
             const int n = __builtin_amdgcn_readfirstlane(n_raw);
             if (n >= K) {
-                const float ks = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ks_raw)));
-                const int ki = __builtin_amdgcn_readfirstlane(ki_raw);
+                const float ks = ONE_TRIP ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ks_raw), K - 1))
+                                          : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ks_raw)));
+                const int ki = ONE_TRIP ? __builtin_amdgcn_readlane(ki_raw, K - 1) : __builtin_amdgcn_readfirstlane(ki_raw);
                 if (!crh_better(fmaxf(sc, CRH_MASKED_SCORE), gi, ks, ki)) continue;   // cannot enter a full list
             }
             bool masked = (bmL >> r) & 1u;
@@ -113,12 +125,18 @@ __device__ __forceinline__ void tile_slow_path_dma(const f32x16& acc, float& tau
             // wave_list_insert (k <= 64 here) that also hands back the user's NEW threshold out of the registers it already
             // holds -- the k-th entry after the insert is the old (k-1)-th or the candidate -- instead of reading it back
             {
-                const int n = __builtin_amdgcn_readfirstlane(cnt[ul]);
                 float es = CRH_NEG_INF;
                 int ei = CRH_PAD_IDX;
-                if (lane < n) {
-                    es = lsu[lane];
-                    ei = liu[lane];
+                if constexpr (ONE_TRIP) {
+                    if (lane < n) {
+                        es = ks_raw;
+                        ei = ki_raw;
+                    }
+                } else {
+                    if (lane < n) {
+                        es = lsu[lane];
+                        ei = liu[lane];
+                    }
                 }
                 const int p = __popcll(__ballot(lane < n && crh_better(es, ei, sc, gi)));
                 if (p < K) {
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 #pragma unroll
                     for (int u = 0; u < UW; ++u)
                         if (__ballot(m[u] > tau[u]) != 0ull)
-                            tile_slow_path_dma(acc[Q][u], tau[u], ls, li, cnt, K, 32 * u, slot0w + 32 * u, a, ts << 5,
+                            tile_slow_path_dma<sizeof(T) == 4 && DMA_ONE_TRIP_F32>(acc[Q][u], tau[u], ls, li, cnt, K, 32 * u, slot0w + 32 * u, a, ts << 5,
                                                split_end, lane, tb, rfilter);
                     // the list stores of the inserts are drained HERE: left pending, the compiler parks an lgkmcnt(0) at a
                     // later point of the common path, right behind the fragment reads of the barrier group
