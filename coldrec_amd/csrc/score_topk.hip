@@ -1231,8 +1231,8 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
     const int64_t n_waves = a.n_ugroups * a.n_splits;
     if (timing && !use_wg) CRH_HIP(hipMalloc(&a.wave_clock, (size_t)n_waves * 48));   // profile build only: [wave][start,end], [wave][loop start,end], [wave][event ticks,events]
     if (timing && use_dma) {   // DMA kernel: per-tile duration histograms of the first 16 workgroups' waves (64 buckets of 128 cycles)
-        CRH_HIP(hipMalloc(&a.wave_clock, (size_t)16 * 4 * 64 * 8));
-        CRH_HIP(hipMemsetAsync(a.wave_clock, 0, (size_t)16 * 4 * 64 * 8, st));
+        CRH_HIP(hipMalloc(&a.wave_clock, (size_t)16 * 4 * 66 * 8));    // + [wave][cycles in events, events]
+        CRH_HIP(hipMemsetAsync(a.wave_clock, 0, (size_t)16 * 4 * 66 * 8, st));
     }
 #endif
     if (ev_kernel_start) CRH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_kernel_start), st));
@@ -1254,9 +1254,15 @@ int score_topk_impl(int esz, const void* user_emb, const int32_t* users, int64_t
 #ifdef CRH_PROFILE
     if (timing && use_dma) {
         CRH_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)16 * 4 * 64);
+        std::vector<unsigned long long> h((size_t)16 * 4 * 66);
         CRH_HIP(hipMemcpy(h.data(), a.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));
         CRH_HIP(hipFree(a.wave_clock));
+        {
+            unsigned long long tk = 0, ne = 0;
+            for (int q = 0; q < 64; ++q) { tk += h[(size_t)16 * 4 * 64 + 2 * q]; ne += h[(size_t)16 * 4 * 64 + 2 * q + 1]; }
+            fprintf(stderr, "[crh dma timing] events: %.0f per wave, %.0f cycles each (tiles with at least one candidate; 64 waves)\n",
+                    (double)ne / 64.0, ne ? (double)tk / (double)ne : 0.0);
+        }
         for (int wv = 0; wv < 4; ++wv) {
             unsigned long long tot = 0, wsum = 0;
             std::vector<unsigned long long> b(64, 0);

@@ -438,6 +438,9 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
         } while (v < want);
     };
 
+#ifdef CRH_PROFILE
+    unsigned long long ev_ticks = 0, ev_count = 0;       // CRH_SCORE_TIMING
+#endif
     // body j: MFMAs of tile j (ring slot s_cur) into accumulator set P, threshold test of tile j-1 out of set 1-P;
     // s_nxt = slot of tile j+1, s_fill = slot of tile j + PF (barrier form: the slot tile j-1 left)
     auto body = [&](auto Pc, int j, int s_cur, int s_nxt, int s_fill) __attribute__((always_inline)) {
@@ -545,6 +548,9 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 #pragma unroll
                 for (int u = 0; u < UW; ++u) hitm |= __ballot(m[u] > tau[u]);
                 if (hitm != 0ull && live && j > 0 && !(CRH_ABLATE(a.ablate) & 1)) {
+#ifdef CRH_PROFILE
+                    const unsigned long long ev_t0 = a.wave_clock != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
                     const int64_t ts = t0 + j - 1;                                      // the tile being selected
                     const unsigned tb = has_bits ? tbits[((ts >> 6) & 1) * 64 + (ts & 63)] : 0u;
 #pragma unroll
@@ -555,6 +561,12 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
                     // the list stores of the inserts are drained HERE: left pending, the compiler parks an lgkmcnt(0) at a
                     // later point of the common path, right behind the fragment reads of the barrier group
                     __builtin_amdgcn_s_waitcnt(0xc07f);
+#ifdef CRH_PROFILE
+                    if (a.wave_clock != nullptr) {      // CRH_SCORE_TIMING: cycles spent in events and their number, per wave
+                        ev_ticks += __builtin_amdgcn_s_memtime() - ev_t0;
+                        ev_count += 1;
+                    }
+#endif
                 }
             }
         };
@@ -628,6 +640,12 @@ __global__ __launch_bounds__(256, 1) void score_topk_dma_kernel(ScoreArgs a) {
 #endif
     }
 
+#ifdef CRH_PROFILE
+    if (a.wave_clock != nullptr && blockIdx.x < 16 && lane == 0) {
+        a.wave_clock[(size_t)16 * 4 * 64 + ((size_t)blockIdx.x * 4 + wave) * 2] = ev_ticks;
+        a.wave_clock[(size_t)16 * 4 * 64 + ((size_t)blockIdx.x * 4 + wave) * 2 + 1] = ev_count;
+    }
+#endif
     if (live) {
         for (int j = 0; j < UPW; ++j) {
             const int64_t slot = slot0w + j;
