@@ -469,7 +469,10 @@ int crh_sampler_get_state(const crh_sampler* s, uint32_t* key624_host, int* pos_
 int crh_sampler_epoch_async(crh_sampler* s, int64_t batch_size, int32_t* user_out_host, int32_t* pos_out_host,
                             int32_t* neg_out_host, int snapshot_first);   /* != 0: crh_sampler_snapshot on the worker first */
 int crh_sampler_epoch_wait(crh_sampler* s);
-/* save / bring back everything an epoch call advances (generators + cumulative permutation): speculative sampling */
+/* save / bring back everything an epoch call advances (generators + cumulative permutation): speculative sampling.
+ * _snapshot copies no table: the crh_sampler_epoch that follows logs the targets of its swaps and _restore replays them
+ * backwards; anything else that moves the permutation under a snapshot turns it into a plain copy first.  _restore may be
+ * called again after further epochs: the snapshot stays armed until the next _snapshot. */
 int crh_sampler_snapshot(crh_sampler* s);
 int crh_sampler_restore(crh_sampler* s);
 int crh_sampler_epoch(crh_sampler* s, int64_t batch_size, int32_t* user_out_host,
