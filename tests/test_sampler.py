@@ -121,6 +121,36 @@ def test_large_record_set_matches_numpy_oracle():
     assert np.array_equal(k, key_np) and int(pos.value) == int(pos_np)
 
 
+def test_fuzz_small_and_odd_record_sets_against_numpy_oracle():
+    """Round 6's shuffle (two phases per window, AVX-512 or scalar accept list, swap log) and draws on the shapes the real-size
+    tests never see: one to a few hundred records, batches of 1 to 4 096, id spaces on both sides of the 16-bit limit of the
+    record-carrying permutation -- three epochs each, triple for triple against the NumPy oracle."""
+    rng = np.random.default_rng(20)
+    done = 0
+    for case in range(160):
+        n_u, n_i = int(rng.integers(1, 60)), int(rng.integers(2, 90))
+        if case % 7 == 0:
+            n_u = int(rng.integers(60000, 70000))
+        if case % 11 == 0:
+            n_i = int(rng.integers(65000, 66000))
+        n = int(rng.integers(1, 700))
+        ru, ri = rng.integers(0, min(n_u, 50), n), rng.integers(0, max(1, min(n_i, 80) - 1), n)
+        key = np.unique(ru.astype(np.int64) * n_i + ri)
+        rng.shuffle(key)
+        ru, ri = (key // n_i).astype(np.int32), (key % n_i).astype(np.int32)
+        B = int(rng.choice([1, 3, 16, 64, 512, 4096]))
+        s = PairwiseSampler(ru, ri, n_u, n_i)
+        o = orc.PairwiseSampler(ru, ri, n_i, n_u)
+        np.random.seed(int(rng.integers(0, 2 ** 31)))
+        s.pull_numpy_state()
+        for _ in range(3):
+            want = [np.concatenate(x) for x in zip(*o.epoch(B))]
+            for a, b in zip(s.epoch(B), want):
+                assert np.array_equal(a, b), (case, n_u, n_i, len(ru), B)
+        done += 1
+    assert done == 160
+
+
 def test_negatives_never_rated_and_speed():
     rng = np.random.default_rng(0)
     n_u, n_i, n = 2000, 3000, 300_000
