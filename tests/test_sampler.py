@@ -486,7 +486,7 @@ def test_scalar_compactions_when_avx512_is_switched_off():
     env = dict(os.environ, CRH_SAMPLER_NO_AVX512="1")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "golden_g1 or large_record_set or snapshot_restore or prefetcher"],
+                        "golden_g1 or large_record_set or snapshot_restore or prefetcher or fuzz_small"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "deselected" in r.stdout
