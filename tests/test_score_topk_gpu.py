@@ -517,6 +517,43 @@ def test_dma_kernel_equals_ring_kernel_on_a_long_stream(dtype, n_items, n_splits
             assert np.allclose(got_s[r][ok][~masked], raw[~masked], rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("d,form", [(128, "1"), (128, "3"), (64, "1")])
+def test_dma_kernel_events_under_ties_and_long_rated_lists(d, form, monkeypatch):
+    """The event path of the fp32 DMA kernel (one LDS round trip per candidate, round 6) where it is busiest: small-integer
+    embeddings (thousands of equal scores per user: every insert is decided by the item id, and thresholds tie with
+    candidates), rated lists of ~300 items (the membership filter hits all the time: the wave-wide search runs inside events)
+    and 30 % of the catalogue masked.  Flag form, barrier form and 256-byte rows against the kernel the library runs without
+    the DMA kernel, every user bit for bit, plus sampled users against the C oracle."""
+    from coldrec_amd import ops
+    rng = np.random.default_rng(1000 + d + int(form))
+    n_users, n_items, k = 32768 + 5, 70_001, 20
+    U = rng.integers(-2, 3, (n_users, d)).astype(np.float32)
+    V = rng.integers(-2, 3, (n_items, d)).astype(np.float32)
+    rated = [np.unique(rng.integers(0, n_items, 300)) for _ in range(n_users)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rated])]).astype(np.int64)
+    col = np.concatenate(rated).astype(np.int64)
+    cold = np.where(rng.random(n_items) < 0.3)[0]
+    dev = _dev()
+    tU, tV = torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev)
+    srp, src = orc.sort_rated(rowptr, col)
+    rp, rc = torch.from_numpy(srp).to(dev), torch.from_numpy(src).to(dev)
+    bm = ops.make_bitmap(n_items, cold, dev)
+    monkeypatch.setenv("CRH_SCORE_WG", "2")
+    monkeypatch.setenv("CRH_SCORE_DMA", form)
+    assert ops.score_topk_route(n_users, n_items, d, k, n_splits=1)["route"] == "fused-dma"
+    s1, i1 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=1)
+    monkeypatch.setenv("CRH_SCORE_DMA", "0")
+    s0, i0 = ops.score_topk(tU, None, tV, k, rp, rc, bm, n_splits=1)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i0) and torch.equal(s1.view(torch.int32), s0.view(torch.int32))
+    pick = np.concatenate([rng.choice(n_users, 12, replace=False), [0, n_users - 1, 32767, 32768]])
+    sub_rp = np.concatenate([[0], np.cumsum([len(rated[u]) for u in pick])]).astype(np.int64)
+    sub_col = np.concatenate([rated[u] for u in pick]).astype(np.int64)
+    ws, wi = _oracle(U, pick.astype(np.int64), V, k, sub_rp, sub_col, cold)
+    assert np.array_equal(i1.cpu().numpy()[pick], wi)
+    assert np.array_equal(s1.cpu().numpy()[pick].view(np.uint32), ws.view(np.uint32))
+
+
 @pytest.mark.parametrize("n_splits,n_items", [(1, 5003), (0, 5003), (1, 200_003)])
 def test_f32_workgroup_kernel_is_bit_exact(n_splits, n_items, monkeypatch):
     """fp32 d=128 launches with >= 512 user groups and >= 2 M items run the workgroup-cooperative kernel (packed tiles
